@@ -1,0 +1,351 @@
+"""
+oracle/golden_cases.py -- TEST INFRASTRUCTURE ONLY.
+
+Declarative list of parity cases for the render hot path.  A case is
+
+    {"name": str, "sr": int, "graph": SPEC, "blocks": [[start, n], ...]}
+
+and a SPEC is a nested dict {"pe": "<ClassName>", <ctor kwargs>}, where a kwarg may
+itself be a SPEC (PE-valued parameter), {"rng": seed, "n": N, "ch": C, "scale": s,
+"decay": tau} (deterministic pseudo-random float32 array -> ArrayPE input) or
+{"values": [...]} (literal array).  Enum-valued kwargs are plain strings.
+
+The same SPEC is interpreted three ways:
+  * oracle/gen_golden.py      -> the reference's own PE classes (golden outputs)
+  * oracle/graph_eval.py      -> the CPU oracle functions
+  * tests/spec_build.py       -> pygmu2_amd PE classes (the HIP product path)
+
+Blocks are rendered in order on one started graph, so contiguous blocks exercise the
+carried state and gaps exercise the reset-on-discontinuity rules.
+Case shapes follow SURVEY.md section 8(c) "golden vectors to capture".
+"""
+
+from __future__ import annotations
+
+
+def materialize_array(spec):
+    """Turn an array SPEC ({"values": ...} or {"rng": ...}) into a float32 ndarray."""
+    import numpy as np
+    if "values" in spec:
+        return np.asarray(spec["values"], dtype=np.float32)
+    rng = np.random.default_rng(int(spec["rng"]))
+    n, ch = int(spec["n"]), int(spec.get("ch", 1))
+    a = rng.standard_normal((n, ch)) * float(spec.get("scale", 1.0))
+    if "decay" in spec:
+        a = a * np.exp(-np.arange(n) / float(spec["decay"])).reshape(-1, 1)
+    return a.astype(np.float32)
+
+
+def S(pe, **kw):
+    d = {"pe": pe}
+    d.update(kw)
+    return d
+
+
+def blocks_contig(start, sizes):
+    out, pos = [], start
+    for n in sizes:
+        out.append([pos, n])
+        pos += n
+    return out
+
+
+ODD = [17, 23, 19, 41, 7, 93]          # tests/test_convolve_pe.py:153 chunk sizes
+
+
+def cases():
+    C = []
+
+    def add(name, sr, graph, blocks, keep=None):
+        # keep: indices of blocks whose output is stored in the fixture (default: all);
+        # every block is still rendered, in order, so state is carried through.
+        C.append({"name": name, "sr": sr, "graph": graph, "blocks": blocks,
+                  "keep": list(range(len(blocks))) if keep is None else list(keep)})
+
+    # ---------------------------------------------------------------- sources (bit-exact)
+    add("constant_stereo", 44100, S("ConstantPE", value=0.25, channels=2), [[-3, 9]])
+    add("identity_neg", 44100, S("IdentityPE", channels=2), [[-5, 12], [16777210, 12]])
+    add("dirac_window", 44100, S("DiracPE", channels=2), [[-2, 5], [1, 4], [0, 1]])
+    add("array_zero", 44100, S("ArrayPE", data={"values": [0.0, 0.5, 1.0, 0.5, -1.0]}),
+        [[-2, 10], [2, 2], [7, 3]])
+    add("array_hold_both", 44100,
+        S("ArrayPE", data={"values": [[1.0, -1.0], [0.5, 0.25], [2.0, 3.0]]}, extend_mode="hold_both"),
+        [[-3, 9], [5, 4], [-6, 2]])
+    add("crop_zero", 44100, S("CropPE", source=S("IdentityPE"), start=3, duration=4),
+        [[0, 10], [4, 2], [8, 3], [-4, 3]])
+    add("crop_hold", 44100,
+        S("CropPE", source=S("IdentityPE", channels=2), start=3, duration=4, extend_mode="hold_both"),
+        [[0, 10], [8, 3], [-4, 3]])
+    add("crop_open_end", 44100, S("CropPE", source=S("IdentityPE"), start=5, duration=None),
+        [[0, 10], [20, 3]])
+
+    # ---------------------------------------------------------------- SinePE pure
+    add("sine_kat", 44100, S("SinePE", frequency=440.0), [[0, 64]])
+    add("sine_late_stereo", 44100,
+        S("SinePE", frequency=440.0, amplitude=0.8, phase=0.3, channels=2),
+        [[441000, 2048], [-1000, 512], [44100 * 600, 1024]])
+    add("sine_lowfreq", 48000, S("SinePE", frequency=0.37, amplitude=2.0), [[0, 4096]])
+
+    # ---------------------------------------------------------------- SinePE stateful
+    fm = S("MixPE", inputs=[S("ConstantPE", value=440.0), S("SinePE", frequency=5.0, amplitude=50.0)])
+    add("sine_fm", 44100, S("SinePE", frequency=fm, amplitude=0.5),
+        blocks_contig(0, [1024, 1024, 17, 4096]))
+    add("sine_am_pm", 44100,
+        S("SinePE", frequency=220.0, amplitude=S("SinePE", frequency=3.0, amplitude=0.5),
+          phase=S("SinePE", frequency=110.0, amplitude=2.0), channels=2),
+        blocks_contig(0, [512, 2048]))
+    add("sine_fm_constphase_quirk", 44100, S("SinePE", frequency=fm, phase=0.5),
+        blocks_contig(0, [256, 256, 256]))
+
+    # ---------------------------------------------------------------- Gain / Mix
+    add("gain_const", 44100, S("GainPE", source=S("SinePE", frequency=440.0, channels=2), gain=0.5),
+        [[0, 1024], [1024, 1024]])
+    add("gain_const_third", 44100, S("GainPE", source=S("IdentityPE"), gain=1.0 / 3.0), [[0, 4096]])
+    add("gain_pe_mono_on_stereo", 44100,
+        S("GainPE", source=S("SinePE", frequency=440.0, channels=2), gain=S("SinePE", frequency=5.0)),
+        [[0, 4096]])
+    add("gain_pe_stereo", 44100,
+        S("GainPE", source=S("SinePE", frequency=440.0, channels=2),
+          gain=S("ArrayPE", data={"rng": 3, "n": 600, "ch": 2, "scale": 1.0})),
+        [[0, 512], [512, 512]])
+    add("mix3", 44100,
+        S("MixPE", inputs=[S("SinePE", frequency=440.0, amplitude=0.3),
+                           S("SinePE", frequency=550.0, amplitude=0.3),
+                           S("SinePE", frequency=660.0, amplitude=0.3)]),
+        [[0, 4096]])
+    add("mix_partial_extents", 44100,
+        S("MixPE", inputs=[S("CropPE", source=S("SinePE", frequency=440.0), start=0, duration=300),
+                           S("CropPE", source=S("SinePE", frequency=550.0), start=200, duration=300),
+                           S("ArrayPE", data={"rng": 5, "n": 100, "ch": 1, "scale": 0.5})]),
+        [[0, 256], [256, 256], [512, 64], [1000, 16]])
+    add("c1_hello_sine", 44100,
+        S("CropPE", start=0, duration=8 * 44100,
+          source=S("GainPE", gain=0.3,
+                   source=S("MixPE", inputs=[S("SinePE", frequency=440.0),
+                                             S("SinePE", frequency=550.0),
+                                             S("SinePE", frequency=660.0)]))),
+        [[0, 1024], [1024, 1024], [8 * 44100 - 512, 1024]])
+    add("c1_sine_gain", 44100,
+        S("GainPE", source=S("SinePE", frequency=440.0, amplitude=1.0, phase=0.0, channels=2), gain=0.5),
+        blocks_contig(0, [1024] * 4) + [[430 * 1024, 672]])
+
+    # ---------------------------------------------------------------- Biquad constant
+    noise2 = {"rng": 11, "n": 6000, "ch": 2, "scale": 0.5}
+    for mode in ("lowpass", "highpass", "bandpass", "notch", "allpass",
+                 "peaking", "lowshelf", "highshelf"):
+        add(f"biquad_const_{mode}", 44100,
+            S("BiquadPE", source=S("ArrayPE", data=noise2), frequency=1500.0, q=1.3,
+              mode=mode, gain_db=4.5),
+            blocks_contig(0, [1024, 1024, 17, 23, 19, 41, 7, 93, 2000]))
+    add("c2_biquad_sine", 44100,
+        S("BiquadPE", source=S("SinePE", frequency=440.0), frequency=1000.0, q=0.707, mode="lowpass"),
+        [[0, 16384]])
+    add("c2_biquad_sine_stream", 44100,
+        S("BiquadPE", source=S("SinePE", frequency=440.0), frequency=1000.0, q=0.707, mode="lowpass"),
+        blocks_contig(0, [1024] * 8))
+    add("biquad_highq", 48000,
+        S("BiquadPE", source=S("DiracPE"), frequency=300.0, q=100.0, mode="bandpass"),
+        blocks_contig(0, [8192, 8192]))
+    add("biquad_clamps", 48000,
+        S("BiquadPE", source=S("ArrayPE", data={"rng": 12, "n": 3000, "ch": 1, "scale": 0.5}),
+          frequency=90000.0, q=0.0001, mode="lowpass"),
+        blocks_contig(0, [3000]))
+
+    # ---------------------------------------------------------------- Biquad varying
+    add("biquad_var_freq", 44100,
+        S("BiquadPE", source=S("SinePE", frequency=440.0),
+          frequency=S("SinePE", frequency=5.0, amplitude=500.0), q=0.707, mode="lowpass"),
+        blocks_contig(0, [4096, 1024, 17, 2, 2000]))
+    add("biquad_var_q", 44100,
+        S("BiquadPE", source=S("SinePE", frequency=440.0, channels=2), frequency=1000.0,
+          q=S("SinePE", frequency=2.0, amplitude=1.0), mode="bandpass"),
+        blocks_contig(0, [4096, 4096]))
+    fsweep = S("MixPE", inputs=[S("ConstantPE", value=1200.0), S("SinePE", frequency=3.0, amplitude=900.0)])
+    for mode in ("highpass", "peaking", "lowshelf", "highshelf", "notch", "allpass"):
+        add(f"biquad_var_{mode}", 48000,
+            S("BiquadPE", source=S("ArrayPE", data=noise2), frequency=fsweep,
+              q=S("MixPE", inputs=[S("ConstantPE", value=2.0), S("SinePE", frequency=1.0, amplitude=1.5)]),
+              mode=mode, gain_db=-6.0),
+            blocks_contig(0, [3000, 3000]))
+
+    # ---------------------------------------------------------------- BlitSaw
+    add("blitsaw_kat", 44100, S("BlitSawPE", frequency=440.0), blocks_contig(0, [4096]))
+    add("blitsaw_chunked", 44100, S("BlitSawPE", frequency=440.0),
+        blocks_contig(0, [1024, 1024] + ODD + [1848]))
+    add("blitsaw_m20_stereo", 48000,
+        S("BlitSawPE", frequency=110.0, amplitude=0.7, initial_phase=0.25, m=20, leak=0.995, channels=2),
+        blocks_contig(100, [2048, 2048]))
+    add("blitsaw_gap_reset", 44100, S("BlitSawPE", frequency=220.0, initial_phase=1.75),
+        [[0, 1024], [1024, 1024], [5000, 1024], [6024, 512]])
+    add("blitsaw_fm", 44100,
+        S("BlitSawPE", frequency=S("MixPE", inputs=[S("ConstantPE", value=200.0),
+                                                     S("SinePE", frequency=4.0, amplitude=120.0)]),
+          amplitude=S("MixPE", inputs=[S("ConstantPE", value=0.6), S("SinePE", frequency=2.0, amplitude=0.3)])),
+        blocks_contig(0, [4096, 4096]))
+    add("blitsaw_m_pe", 44100,
+        S("BlitSawPE", frequency=330.0,
+          m=S("MixPE", inputs=[S("ConstantPE", value=12.0), S("SinePE", frequency=2.0, amplitude=10.0)])),
+        blocks_contig(0, [4096]))
+    add("blitsaw_low_high", 48000, S("BlitSawPE", frequency=27.5), blocks_contig(0, [8192]))
+    add("blitsaw_high", 48000, S("BlitSawPE", frequency=9000.0), blocks_contig(0, [2048]))
+    add("blitsaw_late", 48000, S("BlitSawPE", frequency=440.0), blocks_contig(0, [30000, 30000, 4096]),
+        keep=[2])
+
+    # ---------------------------------------------------------------- SuperSaw
+    add("supersaw_kat", 44100, S("SuperSawPE", frequency=440.0, voices=7, seed=1234),
+        blocks_contig(0, [4096]))
+    for mm in ("equal", "linear", "center_heavy"):
+        add(f"supersaw_{mm}_6v", 48000,
+            S("SuperSawPE", frequency=110.0, amplitude=0.8, voices=6, detune_cents=35.0,
+              mix_mode=mm, channels=2, seed=7),
+            blocks_contig(0, [1024, 1024, 93]))
+    add("supersaw_nophase_3v", 44100,
+        S("SuperSawPE", frequency=220.0, voices=3, randomize_phase=False),
+        blocks_contig(0, [2048]))
+    add("supersaw_1v", 44100, S("SuperSawPE", frequency=220.0, voices=1, seed=3), blocks_contig(0, [1024]))
+    add("supersaw_freq_pe", 44100,
+        S("SuperSawPE", frequency=S("MixPE", inputs=[S("ConstantPE", value=300.0),
+                                                      S("SinePE", frequency=3.0, amplitude=40.0)]),
+          amplitude=S("SinePE", frequency=1.0, amplitude=0.9), voices=5, seed=99),
+        blocks_contig(0, [2048, 2048]))
+
+    # ---------------------------------------------------------------- Ladder
+    saw = S("SuperSawPE", frequency=110.0, voices=7, detune_cents=20.0, seed=0)
+    for mode in ("lp24", "lp12", "bp24", "bp12", "hp24", "hp12"):
+        add(f"ladder_{mode}", 48000,
+            S("LadderPE", source=S("ArrayPE", data=noise2), frequency=1200.0, resonance=0.3,
+              mode=mode, drive=1.0, oversample=2),
+            blocks_contig(0, [1024, 1024, 17, 983]))
+    add("ladder_dc_kat", 44100,
+        S("LadderPE", source=S("ConstantPE", value=1.0), frequency=1000.0, resonance=0.0),
+        blocks_contig(0, [4096]))
+    add("ladder_res09_drive", 48000,
+        S("LadderPE", source=saw, frequency=800.0, resonance=0.9, mode="lp24", drive=2.5, oversample=4),
+        blocks_contig(0, [2048, 2048]))
+    add("ladder_os1_pbg", 48000,
+        S("LadderPE", source=S("ArrayPE", data=noise2), frequency=3000.0, resonance=0.6,
+          mode="bp12", drive=0.5, passband_gain=0.2, oversample=1),
+        blocks_contig(0, [3000]))
+    add("ladder_silence_decay", 48000,
+        S("LadderPE", source=S("ArrayPE", data={"rng": 21, "n": 600, "ch": 2, "scale": 0.8}),
+          frequency=500.0, resonance=0.5),
+        blocks_contig(0, [512, 512, 512]))
+    add("ladder_mod", 48000,
+        S("LadderPE", source=saw,
+          frequency=S("MixPE", inputs=[S("ConstantPE", value=1500.0), S("SinePE", frequency=2.0, amplitude=1400.0)]),
+          resonance=S("MixPE", inputs=[S("ConstantPE", value=0.5), S("SinePE", frequency=0.5, amplitude=0.7)]),
+          drive=S("MixPE", inputs=[S("ConstantPE", value=2.0), S("SinePE", frequency=1.0, amplitude=2.5)]),
+          mode="lp24"),
+        blocks_contig(0, [4096, 4096]))
+    add("c4_voice", 48000,
+        S("MixPE", inputs=[
+            S("LadderPE", source=S("SuperSawPE", frequency=55.0 * 2 ** (i / 12.0), voices=7,
+                                    detune_cents=20.0, seed=i),
+              frequency=1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2)
+            for i in range(3)]),
+        blocks_contig(0, [4096, 4096]))
+
+    # ---------------------------------------------------------------- Comb
+    add("comb_kat", 44100,
+        S("CombPE", source=S("ConstantPE", value=0.25, channels=2), frequency=440.0, feedback=0.7),
+        blocks_contig(0, [512]))
+    add("comb_sine_chunked", 48000,
+        S("CombPE", source=S("SinePE", frequency=330.0), frequency=220.0, feedback=-0.9),
+        blocks_contig(0, [1024, 1024] + ODD + [2000]))
+    add("comb_sweep", 48000,
+        S("CombPE", source=S("ArrayPE", data=noise2),
+          frequency=S("MixPE", inputs=[S("ConstantPE", value=400.0), S("SinePE", frequency=3.0, amplitude=380.0)]),
+          feedback=S("SinePE", frequency=1.0, amplitude=1.5), min_frequency=30.0, smoothing_samples=200),
+        blocks_contig(0, [3000, 3000]))
+    add("comb_high_freq", 48000,
+        S("CombPE", source=S("ArrayPE", data=noise2), frequency=30000.0, feedback=0.99, smoothing_samples=1),
+        blocks_contig(0, [2048]))
+    add("comb_step", 48000,
+        S("CombPE", source=S("ArrayPE", data=noise2),
+          frequency=S("ArrayPE", data={"values": [100.0] * 1000 + [1000.0] * 3000}, extend_mode="hold_last"),
+          feedback=0.8, smoothing_samples=480),
+        blocks_contig(0, [2500, 2500]))
+
+    # ---------------------------------------------------------------- gates / ADSR (bit-exact)
+    add("periodic_gate", 48000, S("PeriodicGate", frequency=2.0, duty_cycle=0.5),
+        [[0, 48000 // 4], [48000 * 100, 4096], [-5000, 4096]])
+    add("periodic_gate_odd", 44100, S("PeriodicGate", frequency=7.3, duty_cycle=0.31, phase=0.4),
+        [[0, 20000], [44100 * 1000 + 17, 4096]])
+    add("periodic_trigger", 44100, S("PeriodicTrigger", hz=7.0, phase=0.25, amplitude=2),
+        [[0, 20000], [-9000, 9000], [44100 * 3000, 8000]])
+    g1 = {"values": [1.0] * 500 + [0.0] * 500}
+    add("adsr_full_cycle", 1000,
+        S("AdsrGatedPE", gate=S("ArrayPE", data=g1), attack_time=0.010, decay_time=0.020,
+          sustain_level=0.5, release_time=0.030),
+        blocks_contig(0, [1000]))
+    add("adsr_early_release_chunked", 1000,
+        S("AdsrGatedPE", gate=S("ArrayPE", data={"values": [1.0] * 5 + [0.0] * 100 + [1.0] * 12 + [0.0] * 3 + [1.0] * 200 + [0.0] * 80}),
+          attack_time=0.010, decay_time=0.020, sustain_level=0.5, release_time=0.030),
+        blocks_contig(0, [7, 93, 19, 41, 240]))
+    add("adsr_bad_gate_values", 1000,
+        S("AdsrGatedPE", gate=S("ArrayPE", data={"values": [0.0, 0.5, 1.0, 1.0, 0.5, 0.0, 1.0, 1.0, 0.0, 0.0] * 8}),
+          attack_time=0.004, decay_time=0.003, sustain_level=0.25, release_time=0.002),
+        blocks_contig(0, [80]))
+    add("adsr_periodic_gate", 48000,
+        S("AdsrGatedPE", gate=S("PeriodicGate", frequency=2.03, duty_cycle=0.5),
+          attack_time=0.01, decay_time=0.1, sustain_level=0.7, release_time=0.2),
+        blocks_contig(0, [16384, 16384, 16384]))
+    add("adsr_sustain_edges", 48000,
+        S("AdsrGatedPE", gate=S("PeriodicGate", frequency=5.0, duty_cycle=0.9),
+          attack_time=0.02, decay_time=0.02, sustain_level=1.0, release_time=0.005),
+        blocks_contig(0, [20000]))
+    add("adsr_triggered", 1000,
+        S("AdsrTriggeredPE", trigger=S("PeriodicTrigger", hz=2.0), attack_time=0.010, decay_time=0.020,
+          sustain_time=0.1, sustain_level=0.5, release_time=0.030),
+        blocks_contig(0, [300, 300, 17, 883]))
+    add("adsr_triggered_retrigger", 1000,
+        S("AdsrTriggeredPE", trigger=S("PeriodicTrigger", hz=25.0, phase=0.5), attack_time=0.030,
+          decay_time=0.020, sustain_time=0.005, sustain_level=0.6, release_time=0.050),
+        blocks_contig(-100, [500, 500]))
+
+    # ---------------------------------------------------------------- C5 voice graph
+    def c5_voice(i):
+        return S("GainPE",
+                 source=S("BiquadPE", source=S("BlitSawPE", frequency=27.5 * 2 ** (i / 48.0)),
+                          frequency=2000.0, q=0.707),
+                 gain=S("AdsrGatedPE", gate=S("PeriodicGate", frequency=2.0 + 0.01 * i, duty_cycle=0.5),
+                        attack_time=0.01, decay_time=0.1, sustain_level=0.7, release_time=0.2))
+    add("c5_one_voice", 48000, c5_voice(100), blocks_contig(0, [8192, 8192]))
+    add("c5_mix4", 48000, S("MixPE", inputs=[c5_voice(i) for i in (0, 171, 342, 511)]),
+        blocks_contig(0, [8192, 8192]))
+
+    # ---------------------------------------------------------------- Convolve
+    add("conv_kat", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"values": [1.0, 2.0, 3.0, 4.0]}),
+          fir=S("ArrayPE", data={"values": [1.0, 0.5, -1.0]}), fft_size=16),
+        [[0, 6]])
+    add("conv_identity", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 0, "n": 256, "ch": 1, "scale": 1.0}),
+          fir=S("ArrayPE", data={"values": [1.0]}), fft_size=64),
+        [[0, 256]])
+    add("conv_stereo_src_mono_fir", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 1, "n": 200, "ch": 2, "scale": 1.0}),
+          fir=S("ArrayPE", data={"rng": 2, "n": 33, "ch": 1, "scale": 1.0}), fft_size=128),
+        [[0, 232]])
+    add("conv_mono_src_stereo_fir", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 3, "n": 200, "ch": 1, "scale": 1.0}),
+          fir=S("ArrayPE", data={"rng": 4, "n": 33, "ch": 2, "scale": 1.0}), fft_size=128),
+        [[0, 232]])
+    add("conv_stereo_stereo_chunked", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 5, "n": 200, "ch": 2, "scale": 1.0}),
+          fir=S("ArrayPE", data={"rng": 6, "n": 33, "ch": 2, "scale": 1.0}), fft_size=64),
+        blocks_contig(0, ODD + [32]))
+    add("conv_default_fft", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 7, "n": 3000, "ch": 1, "scale": 1.0}),
+          fir=S("ArrayPE", data={"rng": 8, "n": 129, "ch": 1, "scale": 1.0})),
+        blocks_contig(0, [1000, 2128]))
+    add("conv_gap_clears_history", 10000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 9, "n": 600, "ch": 2, "scale": 1.0}),
+          fir=S("ArrayPE", data={"rng": 10, "n": 65, "ch": 1, "scale": 1.0}), fft_size=256),
+        [[0, 100], [100, 100], [300, 100], [400, 264], [-50, 120]])
+    add("c3_reduced", 48000,
+        S("ConvolvePE", src=S("ArrayPE", data={"rng": 0, "n": 12000, "ch": 2, "scale": 0.1}),
+          fir=S("ArrayPE", data={"rng": 1, "n": 4096, "ch": 1, "scale": 1.0, "decay": 500.0}),
+          fft_size=8192),
+        blocks_contig(0, [4097, 4097, 3806, 4095]))
+    return C

@@ -1,0 +1,296 @@
+"""
+oracle/graph_eval.py -- TEST INFRASTRUCTURE ONLY.
+
+Evaluates a golden-case SPEC (see oracle/golden_cases.py) on the CPU by composing the
+oracle functions of oracle/pe_oracle.py with the reference's pull semantics: every
+node renders exactly `n` frames for (start, n); MixPE skips inputs whose extent
+misses the window (mix_pe.py:81-85); windowing nodes zero-fill / hold outside their
+extent.  This is glue only -- all arithmetic lives in pe_oracle.py.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import pe_oracle as O
+from .golden_cases import materialize_array
+
+INF = (None, None)
+
+
+def _isect(a, b):
+    """extent.py:124-161 on (start, end) tuples; empty -> (x, x)."""
+    if a[0] is not None and a[0] == a[1]:
+        return (a[0], a[0])
+    if b[0] is not None and b[0] == b[1]:
+        return (b[0], b[0])
+    s = b[0] if a[0] is None else (a[0] if b[0] is None else max(a[0], b[0]))
+    e = b[1] if a[1] is None else (a[1] if b[1] is None else min(a[1], b[1]))
+    if s is not None and e is not None and s > e:
+        return (s, s)
+    return (s, e)
+
+
+def _empty(a):
+    return a[0] is not None and a[1] is not None and a[0] == a[1]
+
+
+def _union(a, b):
+    if _empty(a):
+        return b
+    if _empty(b):
+        return a
+    s = None if (a[0] is None or b[0] is None) else min(a[0], b[0])
+    e = None if (a[1] is None or b[1] is None) else max(a[1], b[1])
+    return (s, e)
+
+
+def _intersects(a, b):
+    if _empty(a) or _empty(b):
+        return False
+    if a[1] is not None and b[0] is not None and a[1] <= b[0]:
+        return False
+    if b[1] is not None and a[0] is not None and b[1] <= a[0]:
+        return False
+    return True
+
+
+class Node:
+    def __init__(self, spec, sr):
+        self.spec = spec
+        self.sr = sr
+        self.kind = spec["pe"]
+        self.kw = {k: v for k, v in spec.items() if k != "pe"}
+        self.sub = {}
+        for k, v in self.kw.items():
+            if isinstance(v, dict) and "pe" in v:
+                self.sub[k] = Node(v, sr)
+            elif k == "inputs":
+                self.sub[k] = [Node(s, sr) for s in v]
+        if self.kind == "ArrayPE":
+            self.array = materialize_array(self.kw["data"])
+            if self.array.ndim == 1:
+                self.array = self.array.reshape(-1, 1)
+        self.reset()
+
+    # ------------------------------------------------------------------ state
+    def reset(self):
+        k, kw = self.kind, self.kw
+        self.state = None
+        if k == "SinePE":
+            self.state = O.sine_state()
+        elif k == "BlitSawPE":
+            self.state = O.blitsaw_state(kw.get("initial_phase", 0.0))
+        elif k == "SuperSawPE":
+            if getattr(self, "_ss_proto", None) is None:
+                # the RNG is consumed once, at construction (super_saw_pe.py:98,244-249)
+                self._ss_proto = O.supersaw_params(kw.get("voices", 7), kw.get("detune_cents", 20.0),
+                                                   kw.get("mix_mode", "center_heavy"),
+                                                   kw.get("randomize_phase", True), kw.get("seed"))
+            r, g, p = self._ss_proto
+            self.state = {"ratios": r, "gains": g, "osc": [O.blitsaw_state(x) for x in p]}
+        elif k in ("BiquadPE", "LadderPE", "CombPE"):
+            self.state = None          # lazily sized by channel count
+        elif k in ("AdsrGatedPE", "AdsrTriggeredPE"):
+            self.state = O.adsr_state()
+        elif k == "ConvolvePE":
+            self.state = O.convolve_state()
+        for s in self.sub.values():
+            for n in (s if isinstance(s, list) else [s]):
+                n.reset()
+
+    # ------------------------------------------------------------------ static info
+    def channels(self):
+        k, kw = self.kind, self.kw
+        if k in ("ConstantPE", "IdentityPE", "DiracPE", "SinePE", "BlitSawPE", "SuperSawPE"):
+            return int(kw.get("channels", 1))
+        if k == "ArrayPE":
+            return self.array.shape[1]
+        if k in ("PeriodicGate", "PeriodicTrigger", "AdsrGatedPE", "AdsrTriggeredPE"):
+            return 1
+        if k == "MixPE":
+            return self.sub["inputs"][0].channels()
+        if k == "ConvolvePE":
+            sc, fc = self.sub["src"].channels(), self.sub["fir"].channels()
+            return sc if fc == 1 else (fc if sc == 1 else sc)
+        return self.sub["source"].channels()
+
+    def extent(self):
+        k, kw = self.kind, self.kw
+        if k == "ArrayPE":
+            return (0, self.array.shape[0])
+        if k == "CropPE":
+            s = int(kw["start"])
+            e = None if kw.get("duration") is None else s + int(kw["duration"])
+            return _isect((s, e), self.sub["source"].extent())
+        if k == "MixPE":
+            ext = self.sub["inputs"][0].extent()
+            for n in self.sub["inputs"][1:]:
+                ext = _union(ext, n.extent())
+            return ext
+        if k == "GainPE":
+            ext = self.sub["source"].extent()
+            if "gain" in self.sub:
+                ext = _isect(ext, self.sub["gain"].extent())
+            return ext
+        if k in ("BiquadPE", "CombPE"):
+            ext = self.sub["source"].extent()
+            for name in ("frequency", "q", "feedback"):
+                if name in self.sub:
+                    i = _isect(ext, self.sub[name].extent())
+                    ext = ext if _empty(i) else i
+            return ext
+        if k == "LadderPE":
+            ext = self.sub["source"].extent()
+            for name in ("frequency", "resonance", "drive"):
+                if name in self.sub:
+                    ext = _isect(ext, self.sub[name].extent())
+            return ext
+        if k == "AdsrGatedPE":
+            return self.sub["gate"].extent()
+        if k == "AdsrTriggeredPE":
+            return self.sub["trigger"].extent()
+        if k == "ConvolvePE":
+            se = self.sub["src"].extent()
+            L = self.sub["fir"].extent()[1]
+            return (se[0], None if se[1] is None else se[1] + L - 1)
+        if k in ("SinePE", "BlitSawPE", "SuperSawPE", "PeriodicGate"):
+            ext = INF
+            for name in ("frequency", "amplitude", "phase", "m", "duty_cycle"):
+                if name in self.sub:
+                    ext = _isect(ext, self.sub[name].extent())
+            return ext
+        return INF
+
+    def _param(self, name, start, n, default=None):
+        """Scalar, or the float32 (N,C) render of a PE-valued parameter."""
+        if name in self.sub:
+            return self.sub[name].render(start, n)
+        return self.kw.get(name, default)
+
+    # ------------------------------------------------------------------ render
+    def render(self, start, n):
+        k, kw, sr = self.kind, self.kw, self.sr
+        if n == 0:
+            return np.zeros((0, self.channels()), dtype=np.float32)
+        if k == "ConstantPE":
+            return O.constant(n, kw["value"], kw.get("channels", 1))
+        if k == "IdentityPE":
+            return O.identity(start, n, kw.get("channels", 1))
+        if k == "DiracPE":
+            return O.dirac(start, n, kw.get("channels", 1))
+        if k == "ArrayPE":
+            em = kw.get("extend_mode", "zero")
+            return O.array_window(self.array, start, n,
+                                  hold_first=em in ("hold_first", "hold_both"),
+                                  hold_last=em in ("hold_last", "hold_both"))
+        if k == "CropPE":
+            return self._crop(start, n)
+        if k == "SinePE":
+            if not self.sub:
+                return O.sine_pure(start, n, kw.get("frequency", 440.0), kw.get("amplitude", 1.0),
+                                   kw.get("phase", 0.0), sr, kw.get("channels", 1))
+            return O.sine_stateful(self.state, n, self._param("frequency", start, n, 440.0),
+                                   self._param("amplitude", start, n, 1.0),
+                                   self._param("phase", start, n, 0.0), sr, kw.get("channels", 1))
+        if k == "GainPE":
+            x = self.sub["source"].render(start, n)
+            if "gain" in self.sub:
+                return O.gain_vec(x, self.sub["gain"].render(start, n))
+            return O.gain_const(x, kw.get("gain", 1.0))
+        if k == "MixPE":
+            req = (start, start + n)
+            rendered = [c.render(start, n) for c in self.sub["inputs"] if _intersects(c.extent(), req)]
+            if not rendered:
+                return np.zeros((n, self.channels()), dtype=np.float32)
+            return O.mix(rendered)
+        if k == "BiquadPE":
+            x = self.sub["source"].render(start, n)
+            if self.state is None or self.state["zi"].shape[1] != x.shape[1]:
+                self.state = O.biquad_state(x.shape[1])
+            f = self._param("frequency", start, n)
+            q = self._param("q", start, n)
+            mode, gdb = kw.get("mode", "lowpass"), kw.get("gain_db", 0.0)
+            if "frequency" in self.sub or "q" in self.sub:
+                return O.biquad_varying(self.state, x, f, q, mode, gdb, sr)
+            return O.biquad_const(self.state, x, f, q, mode, gdb, sr)
+        if k == "BlitSawPE":
+            return O.blitsaw(self.state, start, n, self._param("frequency", start, n),
+                             self._param("amplitude", start, n, 1.0), self._param("m", start, n, None),
+                             kw.get("leak", 0.999), sr, kw.get("channels", 1))
+        if k == "SuperSawPE":
+            return O.supersaw(self.state, start, n, self._param("frequency", start, n),
+                              self._param("amplitude", start, n, 1.0), sr, kw.get("channels", 1))
+        if k == "LadderPE":
+            x = self.sub["source"].render(start, n)
+            if self.state is None or self.state["z0"].shape[0] != x.shape[1]:
+                self.state = O.ladder_state(x.shape[1])
+            return O.ladder(self.state, x, self._param("frequency", start, n),
+                            self._param("resonance", start, n, 0.0), kw.get("mode", "lp24"),
+                            self._param("drive", start, n, 1.0), kw.get("passband_gain", 0.5),
+                            kw.get("oversample", 2), sr)
+        if k == "CombPE":
+            x = self.sub["source"].render(start, n)
+            if self.state is None or self.state["buf"].shape[1] != x.shape[1]:
+                self.state = O.comb_state(x.shape[1], sr, kw.get("min_frequency", 20.0))
+            return O.comb(self.state, x, self._param("frequency", start, n),
+                          self._param("feedback", start, n, 0.0), kw.get("min_frequency", 20.0),
+                          kw.get("smoothing_samples", 2400), sr)
+        if k == "PeriodicGate":
+            return O.periodic_gate(start, n, kw.get("frequency", 1.0), kw.get("duty_cycle", 0.5),
+                                   kw.get("phase", 0.0), sr)
+        if k == "PeriodicTrigger":
+            return O.periodic_trigger(start, n, kw["hz"], kw.get("phase", 0.0), kw.get("amplitude", 1), sr)
+        if k == "AdsrGatedPE":
+            g = self.sub["gate"].render(start, n)
+            return O.adsr_gated(self.state, g, kw.get("attack_time", 0.1), kw.get("decay_time", 0.1),
+                                kw.get("sustain_level", 0.5), kw.get("release_time", 0.1), sr)
+        if k == "AdsrTriggeredPE":
+            t = self.sub["trigger"].render(start, n)
+            return O.adsr_triggered(self.state, t, start, kw.get("attack_time", 0.1),
+                                    kw.get("decay_time", 0.1), kw.get("sustain_time", 0.5),
+                                    kw.get("sustain_level", 0.5), kw.get("release_time", 0.1), sr)
+        if k == "ConvolvePE":
+            if "h" not in self.state:
+                L = self.sub["fir"].extent()[1]
+                self.state["h"] = self.sub["fir"].render(0, L)
+            x = self.sub["src"].render(start, n)
+            return O.convolve(self.state, start, x, self.state["h"], kw.get("fft_size"))
+        raise KeyError(f"oracle graph_eval: unknown PE kind {k}")
+
+    def _crop(self, start, n):
+        """extent_window_pe.py:88-157 (CropPE)."""
+        kw = self.kw
+        src = self.sub["source"]
+        cs = int(kw["start"])
+        ce = None if kw.get("duration") is None else cs + int(kw["duration"])
+        em = kw.get("extend_mode", "zero")
+        hf = em in ("hold_first", "hold_both")
+        hl = em in ("hold_last", "hold_both")
+        end = start + n
+        lo = max(start, cs)
+        hi = end if ce is None else min(end, ce)
+        ch = src.channels()
+        if lo >= hi or end <= cs or (ce is not None and start >= ce):
+            data = np.zeros((n, ch), dtype=np.float32)
+            if end <= cs and hf:
+                data[:, :] = src.render(cs, 1)[0:1, :]
+            elif ce is not None and start >= ce and hl and ce > 0:
+                data[:, :] = src.render(ce - 1, 1)[0:1, :]
+            return data
+        seg = src.render(lo, hi - lo)
+        data = np.zeros((n, seg.shape[1]), dtype=np.float32)
+        if start < cs and hf:
+            data[:cs - start, :] = src.render(cs, 1)[0:1, :]
+        data[lo - start:hi - start, :] = seg
+        if ce is not None and end > ce and hl and ce > 0:
+            a = ce - start
+            if a < n:
+                data[a:, :] = src.render(ce - 1, 1)[0:1, :]
+        return data
+
+
+def run_case(case):
+    """Render every block of a golden case through the oracle; returns list of arrays."""
+    g = Node(case["graph"], case["sr"])
+    return [g.render(int(s), int(n)) for s, n in case["blocks"]]

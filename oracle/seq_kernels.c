@@ -1,0 +1,280 @@
+/*
+ * oracle/seq_kernels.c -- TEST INFRASTRUCTURE ONLY (parity oracle + CPU baseline).
+ *
+ * Plain-C scalar restatement of the strictly sequential per-sample loops that the
+ * reference runs through numba (or a Python fallback).  Nothing under pygmu2_amd/
+ * may link, import or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it (through oracle/pe_oracle.py).
+ *
+ * Compile with -O2 -ffp-contract=off so that every float64 operation is rounded
+ * exactly like the reference's scalar Python / numba arithmetic (no FMA fusion).
+ *
+ * Each function cites the reference code it follows (paths relative to
+ * /root/reference/src/pygmu2/).
+ */
+#include <math.h>
+#include <stdint.h>
+
+/* ---------------------------------------------------------------------------
+ * Time-varying biquad, direct form I.  Follows biquad_pe.py:35-62
+ * (_biquad_varying_numba).  x, y are (n, c) row-major float64; b0..a2 are (n,);
+ * x1,x2,y1,y2 are (c,) state vectors updated in place.
+ */
+void orc_biquad_varying(const double *x, double *y, int64_t n, int c,
+                        const double *b0, const double *b1, const double *b2,
+                        const double *a1, const double *a2,
+                        double *x1, double *x2, double *y1, double *y2)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        for (int ch = 0; ch < c; ++ch) {
+            double xin = x[i * c + ch];
+            double y0 = (b0[i] * xin + b1[i] * x1[ch] + b2[i] * x2[ch]
+                         - a1[i] * y1[ch] - a2[i] * y2[ch]);
+            y[i * c + ch] = y0;
+            x2[ch] = x1[ch];
+            x1[ch] = xin;
+            y2[ch] = y1[ch];
+            y1[ch] = y0;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * Moog ladder.  Follows ladder_pe.py:31-203 (_ladder_process_numba).
+ * z0, z1 are (c, 4) row-major, old_input is (c,); all updated in place.
+ */
+void orc_ladder(const double *x, double *y, int64_t n, int c,
+                const double *freq, const double *resonance, const double *drive,
+                double *z0, double *z1, double *old_input,
+                double sample_rate, double passband_gain, int oversample,
+                int mode_index, double state_decay, double input_threshold,
+                double resonance_multiplier)
+{
+    const double two_pi = 2.0 * 3.141592653589793;
+    double oversample_recip = 1.0 / (double)oversample;
+    double min_cutoff = 5.0;
+    double nyquist = sample_rate / 2.0;
+    double max_cutoff = nyquist * 0.85;
+    if (max_cutoff > nyquist - 1.0) max_cutoff = nyquist - 1.0;
+
+    for (int64_t i = 0; i < n; ++i) {
+        double cutoff = freq[i];
+        if (cutoff < min_cutoff) cutoff = min_cutoff;
+        if (cutoff > max_cutoff) cutoff = max_cutoff;
+
+        double wc = cutoff * two_pi / (sample_rate * (double)oversample);
+        double wc2 = wc * wc;
+        double wc3 = wc2 * wc;
+        double wc4 = wc3 * wc;
+        double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
+        double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
+
+        double res = resonance[i];
+        if (res < 0.0) res = 0.0;
+        if (res > 1.0) res = 1.0;
+        double k = 4.0 * res * resonance_multiplier;
+
+        double drv = drive[i];
+        double drive_scaled;
+        if (drv < 0.0) drv = 0.0;
+        if (drv > 1.0) {
+            if (drv > 4.0) drv = 4.0;
+            drive_scaled = 1.0 + (drv - 1.0) * (1.0 - passband_gain);
+        } else {
+            drive_scaled = drv;
+        }
+
+        for (int ch = 0; ch < c; ++ch) {
+            double *a0 = z0 + ch * 4;
+            double *a1 = z1 + ch * 4;
+            double input_sample = x[i * c + ch] * drive_scaled;
+            double input_abs = input_sample >= 0.0 ? input_sample : -input_sample;
+            if (input_abs < input_threshold) {
+                for (int s = 0; s < 4; ++s) {
+                    a0[s] *= state_decay;
+                    a1[s] *= state_decay;
+                }
+                old_input[ch] *= state_decay;
+            }
+            double total = 0.0;
+            double interp = 0.0;
+            for (int os = 0; os < oversample; ++os) {
+                double in_interp = interp * old_input[ch] + (1.0 - interp) * input_sample;
+                double u = tanh(in_interp - (a1[3] - passband_gain * in_interp) * k * q_adjust);
+                double ft, stage1, stage2, stage3, stage4, weighted;
+
+                ft = u * 0.76923077 + 0.23076923 * a0[0] - a1[0];
+                ft = ft * alpha + a1[0];
+                a1[0] = ft; a0[0] = u; stage1 = ft;
+
+                ft = stage1 * 0.76923077 + 0.23076923 * a0[1] - a1[1];
+                ft = ft * alpha + a1[1];
+                a1[1] = ft; a0[1] = stage1; stage2 = ft;
+
+                ft = stage2 * 0.76923077 + 0.23076923 * a0[2] - a1[2];
+                ft = ft * alpha + a1[2];
+                a1[2] = ft; a0[2] = stage2; stage3 = ft;
+
+                ft = stage3 * 0.76923077 + 0.23076923 * a0[3] - a1[3];
+                ft = ft * alpha + a1[3];
+                a1[3] = ft; a0[3] = stage3; stage4 = ft;
+
+                switch (mode_index) {
+                case 0: weighted = stage4; break;
+                case 1: weighted = stage2; break;
+                case 2: weighted = (stage2 + stage4) * 4.0 - stage3 * 8.0; break;
+                case 3: weighted = (stage1 - stage2) * 2.0; break;
+                case 4: weighted = u + stage4 - (stage1 + stage3) * 4.0 + stage2 * 6.0; break;
+                default: weighted = u + stage2 - stage1 * 2.0; break;
+                }
+                total += weighted * oversample_recip;
+                interp += oversample_recip;
+            }
+            old_input[ch] = input_sample;
+            y[i * c + ch] = total;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * Feedback comb.  Follows comb_pe.py:26-113 (_comb_process_numba).
+ * buffer is (buffer_len, c) row-major; *write_pos and *smoothed_freq are the
+ * carried scalars.  np.round is round-half-to-even == rint() in the default
+ * rounding mode.
+ */
+void orc_comb(const double *x, double *y, int64_t n, int c,
+              const double *freq_values, const double *fb_values,
+              double *buffer, int64_t buffer_len,
+              int64_t *write_pos_io, double *smoothed_freq_io,
+              double sample_rate, double min_frequency, int64_t smoothing_samples,
+              double max_feedback)
+{
+    int64_t write_pos = *write_pos_io;
+    double smoothed_freq = *smoothed_freq_io;
+    double smooth_alpha = 1.0 / (double)smoothing_samples;
+
+    for (int64_t i = 0; i < n; ++i) {
+        double raw_freq = freq_values[i];
+        if (raw_freq < min_frequency) raw_freq = min_frequency;
+        if (smoothed_freq < 0.0)
+            smoothed_freq = raw_freq;
+        else
+            smoothed_freq += (raw_freq - smoothed_freq) * smooth_alpha;
+
+        double f = smoothed_freq;
+        if (f < 1.0) f = 1.0;
+        int64_t delay_samples = (int64_t)rint(sample_rate / f);
+        if (delay_samples < 1) delay_samples = 1;
+        if (delay_samples >= buffer_len) delay_samples = buffer_len - 1;
+
+        int64_t read_pos = write_pos - delay_samples;
+        if (read_pos < 0) read_pos += buffer_len;
+
+        double fb = fb_values[i];
+        if (!isfinite(fb)) fb = 0.0;
+        if (fb > max_feedback) fb = max_feedback;
+        if (fb < -max_feedback) fb = -max_feedback;
+
+        for (int ch = 0; ch < c; ++ch) {
+            double delayed = buffer[read_pos * c + ch];
+            double out_sample = x[i * c + ch] + fb * delayed;
+            buffer[write_pos * c + ch] = out_sample;
+            y[i * c + ch] = out_sample;
+        }
+        write_pos += 1;
+        if (write_pos >= buffer_len) write_pos = 0;
+    }
+    *write_pos_io = write_pos;
+    *smoothed_freq_io = smoothed_freq;
+}
+
+/* ---------------------------------------------------------------------------
+ * ADSR envelopes.  States: 0 IDLE, 1 ATTACK, 2 DECAY, 3 SUSTAIN, 4 RELEASE.
+ *
+ * Gated variant follows adsr_pe.py:124-196: emit the current level first, then
+ * detect gate edges (prev==0 && cur==1 -> ATTACK, prev==1 && cur==0 -> RELEASE),
+ * then advance the active segment.  st[0]=state, st[1]=env, st[2]=prev_gate.
+ */
+void orc_adsr_gated(const float *gate, float *out, int64_t n,
+                    double attack_dvdt, double decay_dvdt, double release_dvdt,
+                    double sustain_level, double *st)
+{
+    int state = (int)st[0];
+    double env = st[1];
+    double prev_gate = st[2];
+    for (int64_t i = 0; i < n; ++i) {
+        out[i] = (float)env;
+        double cur = (double)gate[i];
+        int new_attack = (prev_gate == 0.0 && cur == 1.0);
+        int new_release = (prev_gate == 1.0 && cur == 0.0);
+        prev_gate = cur;
+        if (new_attack) state = 1;
+        else if (new_release) state = 4;
+
+        switch (state) {
+        case 0: env = 0.0; break;
+        case 1:
+            env += attack_dvdt;
+            if (env >= 1.0) { env = 1.0; state = 2; }
+            break;
+        case 2:
+            env += decay_dvdt;
+            if (env <= sustain_level) { env = sustain_level; state = 3; }
+            break;
+        case 3: env = sustain_level; break;
+        case 4:
+            env += release_dvdt;
+            if (env <= 0.0) { env = 0.0; state = 0; }
+            break;
+        }
+    }
+    st[0] = (double)state;
+    st[1] = env;
+    st[2] = prev_gate;
+}
+
+/*
+ * Triggered variant follows adsr_pe.py:279-335: trigger>0 restarts ATTACK from the
+ * current level; SUSTAIN lasts until now >= sustain_ends_at where sustain_ends_at
+ * is set to (now + sustain_samples) on the DECAY->SUSTAIN sample.
+ * st[0]=state, st[1]=env, st[2]=sustain_ends_at (absolute sample index).
+ */
+void orc_adsr_triggered(const float *trig, float *out, int64_t start, int64_t n,
+                        double attack_dvdt, double decay_dvdt, double release_dvdt,
+                        double sustain_level, int64_t sustain_samples, double *st)
+{
+    int state = (int)st[0];
+    double env = st[1];
+    int64_t sustain_ends_at = (int64_t)st[2];
+    for (int64_t i = 0; i < n; ++i) {
+        out[i] = (float)env;
+        int64_t now = start + i;
+        if (trig[i] > 0.0f) state = 1;
+        switch (state) {
+        case 0: env = 0.0; break;
+        case 1:
+            env += attack_dvdt;
+            if (env >= 1.0) { env = 1.0; state = 2; }
+            break;
+        case 2:
+            env += decay_dvdt;
+            if (env <= sustain_level) {
+                env = sustain_level;
+                sustain_ends_at = now + sustain_samples;
+                state = 3;
+            }
+            break;
+        case 3:
+            env = sustain_level;
+            if (now >= sustain_ends_at) state = 4;
+            break;
+        case 4:
+            env += release_dvdt;
+            if (env <= 0.0) { env = 0.0; state = 0; }
+            break;
+        }
+    }
+    st[0] = (double)state;
+    st[1] = env;
+    st[2] = (double)sustain_ends_at;
+}
