@@ -1,0 +1,264 @@
+/*
+ * pygmu_hip.h -- C ABI of libpygmu_hip.so, the MI355X (gfx950) render library behind
+ * pygmu2's `ProcessingElement._render(start, duration) -> Snippet` hot path.
+ *
+ * The reference (rdpoor/pygmu2) is pure Python/numpy: it has no FFI.  The drop-in
+ * boundary is therefore the body of each PE's `_render`; every entry
+ * point below replaces the numpy/scipy/numba arithmetic of one reference function,
+ * cited as `file:line` relative to /root/reference/src/pygmu2/.  The Python binding a
+ * maintainer would add is shown in INTEGRATION.md (ctypes; pygmu2_amd/device.py is
+ * that binding for this repository's own PE classes).
+ *
+ * Conventions
+ *  - Plain C types only.  `float*` / `double*` / `void*` arguments are DEVICE pointers
+ *    obtained from pgx_malloc unless the name ends in `_host`.
+ *  - Audio buffers are (frames, channels) row-major float32, exactly the reference's
+ *    Snippet payload (snippet.py:37-45).  Batched entry points take `batch` independent
+ *    instances ("voices"); instance i's buffer starts `*_stride` ELEMENTS after
+ *    instance i-1's, its parameter block is params[i], its state is state[i].
+ *  - Parameter blocks and state blobs live in device memory and are owned by the caller
+ *    (the PE object).  A zero-filled state blob is the reset state unless noted.
+ *  - Every call is asynchronous on the library stream (pgx_stream_handle) unless
+ *    documented as synchronous.  No entry point allocates or synchronises unless noted,
+ *    so sequences of calls can be captured into a HIP graph.
+ *  - Return value: 0 on success, negative pgx_status otherwise; the message of the last
+ *    failure on the calling thread is available from pgx_last_error().  No C++
+ *    exception crosses this boundary.
+ */
+#ifndef PYGMU_HIP_H
+#define PYGMU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PGX_OK = 0,
+    PGX_ERR_INVALID = -1,   /* bad argument (maps to Python ValueError)            */
+    PGX_ERR_RUNTIME = -2,   /* HIP runtime failure (maps to Python RuntimeError)   */
+    PGX_ERR_NOT_INIT = -3,  /* pgx_init not called / no device                      */
+    PGX_ERR_NOMEM = -4
+} pgx_status;
+
+/* ------------------------------------------------------------------ runtime */
+int pgx_abi_version(void);
+const char *pgx_last_error(void);
+int pgx_device_count(int *count);
+int pgx_init(int device);                 /* select device, create stream + pool; idempotent */
+int pgx_shutdown(void);                   /* sync, release pool, destroy stream              */
+int pgx_device_name(char *buf, size_t len);
+void *pgx_stream_handle(void);            /* hipStream_t of the library stream               */
+int pgx_stream_sync(void);
+
+int pgx_malloc(void **dptr, size_t bytes);      /* pooled (size-class free lists)           */
+int pgx_free(void *dptr);                       /* returns the block to the pool            */
+int pgx_pool_trim(void);                        /* hipFree every cached block               */
+int pgx_memset(void *dptr, int byte_value, size_t bytes);
+int pgx_memcpy_h2d(void *dst, const void *src_host, size_t bytes);  /* synchronous */
+int pgx_memcpy_d2h(void *dst_host, const void *src, size_t bytes);  /* synchronous */
+int pgx_memcpy_d2d(void *dst, const void *src, size_t bytes);
+
+int pgx_event_create(void **event);
+int pgx_event_destroy(void *event);
+int pgx_event_record(void *event);              /* on the library stream */
+int pgx_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+
+/* ------------------------------------------------------------------ sources / copies
+ * ConstantPE._render (constant_pe.py:51-63), IdentityPE._render (identity_pe.py:43-60),
+ * DiracPE._render (dirac_pe.py:48-67), ArrayPE._render (array_pe.py:74-129) and the
+ * copy/hold part of _ExtentWindowPE._render (extent_window_pe.py:88-157).  Bit-exact.
+ */
+int pgx_fill(float *out, int64_t n_elems, float value);
+/* IdentityPE: out[i, :] = first + float(i) * delta in float32, where the host passes
+ * first = float32(start), delta = float32(start + 1) - first (numpy's arange fill rule). */
+int pgx_ramp(float *out, float first, float delta, int64_t n, int channels);
+int pgx_dirac(float *out, int64_t start, int64_t n, int channels);
+/* out[f, :] = src[start + f - src_start, :] where start+f lies in [src_start, src_start+src_len),
+ * else src[0] if (before && hold_first), src[src_len-1] if (after && hold_last), else 0. */
+int pgx_window_copy(float *out, int64_t start, int64_t n, int channels,
+                    const float *src, int64_t src_start, int64_t src_len,
+                    int hold_first, int hold_last);
+
+/* out[f] = in[f, ch]: channel selection of a control stream, as _scalar_or_pe_values does
+ * for a multi-channel parameter PE (processing_element.py:346-352). */
+int pgx_extract_channel(float *out, const float *in, int64_t n, int channels, int ch);
+
+/* ------------------------------------------------------------------ SinePE
+ * Pure path: SinePE._render + _compute_phase_pure (sine_pe.py:119-175).
+ *   phase = phase0 + w * (double(n) / sr),  out = float(amp * sin(phase)),  w = (2*pi)*f
+ *   computed on the host exactly as the reference does.  float64 throughout.
+ */
+typedef struct {
+    double w;        /* (2.0 * pi) * frequency */
+    double amp;
+    double phase0;
+} pgx_sine_params;
+int pgx_sine_render(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
+                    int channels, double sample_rate, const pgx_sine_params *params);
+
+/* Stateful path: _compute_phase_stateful (sine_pe.py:177-232).  freq/amp/phase_mod are
+ * optional per-sample float32 control streams (frames, 1); NULL -> the scalar in params.
+ * state[instance] = { accumulated_phase, initialised flag }.  The phase term is added to
+ * every sample and is included in the carried phase, as in the reference. */
+typedef struct {
+    double freq;
+    double amp;
+    double phase;          /* scalar phase (used as initial phase and as per-sample term) */
+    int32_t phase_is_stream;
+    int32_t pad;
+} pgx_sine_stateful_params;
+int pgx_sine_stateful(float *out, int64_t n, int channels, double sample_rate,
+                      const pgx_sine_stateful_params *params,
+                      const float *freq, const float *amp, const float *phase_mod,
+                      double *state /* [2] */);
+
+/* ------------------------------------------------------------------ GainPE / MixPE
+ * GainPE._render (gain_pe.py:92-127): one float32 multiply -> bit-exact.
+ * MixPE._render (mix_pe.py:91-94): float32 adds in input order -> bit-exact. */
+int pgx_gain_const(float *out, const float *in, int64_t n_elems, float gain);
+int pgx_gain_vec(float *out, const float *in, const float *gain, int64_t n, int channels,
+                 int gain_channels /* 1 (broadcast) or == channels */);
+/* ins_host: HOST array of k device pointers, each n_elems floats. */
+int pgx_mix_n(float *out, const float *const *ins_host, int k, int64_t n_elems);
+/* Sum of `batch` equally shaped voices stored [batch][n_elems] (stride in elements),
+ * accumulated in float32 in voice order 0..batch-1 (== MixPE over the voices). */
+int pgx_mix_batch(float *out, const float *in, int64_t in_stride, int batch, int64_t n_elems);
+
+/* ------------------------------------------------------------------ BiquadPE
+ * Constant coefficients: BiquadPE._filter_constant_coeffs (biquad_pe.py:383-404), i.e.
+ * scipy.signal.lfilter's direct-form-II-transposed section in float64:
+ *     y = z0 + b0*x;  z0 = (z1 + b1*x) - a1*y;  z1 = b2*x - a2*y
+ * evaluated by a parallel scan over affine state maps; each thread re-runs its chunk in
+ * exactly this operation order from its scanned carry-in.
+ * coef[instance] = {b0,b1,b2,a1,a2} (host computes them, biquad_pe.py:217-335);
+ * state[instance][channel] = {z0,z1}.  workspace: device scratch of at least
+ * pgx_biquad_workspace_bytes(batch, n, channels) bytes (may be NULL when that is 0). */
+size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels);
+int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_stride,
+                     int batch, int64_t n, int channels,
+                     const double *coef /* [batch][5] */, double *state /* [batch][channels][2] */,
+                     void *workspace);
+
+/* Time-varying coefficients: _compute_coefficients per sample (biquad_pe.py:217-335) +
+ * the direct-form-I recurrence of _biquad_varying_numba (biquad_pe.py:35-62).
+ * freq/q: per-sample float32 control streams (frames,1) or NULL -> scalar.
+ * state[channel] = {x1,x2,y1,y2}.  mode: 0 lowpass,1 highpass,2 bandpass,3 notch,
+ * 4 allpass,5 peaking,6 lowshelf,7 highshelf. */
+typedef struct {
+    double freq;
+    double q;
+    double gain_db;
+    int32_t mode;
+    int32_t pad;
+} pgx_biquad_var_params;
+/* gain_a = 10^(gain_db/40) and gain_sqrt_a = sqrt(gain_a), computed by the host exactly as the
+ * reference does (biquad_pe.py:250,290). */
+int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, double sample_rate,
+                       const pgx_biquad_var_params *params, const float *freq, const float *q,
+                       double gain_a, double gain_sqrt_a, double *state /* [channels][4] */);
+
+/* ------------------------------------------------------------------ BlitSawPE / SuperSawPE
+ * BlitSawPE._render (blit_saw_pe.py:150-264): phase cumsum -> mod 1 -> Dirichlet kernel
+ * -> leaky integrator -> *2 *amp -> float32.  state[instance] = {phase, integrator}.
+ * The caller applies the reset-on-discontinuity rule (blit_saw_pe.py:182-185) by
+ * re-initialising state to {initial_phase, 0} before the call.
+ * freq/amp/m streams: optional per-sample float32 (frames,1), stride in elements between
+ * instances (0 = shared). */
+typedef struct {
+    double freq;
+    double amp;
+    double leak;
+    double m;              /* <= 0: automatic (largest odd M below Nyquist) */
+} pgx_blitsaw_params;
+int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channels,
+                double sample_rate, const pgx_blitsaw_params *params,
+                const float *freq, int64_t freq_stride,
+                const float *amp, int64_t amp_stride,
+                const float *m, int64_t m_stride,
+                double *state /* [batch][2] */);
+
+/* SuperSawPE._render (super_saw_pe.py:287-318): out = float(amp * sum_v double(voice_v))
+ * where voice_v is the float32 output of BlitSaw v.  `voices` = [batch*nvoices] float32
+ * buffers laid out [instance][voice][frames]; amp stream optional. */
+int pgx_supersaw_sum(float *out, int64_t out_stride, int batch, int nvoices, int64_t n,
+                     int channels, const float *voices, const double *amp_scalar /* [batch] */,
+                     const float *amp, int64_t amp_stride);
+
+/* ------------------------------------------------------------------ LadderPE
+ * _ladder_process_numba (ladder_pe.py:31-203).  One lane per (instance, channel) chain.
+ * state[instance][channel] = {z0[4], z1[4], old_input}. */
+typedef struct {
+    double freq;
+    double resonance;
+    double drive;
+    double passband_gain;
+    int32_t oversample;
+    int32_t mode;          /* 0 lp24,1 lp12,2 bp24,3 bp12,4 hp24,5 hp12 */
+} pgx_ladder_params;
+int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride,
+               int batch, int64_t n, int channels, double sample_rate,
+               const pgx_ladder_params *params,
+               const float *freq, const float *resonance, const float *drive, /* batch==1 only */
+               double *state /* [batch][channels][9] */);
+
+/* ------------------------------------------------------------------ CombPE
+ * _comb_process_numba (comb_pe.py:26-113).  state = {write_pos, smoothed_freq(-1 = unset)};
+ * ring = (buffer_len, channels) float64, zero at reset.  delay_scratch: n int32. */
+int pgx_comb(float *out, const float *in, int64_t n, int channels, double sample_rate,
+             double freq_scalar, double fb_scalar, const float *freq, const float *fb,
+             double min_frequency, int64_t smoothing_samples,
+             double *ring, int64_t buffer_len, double *state /* [2] */,
+             int32_t *delay_scratch, double *fb_scratch);
+
+/* ------------------------------------------------------------------ envelopes / gates
+ * PeriodicGate (periodic_gate.py:63-67 over function_gen_pe.py:157-193, scalar params):
+ *   gate = (mod(mod(double(n)*dt,1)+phase,1) < duty) ? 1 : 0.  Bit-exact.
+ * PeriodicTrigger (periodic_trigger.py:49-58): amp where (n+phase_samples) % period == 0. */
+typedef struct {
+    double dt;             /* frequency / sample_rate */
+    double phase;
+    double duty;           /* already clipped to [0,1] */
+} pgx_gate_params;
+int pgx_periodic_gate(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
+                      const pgx_gate_params *params);
+int pgx_periodic_trigger(float *out, int64_t start, int64_t n, int64_t period,
+                         int64_t phase_samples, float amplitude);
+
+/* AdsrGatedPE._render (adsr_pe.py:124-196) / AdsrTriggeredPE._render (adsr_pe.py:279-335):
+ * sequential float64 accumulation, one lane per instance -> bit-exact.
+ * state[instance] = {state enum, env, prev_gate | sustain_ends_at}. */
+typedef struct {
+    double attack_dvdt;
+    double decay_dvdt;
+    double release_dvdt;
+    double sustain_level;
+    int64_t sustain_samples;   /* triggered variant only */
+} pgx_adsr_params;
+int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t gate_stride,
+                   int batch, int64_t n, const pgx_adsr_params *params, double *state);
+int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride,
+                       int batch, int64_t start, int64_t n, const pgx_adsr_params *params,
+                       double *state);
+
+/* ------------------------------------------------------------------ ConvolvePE
+ * ConvolvePE._render (convolve_pe.py:250-342): y = x * h (linear, streaming).  The
+ * reference evaluates it by float64 FFT overlap-save; this library evaluates the same sum
+ * directly as a Toeplitz(h) x Hankel(x) matrix product on the f32 MFMA units with
+ * float64 accumulation across K-slabs.
+ *   x:     (n, src_ch) float32 current block
+ *   hist:  (L-1, out_ch) float32 previous inputs (fanned out), updated in place
+ *   h:     (L, fir_ch) float32
+ *   out:   (n, out_ch) float32
+ * workspace >= pgx_convolve_workspace_bytes(n, L, out_ch). */
+size_t pgx_convolve_workspace_bytes(int64_t n, int64_t fir_len, int out_channels);
+int pgx_convolve(float *out, const float *x, int64_t n, int src_channels,
+                 const float *h, int64_t fir_len, int fir_channels, int out_channels,
+                 float *hist, void *workspace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGMU_HIP_H */

@@ -1,0 +1,26 @@
+"""Small helpers shared by the PE modules: library handle, output allocation, pointer
+extraction.  Every PE `_render` goes through `lib()`; without the HIP library or a GPU
+that raises RuntimeError (no CPU fallback)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import device as _dev
+from .device import DeviceBuffer, check
+
+
+def lib():
+    return _dev.ensure_init()
+
+
+def new_output(frames: int, channels: int) -> DeviceBuffer:
+    return DeviceBuffer((int(frames), int(channels)), np.float32)
+
+
+def ptr(buf) -> int | None:
+    """Device address of a DeviceBuffer, or None (-> NULL) for an absent stream."""
+    return None if buf is None else buf.ptr
+
+
+__all__ = ["lib", "new_output", "ptr", "check", "DeviceBuffer"]

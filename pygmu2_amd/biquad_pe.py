@@ -1,0 +1,189 @@
+"""
+BiquadPE: RBJ-cookbook second-order IIR section, 8 modes (biquad_pe.py:65-474).
+
+Constant frequency/Q: coefficients are computed once on the host with the reference's
+own float64 formulas; the recurrence (scipy lfilter's DF-II-T order) runs on the device
+as a parallel scan (pgx_biquad_const).  PE-driven frequency or Q: per-sample
+coefficients and the direct-form-I recurrence of the reference's numba kernel, also a
+scan, with time-varying 2x2 maps (pgx_biquad_varying).
+State lives in HBM and is zeroed by on_start / on_stop / reset_state.
+"""
+
+from __future__ import annotations
+
+from enum import Enum
+
+import numpy as np
+
+from . import device as _dev
+from ._kernels import DeviceBuffer, check, lib, new_output, ptr
+from .config import handle_error
+from .extent import Extent
+from .processing_element import ProcessingElement
+from .snippet import Snippet
+
+
+class BiquadMode(Enum):
+    LOWPASS = "lowpass"
+    HIGHPASS = "highpass"
+    BANDPASS = "bandpass"
+    NOTCH = "notch"
+    ALLPASS = "allpass"
+    PEAKING = "peaking"
+    LOWSHELF = "lowshelf"
+    HIGHSHELF = "highshelf"
+
+
+_MODE_INDEX = {m: i for i, m in enumerate(BiquadMode)}
+
+
+def rbj_coefficients(mode: BiquadMode, freq: float, q: float, gain_db: float, sample_rate: float):
+    """(b0, b1, b2, a1, a2) normalised by a0, float64, for one (freq, q) pair.
+
+    Host-side scalar evaluation of the cookbook formulas in the same operation order as
+    the reference's vectorised `_compute_coefficients` (biquad_pe.py:217-335), including
+    its clamps: freq to [1, 0.99*Nyquist], q to [0.01, 100].
+    """
+    f = np.atleast_1d(freq).astype(np.float64)      # 1-element arrays, as the reference's
+    qq = np.atleast_1d(q).astype(np.float64)        # constant path passes (biquad_pe.py:369-372)
+    nyquist = sample_rate / 2.0
+    f = np.clip(f, 1.0, nyquist * 0.99)
+    qq = np.clip(qq, 0.01, 100.0)
+    omega = 2.0 * np.pi * f / sample_rate
+    sn, cs = np.sin(omega), np.cos(omega)
+    alpha = sn / (2.0 * qq)
+    A = 10.0 ** (gain_db / 40.0)
+    if mode == BiquadMode.LOWPASS:
+        b0 = (1.0 - cs) / 2.0; b1 = 1.0 - cs; b2 = (1.0 - cs) / 2.0
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha
+    elif mode == BiquadMode.HIGHPASS:
+        b0 = (1.0 + cs) / 2.0; b1 = -(1.0 + cs); b2 = (1.0 + cs) / 2.0
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha
+    elif mode == BiquadMode.BANDPASS:
+        b0 = alpha; b1 = 0.0; b2 = -alpha
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha
+    elif mode == BiquadMode.NOTCH:
+        b0 = 1.0; b1 = -2.0 * cs; b2 = 1.0
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha
+    elif mode == BiquadMode.ALLPASS:
+        b0 = 1.0 - alpha; b1 = -2.0 * cs; b2 = 1.0 + alpha
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha
+    elif mode == BiquadMode.PEAKING:
+        b0 = 1.0 + alpha * A; b1 = -2.0 * cs; b2 = 1.0 - alpha * A
+        a0 = 1.0 + alpha / A; a1 = -2.0 * cs; a2 = 1.0 - alpha / A
+    elif mode == BiquadMode.LOWSHELF:
+        sA = np.sqrt(A)
+        b0 = A * ((A + 1.0) - (A - 1.0) * cs + 2.0 * sA * alpha)
+        b1 = 2.0 * A * ((A - 1.0) - (A + 1.0) * cs)
+        b2 = A * ((A + 1.0) - (A - 1.0) * cs - 2.0 * sA * alpha)
+        a0 = (A + 1.0) + (A - 1.0) * cs + 2.0 * sA * alpha
+        a1 = -2.0 * ((A - 1.0) + (A + 1.0) * cs)
+        a2 = (A + 1.0) + (A - 1.0) * cs - 2.0 * sA * alpha
+    elif mode == BiquadMode.HIGHSHELF:
+        sA = np.sqrt(A)
+        b0 = A * ((A + 1.0) + (A - 1.0) * cs + 2.0 * sA * alpha)
+        b1 = -2.0 * A * ((A - 1.0) + (A + 1.0) * cs)
+        b2 = A * ((A + 1.0) + (A - 1.0) * cs - 2.0 * sA * alpha)
+        a0 = (A + 1.0) - (A - 1.0) * cs + 2.0 * sA * alpha
+        a1 = 2.0 * ((A - 1.0) - (A + 1.0) * cs)
+        a2 = (A + 1.0) - (A - 1.0) * cs - 2.0 * sA * alpha
+    else:
+        handle_error(f"Unknown filter mode: {mode}", fatal=True, exception_class=ValueError)
+        return (0.0, 0.0, 0.0, 0.0, 0.0)
+    return tuple(float(np.atleast_1d(v)[0]) for v in (b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0))
+
+
+class BiquadPE(ProcessingElement):
+    def __init__(self, source: ProcessingElement, frequency, q,
+                 mode: BiquadMode = BiquadMode.LOWPASS, gain_db: float = 0.0):
+        self._source = source
+        self._frequency = frequency
+        self._q = q
+        self._mode = mode
+        self._gain_db = gain_db
+        self._freq_is_pe = isinstance(frequency, ProcessingElement)
+        self._q_is_pe = isinstance(q, ProcessingElement)
+        self._coef: DeviceBuffer | None = None        # [5] float64 (constant path)
+        self._params: DeviceBuffer | None = None      # pgx_biquad_var_params (varying path)
+        self._state: DeviceBuffer | None = None       # [C][2] or [C][4] float64
+        self._state_channels = 0
+        self._workspace: DeviceBuffer | None = None
+
+    source = property(lambda self: self._source)
+    frequency = property(lambda self: self._frequency)
+    q = property(lambda self: self._q)
+    mode = property(lambda self: self._mode)
+    gain_db = property(lambda self: self._gain_db)
+
+    def inputs(self) -> list[ProcessingElement]:
+        out = [self._source]
+        if self._freq_is_pe:
+            out.append(self._frequency)
+        if self._q_is_pe:
+            out.append(self._q)
+        return out
+
+    def is_pure(self) -> bool:
+        return False
+
+    def channel_count(self) -> int | None:
+        return self._source.channel_count()
+
+    def _compute_extent(self) -> Extent:
+        ext = self._source.extent()
+        if self._freq_is_pe:
+            ext = ext.intersection(self._frequency.extent()) or ext
+        if self._q_is_pe:
+            ext = ext.intersection(self._q.extent()) or ext
+        return ext
+
+    def _reset_state(self) -> None:
+        if self._state is not None:
+            self._state.zero_()
+
+    _on_start = _reset_state
+    _on_stop = _reset_state
+
+    def _ensure_state(self, channels: int) -> None:
+        if self._state is None or self._state_channels != channels:
+            per = 4 if (self._freq_is_pe or self._q_is_pe) else 2
+            self._state = DeviceBuffer((channels, per), np.float64, zero=True)
+            self._state_channels = channels
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        src = self._source.render(start, duration)
+        ch = src.channels
+        self._ensure_state(ch)
+        out = new_output(duration, ch)
+        L = lib()
+        sr = float(self.sample_rate)
+        if not self._freq_is_pe and not self._q_is_pe:
+            if self._coef is None:
+                self._coef = DeviceBuffer.from_host(np.asarray(
+                    rbj_coefficients(self._mode, self._frequency, self._q, self._gain_db, sr),
+                    dtype=np.float64))
+            need = L.pgx_biquad_workspace_bytes(1, duration, ch)
+            if need and (self._workspace is None or self._workspace.nbytes < need):
+                self._workspace = DeviceBuffer((need,), np.uint8)
+            check(L.pgx_biquad_const(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, self._coef.ptr,
+                                     self._state.ptr, ptr(self._workspace) if need else None),
+                  "pgx_biquad_const")
+            return Snippet(start, out)
+
+        f_s, f_buf = self._control_stream(self._frequency, start, duration)
+        q_s, q_buf = self._control_stream(self._q, start, duration)
+        if self._params is None:
+            self._params = _dev.upload_struct(
+                _dev.BIQUAD_VAR_PARAMS, freq=0.0 if f_s is None else f_s, q=0.0 if q_s is None else q_s,
+                gain_db=float(self._gain_db), mode=_MODE_INDEX[self._mode])
+        gain_a = 10.0 ** (self._gain_db / 40.0)
+        check(L.pgx_biquad_varying(out.ptr, src.dev.ptr, duration, ch, sr, self._params.ptr,
+                                   ptr(f_buf), ptr(q_buf), gain_a, float(np.sqrt(gain_a)),
+                                   self._state.ptr), "pgx_biquad_varying")
+        return Snippet(start, out)
+
+    def __repr__(self) -> str:
+        f = f"{type(self._frequency).__name__}(...)" if self._freq_is_pe else str(self._frequency)
+        q = f"{type(self._q).__name__}(...)" if self._q_is_pe else str(self._q)
+        return (f"BiquadPE(source={type(self._source).__name__}, frequency={f}, q={q}, "
+                f"mode={self._mode.value})")

@@ -1,0 +1,107 @@
+"""
+BlitSawPE: band-limited sawtooth (Stilson/Smith BLIT + leaky integrator)
+(blit_saw_pe.py:67-299).
+
+The whole chain -- phase accumulation (prefix scan), wrap, Dirichlet kernel, leaky
+integrator (affine scan), x2, amplitude, float32 rounding -- is one kernel
+(pgx_blitsaw), one workgroup per oscillator, float64 inside.  The reset rule for
+non-contiguous renders (blit_saw_pe.py:182-185) is applied here, on the host.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import device as _dev
+from ._kernels import DeviceBuffer, check, lib, new_output, ptr
+from .extent import Extent
+from .processing_element import ProcessingElement
+from .snippet import Snippet
+
+
+class BlitSawPE(ProcessingElement):
+    def __init__(self, frequency, amplitude=1.0, initial_phase: float = 0.0, m=None,
+                 leak: float = 0.999, channels: int = 1):
+        self._frequency = frequency
+        self._amplitude = amplitude
+        self._initial_phase = initial_phase % 1.0
+        self._m = m
+        self._leak = leak
+        self._channels = channels
+        self._params: DeviceBuffer | None = None
+        self._state: DeviceBuffer | None = None      # {phase, integrator}
+        self._last_render_end: int | None = None
+
+    frequency = property(lambda self: self._frequency)
+    amplitude = property(lambda self: self._amplitude)
+    m = property(lambda self: self._m)
+    leak = property(lambda self: self._leak)
+    initial_phase = property(lambda self: self._initial_phase)
+
+    def inputs(self) -> list[ProcessingElement]:
+        return [p for p in (self._frequency, self._amplitude, self._m)
+                if isinstance(p, ProcessingElement)]
+
+    def is_pure(self) -> bool:
+        return False
+
+    def channel_count(self) -> int:
+        return self._channels
+
+    def _compute_extent(self) -> Extent:
+        ext = Extent(None, None)
+        for pe in self.inputs():
+            ext = ext.intersection(pe.extent())
+        return ext
+
+    def _reset_state(self) -> None:
+        self._last_render_end = None
+
+    _on_start = _reset_state
+    _on_stop = _reset_state
+
+    # host-side pieces shared with the voice bank -------------------------------------------
+    def _scalar_params(self) -> dict:
+        def scalar(p):
+            return 0.0 if isinstance(p, ProcessingElement) else float(p)
+        if self._m is None:
+            m = -1.0                                   # automatic
+        elif isinstance(self._m, ProcessingElement):
+            m = 1.0                                    # unused: a stream is supplied
+        else:
+            m = float(max(int(np.float64(float(self._m)).astype(np.int32)), 1))
+        return dict(freq=scalar(self._frequency), amp=scalar(self._amplitude),
+                    leak=float(self._leak), m=m)
+
+    def _initial_state(self) -> np.ndarray:
+        ip = self._initial_phase
+        ip = float(np.asarray(ip).reshape(-1)[0])      # SuperSaw passes a 1-element ndarray
+        return np.array([ip, 0.0], dtype=np.float64)
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        L = lib()
+        if self._params is None:
+            self._params = _dev.upload_struct(_dev.BLITSAW_PARAMS, **self._scalar_params())
+        if self._state is None:
+            self._state = DeviceBuffer((2,), np.float64)
+            self._last_render_end = None
+        if self._last_render_end is None or start != self._last_render_end:
+            self._state.upload(self._initial_state())
+        f_s, f_buf = self._control_stream(self._frequency, start, duration)
+        a_s, a_buf = self._control_stream(self._amplitude, start, duration)
+        m_buf = None
+        if isinstance(self._m, ProcessingElement):
+            _, m_buf = self._control_stream(self._m, start, duration)
+        out = new_output(duration, self._channels)
+        check(L.pgx_blitsaw(out.ptr, 0, 1, duration, self._channels, float(self.sample_rate),
+                            self._params.ptr, ptr(f_buf), 0, ptr(a_buf), 0, ptr(m_buf), 0,
+                            self._state.ptr), "pgx_blitsaw")
+        self._last_render_end = start + duration
+        return Snippet(start, out)
+
+    def __repr__(self) -> str:
+        def s(p):
+            return type(p).__name__ if isinstance(p, ProcessingElement) else str(p)
+        m = "auto" if self._m is None else s(self._m)
+        return (f"BlitSawPE(frequency={s(self._frequency)}, amplitude={s(self._amplitude)}, "
+                f"m={m}, leak={self._leak}, channels={self._channels})")

@@ -1,0 +1,164 @@
+"""
+ConvolvePE: streaming convolution y = src * fir with a finite FIR PE
+(convolve_pe.py:40-349).
+
+The reference computes the linear convolution by float64 FFT overlap-save with an
+(L-1)-sample input history; this PE computes the identical sum as a dense
+Toeplitz x Hankel product on the MI355X f32 matrix cores with float64 accumulation
+across 1024-tap slabs (pgx_convolve), keeping the same history semantics: the history
+is cleared when a render is not contiguous with the previous one.  `fft_size` is kept
+for API compatibility and validated like the reference does, but does not influence
+the result (overlap-save output is independent of the FFT size).
+
+Channel rules (convolve_pe.py:114-144,207-223): mono FIR -> applied to every source
+channel; FIR channels == source channels -> per-channel; mono source + N-channel FIR ->
+fan-out to N channels.
+Deviation (documented in SURVEY.md section 8 a14): the reference cannot be re-started
+after stop() (its tail is dropped and never re-created); here reset just clears history.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from ._kernels import DeviceBuffer, check, lib, new_output
+from .extent import Extent
+from .processing_element import ProcessingElement
+from .snippet import Snippet
+
+
+def _next_pow2(n: int) -> int:
+    p = 1
+    while p < n:
+        p <<= 1
+    return p
+
+
+class ConvolvePE(ProcessingElement):
+    def __init__(self, src: ProcessingElement, fir: ProcessingElement, *, fft_size: int | None = None):
+        self._src = src
+        self._fir = fir
+        self._fft_size = int(fft_size) if fft_size is not None else None
+        self._fir_len: int | None = None
+        self._h: DeviceBuffer | None = None          # (L, fir_ch) float32, rendered once
+        self._fir_ch = 0
+        self._out_ch = 0
+        self._hist: DeviceBuffer | None = None       # (L-1, out_ch) float32
+        self._workspace: DeviceBuffer | None = None
+        self._last_render_end: int | None = None
+
+    src = property(lambda self: self._src)
+    fir = property(lambda self: self._fir)
+    fft_size = property(lambda self: self._fft_size)
+
+    def inputs(self) -> list[ProcessingElement]:
+        return [self._src, self._fir]
+
+    @staticmethod
+    def ir_energy_norm(filter_pe: ProcessingElement) -> float:
+        """sqrt(sum of squares) of a finite filter PE; 1.0 if unbounded or ~zero."""
+        ext = filter_pe.extent()
+        if ext.start is None or ext.end is None:
+            return 1.0
+        data = filter_pe.render(ext.start, ext.end - ext.start).data
+        norm = np.sqrt(np.sum(data.astype(np.float64) ** 2))
+        return float(norm) if norm > 1e-10 else 1.0
+
+    def is_pure(self) -> bool:
+        return False
+
+    def channel_count(self) -> int | None:
+        src_ch = self._src.channel_count()
+        fir_ch = self._fir.channel_count()
+        if src_ch is None and fir_ch is None:
+            return None
+        if src_ch is None:
+            return fir_ch
+        if fir_ch is None or int(fir_ch) == 1:
+            return src_ch
+        if int(src_ch) == 1:
+            return int(fir_ch)
+        return src_ch
+
+    def _reset_state(self) -> None:
+        self._last_render_end = None          # history is cleared on the next render
+
+    _on_start = _reset_state
+    _on_stop = _reset_state
+
+    def _compute_extent(self) -> Extent:
+        src_ext = self._src.extent()
+        fir_ext = self._fir.extent()
+        if fir_ext.start is not None and fir_ext.start != 0:
+            raise ValueError(f"ConvolvePE filter extent must start at 0, got {fir_ext}")
+        if fir_ext.start is None:
+            raise ValueError(f"ConvolvePE filter extent must be finite and start at 0, got {fir_ext}")
+        if fir_ext.end is None:
+            raise ValueError(f"ConvolvePE filter extent must be finite, got {fir_ext}")
+        length = int(fir_ext.end - fir_ext.start)
+        if length < 1:
+            return Extent(0, 0)
+        if src_ext.end is None:
+            return Extent(src_ext.start, None)
+        return Extent(src_ext.start, int(src_ext.end + (length - 1)))
+
+    def _prepare(self) -> None:
+        if self._h is not None:
+            return
+        fir_ext = self._fir.extent()
+        if fir_ext.start != 0 or fir_ext.end is None:
+            raise ValueError(f"ConvolvePE filter must have extent Extent(0, N), got {fir_ext}")
+        length = int(fir_ext.end)
+        if length < 1:
+            raise ValueError("ConvolvePE filter must be non-empty")
+        h = self._fir.render(0, length)
+        if h.duration != length:
+            raise ValueError(f"ConvolvePE filter returned invalid shape {(h.duration, h.channels)}")
+        src_ch = self._src.channel_count()
+        if src_ch is None:
+            src_ch = self._src.render(0, 1).channels
+        fir_ch = h.channels
+        if fir_ch == 1:
+            out_ch = int(src_ch)
+        elif int(src_ch) == 1 or fir_ch == int(src_ch):
+            out_ch = fir_ch
+        else:
+            raise ValueError(f"ConvolvePE filter channels ({fir_ch}) must match src channels ({src_ch}), "
+                             f"or be mono, or be multi-channel with a mono source.")
+        if self._fft_size is None:
+            self._fft_size = _next_pow2(max(2048, length))
+        if self._fft_size < length:
+            raise ValueError(f"fft_size ({self._fft_size}) must be >= filter length ({length})")
+        self._fir_len, self._fir_ch, self._out_ch = length, fir_ch, out_ch
+        self._h = h.dev
+        self._hist = DeviceBuffer((max(length - 1, 1), out_ch), np.float32, zero=True)
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        self._prepare()
+        length = self._fir_len
+        if int(self._fft_size) - (length - 1) < 1:
+            raise ValueError(f"fft_size ({self._fft_size}) too small for filter length ({length})")
+        if self._last_render_end is None or start != self._last_render_end:
+            self._hist.zero_()
+        x = self._src.render(start, duration)
+        src_ch = x.channels
+        out_ch = src_ch if self._fir_ch == 1 else self._fir_ch
+        if out_ch != self._out_ch:
+            self._out_ch = out_ch
+            self._hist = DeviceBuffer((max(length - 1, 1), out_ch), np.float32, zero=True)
+        if src_ch != 1 and src_ch != out_ch:
+            raise ValueError(f"ConvolvePE src channels ({src_ch}) incompatible with output channels ({out_ch})")
+        L = lib()
+        need = L.pgx_convolve_workspace_bytes(duration, length, out_ch)
+        if self._workspace is None or self._workspace.nbytes < need:
+            self._workspace = None
+            self._workspace = DeviceBuffer((need,), np.uint8)
+        out = new_output(duration, out_ch)
+        check(L.pgx_convolve(out.ptr, x.dev.ptr, duration, src_ch, self._h.ptr, length, self._fir_ch,
+                             out_ch, self._hist.ptr, self._workspace.ptr), "pgx_convolve")
+        self._last_render_end = start + duration
+        return Snippet(start, out)
+
+    def __repr__(self) -> str:
+        return (f"ConvolvePE(src={type(self._src).__name__}, fir={type(self._fir).__name__}, "
+                f"fft_size={self._fft_size})")

@@ -1,0 +1,434 @@
+// pgx_elementwise.hip -- stateless per-sample kernels: sources, SinePE (pure), GainPE, MixPE,
+// gates/triggers, SuperSaw voice sum.
+//
+// All of these are HBM-streaming kernels: each lane owns 4 consecutive float32 output
+// elements (16 B/lane, 1 KiB per wave store), grids are capped at 256 CUs x 8 blocks and
+// grid-stride over the rest.  Compiled with -ffp-contract=off so float64 expressions are
+// rounded operation by operation like the reference's numpy code.
+
+#include "pgx_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kVec = 4;
+
+// Store up to 4 consecutive floats starting at element e (of total n_elems).
+__device__ __forceinline__ void store4(float *base, int64_t e, int64_t n_elems, bool aligned,
+                                       const float v[4]) {
+    if (aligned && e + 4 <= n_elems) {
+        *reinterpret_cast<float4 *>(base + e) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e + j < n_elems) base[e + j] = v[j];
+    }
+}
+
+__device__ __forceinline__ void load4(const float *base, int64_t e, int64_t n_elems, bool aligned,
+                                      float v[4]) {
+    if (aligned && e + 4 <= n_elems) {
+        float4 t = *reinterpret_cast<const float4 *>(base + e);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (e + j < n_elems) ? base[e + j] : 0.0f;
+    }
+}
+
+__host__ __device__ inline bool is_aligned16(const void *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// numpy's float remainder (np.mod): result takes the sign of the divisor.
+__device__ __forceinline__ double np_mod1(double a) {
+    double r = fmod(a, 1.0);
+    if (r != 0.0) {
+        if (r < 0.0) r += 1.0;
+    } else {
+        r = 0.0;   // copysign(0, +1)
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------ fill / ramp / dirac
+__global__ void __launch_bounds__(kBlock) k_fill(float *out, int64_t n_elems, float value, bool aligned) {
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float v[4] = {value, value, value, value};
+        store4(out, e, n_elems, aligned, v);
+    }
+}
+
+// mode 0: IdentityPE; mode 1: DiracPE (1 at absolute frame 0).
+// IdentityPE is np.arange(start, start+n, dtype=float32) (identity_pe.py:54), which numpy fills as
+// first + float(i) * delta with first = float32(start), delta = float32(start+1) - first, all in
+// float32 -- for |start| >= 2^24 that is NOT float(start+i), and the quirk is reproduced here.
+__global__ void __launch_bounds__(kBlock) k_index_source(float *out, int64_t start, int64_t n, int channels,
+                                                         int mode, float first, float delta, bool aligned) {
+    int64_t n_elems = n * channels;
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t i = (e + j) / channels;
+            v[j] = (mode == 0) ? (first + (float)i * delta) : ((start + i) == 0 ? 1.0f : 0.0f);
+        }
+        store4(out, e, n_elems, aligned, v);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_window_copy(float *out, int64_t start, int64_t n, int channels,
+                                                        const float *src, int64_t src_start, int64_t src_len,
+                                                        int hold_first, int hold_last) {
+    int64_t n_elems = n * channels;
+    int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elems; e += stride) {
+        int64_t f = e / channels;
+        int c = (int)(e - f * channels);
+        int64_t s = start + f - src_start;   // index into src
+        float v = 0.0f;
+        if (s >= 0 && s < src_len) v = src[s * channels + c];
+        else if (s < 0 && hold_first) v = src[c];
+        else if (s >= src_len && hold_last) v = src[(src_len - 1) * channels + c];
+        out[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_extract_channel(float *out, const float *in, int64_t n, int channels,
+                                                            int ch) {
+    int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x; f < n; f += stride) out[f] = in[f * channels + ch];
+}
+
+// ------------------------------------------------------------------------------ SinePE (pure)
+// sine_pe.py:159-175 + :141: phase = phase0 + w * (double(n)/sr); y = amp * sin(phase).
+__global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride, int64_t start, int64_t n,
+                                                 int channels, double sr, const pgx_sine_params *params) {
+    const pgx_sine_params p = params[blockIdx.y];
+    float *o = out + (int64_t)blockIdx.y * out_stride;
+    const bool aligned = is_aligned16(o);
+    int64_t n_elems = n * channels;
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float v[4];
+        int64_t prev_f = -1;
+        float prev_v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t f = (e + j) / channels;
+            if (f != prev_f) {
+                double t = (double)(start + f) / sr;
+                double ph = p.phase0 + p.w * t;
+                prev_v = (float)(p.amp * sin(ph));
+                prev_f = f;
+            }
+            v[j] = prev_v;
+        }
+        store4(o, e, n_elems, aligned, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ GainPE
+__global__ void __launch_bounds__(kBlock) k_gain_const(float *out, const float *in, int64_t n_elems, float g,
+                                                       bool aligned) {
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float v[4];
+        load4(in, e, n_elems, aligned, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * g;
+        store4(out, e, n_elems, aligned, v);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_gain_vec(float *out, const float *in, const float *gain, int64_t n,
+                                                     int channels, int gain_channels, bool aligned) {
+    int64_t n_elems = n * channels;
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float v[4], g[4];
+        load4(in, e, n_elems, aligned, v);
+        if (gain_channels == channels) {
+            load4(gain, e, n_elems, aligned, g);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int64_t f = (e + j) / channels;
+                g[j] = (f < n) ? gain[f] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * g[j];
+        store4(out, e, n_elems, aligned, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ MixPE
+constexpr int kMixMax = 16;
+struct MixPtrs {
+    const float *p[kMixMax];
+};
+
+__global__ void __launch_bounds__(kBlock) k_mix_n(float *out, MixPtrs ins, int k, int accumulate,
+                                                  int64_t n_elems, bool aligned) {
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float acc[4], v[4];
+        int first = 0;
+        if (accumulate) {
+            load4(out, e, n_elems, aligned, acc);
+        } else {
+            load4(ins.p[0], e, n_elems, aligned, acc);
+            first = 1;
+        }
+        for (int i = first; i < k; ++i) {
+            load4(ins.p[i], e, n_elems, aligned, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + v[j];
+        }
+        store4(out, e, n_elems, aligned, acc);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_mix_batch(float *out, const float *in, int64_t in_stride, int batch,
+                                                      int64_t n_elems, bool aligned) {
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
+        float acc[4], v[4];
+        load4(in, e, n_elems, aligned, acc);
+        for (int b = 1; b < batch; ++b) {
+            load4(in + (int64_t)b * in_stride, e, n_elems, aligned, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + v[j];
+        }
+        store4(out, e, n_elems, aligned, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------ gates / triggers
+// function_gen_pe.py:157-193 (pure, rectangle) + periodic_gate.py:63-67.
+__global__ void __launch_bounds__(kBlock) k_periodic_gate(float *out, int64_t out_stride, int64_t start,
+                                                          int64_t n, const pgx_gate_params *params) {
+    const pgx_gate_params p = params[blockIdx.y];
+    float *o = out + (int64_t)blockIdx.y * out_stride;
+    const bool aligned = is_aligned16(o);
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n; e += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double idx = (double)(start + e + j);
+            double base = np_mod1(idx * p.dt);
+            double ph = np_mod1(base + p.phase);
+            v[j] = (ph < p.duty) ? 1.0f : 0.0f;
+        }
+        store4(o, e, n, aligned, v);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_periodic_trigger(float *out, int64_t start, int64_t n, int64_t period,
+                                                             int64_t phase_samples, float amplitude, bool aligned) {
+    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n; e += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t a = start + e + j + phase_samples;
+            v[j] = (a % period == 0) ? amplitude : 0.0f;
+        }
+        store4(out, e, n, aligned, v);
+    }
+}
+
+// ------------------------------------------------------------------------------ SuperSaw voice sum
+// super_saw_pe.py:304-316: float64 accumulate of the float32 voices in voice order, * amp,
+// -> float32, tiled over channels.
+__global__ void __launch_bounds__(kBlock) k_supersaw_sum(float *out, int64_t out_stride, int nvoices, int64_t n,
+                                                         int channels, const float *voices,
+                                                         const double *amp_scalar, const float *amp,
+                                                         int64_t amp_stride) {
+    int b = blockIdx.y;
+    float *o = out + (int64_t)b * out_stride;
+    const float *vbase = voices + (int64_t)b * nvoices * n;
+    const float *a = amp ? amp + (int64_t)b * amp_stride : nullptr;
+    double as = amp_scalar ? amp_scalar[b] : 1.0;
+    int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x; f < n; f += stride) {
+        double acc = 0.0;
+        for (int v = 0; v < nvoices; ++v) acc += (double)vbase[(int64_t)v * n + f];
+        double g = a ? (double)a[f] : as;
+        float y = (float)(acc * g);
+        for (int c = 0; c < channels; ++c) o[f * channels + c] = y;
+    }
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+int pgx_fill(float *out, int64_t n_elems, float value) {
+    PGX_REQUIRE_INIT();
+    if (n_elems <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out != nullptr, "pgx_fill: null output");
+    hipLaunchKernelGGL(k_fill, dim3(pgx::grid_for(pgx::ceil_div(n_elems, kVec), kBlock)), dim3(kBlock), 0,
+                       pgx::stream(), out, n_elems, value, is_aligned16(out));
+    PGX_LAUNCH_CHECK("k_fill");
+    return PGX_OK;
+}
+
+int pgx_ramp(float *out, float first, float delta, int64_t n, int channels) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out != nullptr && channels >= 1, "pgx_ramp: bad argument");
+    hipLaunchKernelGGL(k_index_source, dim3(pgx::grid_for(pgx::ceil_div(n * channels, kVec), kBlock)),
+                       dim3(kBlock), 0, pgx::stream(), out, (int64_t)0, n, channels, 0, first, delta,
+                       is_aligned16(out));
+    PGX_LAUNCH_CHECK("k_index_source");
+    return PGX_OK;
+}
+
+int pgx_dirac(float *out, int64_t start, int64_t n, int channels) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out != nullptr && channels >= 1, "pgx_dirac: bad argument");
+    hipLaunchKernelGGL(k_index_source, dim3(pgx::grid_for(pgx::ceil_div(n * channels, kVec), kBlock)),
+                       dim3(kBlock), 0, pgx::stream(), out, start, n, channels, 1, 0.0f, 0.0f,
+                       is_aligned16(out));
+    PGX_LAUNCH_CHECK("k_index_source");
+    return PGX_OK;
+}
+
+int pgx_window_copy(float *out, int64_t start, int64_t n, int channels, const float *src, int64_t src_start,
+                    int64_t src_len, int hold_first, int hold_last) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && src && channels >= 1 && src_len >= 1, "pgx_window_copy: bad argument");
+    hipLaunchKernelGGL(k_window_copy, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(),
+                       out, start, n, channels, src, src_start, src_len, hold_first, hold_last);
+    PGX_LAUNCH_CHECK("k_window_copy");
+    return PGX_OK;
+}
+
+int pgx_extract_channel(float *out, const float *in, int64_t n, int channels, int ch) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && channels >= 1 && ch >= 0 && ch < channels, "pgx_extract_channel: bad argument");
+    hipLaunchKernelGGL(k_extract_channel, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out, in,
+                       n, channels, ch);
+    PGX_LAUNCH_CHECK("k_extract_channel");
+    return PGX_OK;
+}
+
+int pgx_sine_render(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int channels,
+                    double sample_rate, const pgx_sine_params *params) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && channels >= 1 && sample_rate > 0, "pgx_sine_render: bad argument");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_sine_render: out_stride too small");
+    PGX_CHECK_ARG(batch <= 65535, "pgx_sine_render: batch too large");
+    dim3 grid(pgx::grid_for(pgx::ceil_div(n * channels, kVec), kBlock), batch);
+    hipLaunchKernelGGL(k_sine, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, start, n, channels,
+                       sample_rate, params);
+    PGX_LAUNCH_CHECK("k_sine");
+    return PGX_OK;
+}
+
+int pgx_gain_const(float *out, const float *in, int64_t n_elems, float gain) {
+    PGX_REQUIRE_INIT();
+    if (n_elems <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in, "pgx_gain_const: null pointer");
+    bool al = is_aligned16(out) && is_aligned16(in);
+    hipLaunchKernelGGL(k_gain_const, dim3(pgx::grid_for(pgx::ceil_div(n_elems, kVec), kBlock)), dim3(kBlock), 0,
+                       pgx::stream(), out, in, n_elems, gain, al);
+    PGX_LAUNCH_CHECK("k_gain_const");
+    return PGX_OK;
+}
+
+int pgx_gain_vec(float *out, const float *in, const float *gain, int64_t n, int channels, int gain_channels) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && gain && channels >= 1, "pgx_gain_vec: bad argument");
+    PGX_CHECK_ARG(gain_channels == 1 || gain_channels == channels,
+                  "pgx_gain_vec: gain must be mono or match the source channel count");
+    bool al = is_aligned16(out) && is_aligned16(in) && is_aligned16(gain);
+    hipLaunchKernelGGL(k_gain_vec, dim3(pgx::grid_for(pgx::ceil_div(n * channels, kVec), kBlock)), dim3(kBlock), 0,
+                       pgx::stream(), out, in, gain, n, channels, gain_channels, al);
+    PGX_LAUNCH_CHECK("k_gain_vec");
+    return PGX_OK;
+}
+
+int pgx_mix_n(float *out, const float *const *ins_host, int k, int64_t n_elems) {
+    PGX_REQUIRE_INIT();
+    if (n_elems <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && ins_host && k >= 1, "pgx_mix_n: bad argument");
+    bool al = is_aligned16(out);
+    for (int i = 0; i < k; ++i) {
+        PGX_CHECK_ARG(ins_host[i] != nullptr, "pgx_mix_n: null input");
+        al = al && is_aligned16(ins_host[i]);
+    }
+    int done = 0;
+    while (done < k) {
+        MixPtrs ptrs;
+        int cnt = (k - done < kMixMax) ? (k - done) : kMixMax;
+        for (int i = 0; i < kMixMax; ++i) ptrs.p[i] = (i < cnt) ? ins_host[done + i] : nullptr;
+        hipLaunchKernelGGL(k_mix_n, dim3(pgx::grid_for(pgx::ceil_div(n_elems, kVec), kBlock)), dim3(kBlock), 0,
+                           pgx::stream(), out, ptrs, cnt, done > 0 ? 1 : 0, n_elems, al);
+        PGX_LAUNCH_CHECK("k_mix_n");
+        done += cnt;
+    }
+    return PGX_OK;
+}
+
+int pgx_mix_batch(float *out, const float *in, int64_t in_stride, int batch, int64_t n_elems) {
+    PGX_REQUIRE_INIT();
+    if (n_elems <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && batch >= 1 && in_stride >= n_elems, "pgx_mix_batch: bad argument");
+    bool al = is_aligned16(out) && is_aligned16(in) && (in_stride % 4 == 0);
+    hipLaunchKernelGGL(k_mix_batch, dim3(pgx::grid_for(pgx::ceil_div(n_elems, kVec), kBlock)), dim3(kBlock), 0,
+                       pgx::stream(), out, in, in_stride, batch, n_elems, al);
+    PGX_LAUNCH_CHECK("k_mix_batch");
+    return PGX_OK;
+}
+
+int pgx_periodic_gate(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
+                      const pgx_gate_params *params) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params, "pgx_periodic_gate: null pointer");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_periodic_gate: out_stride too small");
+    PGX_CHECK_ARG(batch <= 65535, "pgx_periodic_gate: batch too large");
+    dim3 grid(pgx::grid_for(pgx::ceil_div(n, kVec), kBlock), batch);
+    hipLaunchKernelGGL(k_periodic_gate, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, start, n, params);
+    PGX_LAUNCH_CHECK("k_periodic_gate");
+    return PGX_OK;
+}
+
+int pgx_periodic_trigger(float *out, int64_t start, int64_t n, int64_t period, int64_t phase_samples,
+                         float amplitude) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && period > 0, "pgx_periodic_trigger: bad argument");
+    hipLaunchKernelGGL(k_periodic_trigger, dim3(pgx::grid_for(pgx::ceil_div(n, kVec), kBlock)), dim3(kBlock), 0,
+                       pgx::stream(), out, start, n, period, phase_samples, amplitude, is_aligned16(out));
+    PGX_LAUNCH_CHECK("k_periodic_trigger");
+    return PGX_OK;
+}
+
+int pgx_supersaw_sum(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                     const float *voices, const double *amp_scalar, const float *amp, int64_t amp_stride) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && voices && nvoices >= 1 && channels >= 1, "pgx_supersaw_sum: bad argument");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_sum: out_stride too small");
+    PGX_CHECK_ARG(batch <= 65535, "pgx_supersaw_sum: batch too large");
+    dim3 grid(pgx::grid_for(n, kBlock), batch);
+    hipLaunchKernelGGL(k_supersaw_sum, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, nvoices, n,
+                       channels, voices, amp_scalar, amp, amp_stride);
+    PGX_LAUNCH_CHECK("k_supersaw_sum");
+    return PGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// pgx_runtime.hip -- device selection, library stream, pooled device memory, copies, events.
+//
+// Host-side plumbing for the C ABI in include/pygmu_hip.h.  The pool keeps freed blocks in
+// power-of-two size classes; because every kernel and copy is ordered on the one library
+// stream, a block may be handed out again as soon as it is freed.
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "pgx_common.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::map<size_t, std::vector<void *>> free_lists;   // size class -> blocks
+    std::unordered_map<void *, size_t> live;             // ptr -> size class
+    size_t bytes_cached = 0;
+};
+
+Runtime &rt() {
+    static Runtime r;
+    return r;
+}
+
+size_t size_class(size_t bytes) {
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+
+}  // namespace
+
+namespace pgx {
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+hipStream_t stream() { return rt().stream; }
+bool initialised() { return rt().ready; }
+
+}  // namespace pgx
+
+extern "C" {
+
+int pgx_abi_version(void) { return 1; }
+
+const char *pgx_last_error(void) { return g_last_error.c_str(); }
+
+int pgx_device_count(int *count) {
+    PGX_CHECK_ARG(count != nullptr, "pgx_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return pgx::fail(PGX_ERR_RUNTIME, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return PGX_OK;
+}
+
+int pgx_init(int device) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (r.ready) {
+        if (r.device != device)
+            return pgx::fail(PGX_ERR_INVALID, "pgx_init: already initialised on another device");
+        return PGX_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return pgx::fail(PGX_ERR_NOT_INIT, "pgx_init: no HIP device available");
+    PGX_CHECK_ARG(device >= 0 && device < n, "pgx_init: device index out of range");
+    PGX_HIP(hipSetDevice(device));
+    PGX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.device = device;
+    r.ready = true;
+    return PGX_OK;
+}
+
+int pgx_pool_trim(void) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (!r.ready) return PGX_OK;
+    (void)hipStreamSynchronize(r.stream);
+    for (auto &kv : r.free_lists)
+        for (void *p : kv.second) (void)hipFree(p);
+    r.free_lists.clear();
+    r.bytes_cached = 0;
+    return PGX_OK;
+}
+
+int pgx_shutdown(void) {
+    Runtime &r = rt();
+    if (!r.ready) return PGX_OK;
+    pgx_pool_trim();
+    std::lock_guard<std::mutex> lock(r.mu);
+    for (auto &kv : r.live) (void)hipFree(kv.first);
+    r.live.clear();
+    (void)hipStreamDestroy(r.stream);
+    r.stream = nullptr;
+    r.ready = false;
+    r.device = -1;
+    return PGX_OK;
+}
+
+int pgx_device_name(char *buf, size_t len) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(buf != nullptr && len > 0, "pgx_device_name: bad buffer");
+    hipDeviceProp_t prop;
+    PGX_HIP(hipGetDeviceProperties(&prop, rt().device));
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return PGX_OK;
+}
+
+void *pgx_stream_handle(void) { return (void *)rt().stream; }
+
+int pgx_stream_sync(void) {
+    PGX_REQUIRE_INIT();
+    PGX_HIP(hipStreamSynchronize(rt().stream));
+    return PGX_OK;
+}
+
+int pgx_malloc(void **dptr, size_t bytes) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(dptr != nullptr, "pgx_malloc: null output");
+    Runtime &r = rt();
+    size_t cls = size_class(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lock(r.mu);
+        auto it = r.free_lists.find(cls);
+        if (it != r.free_lists.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            r.bytes_cached -= cls;
+            r.live[p] = cls;
+            *dptr = p;
+            return PGX_OK;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e == hipErrorOutOfMemory) {
+        pgx_pool_trim();
+        e = hipMalloc(&p, cls);
+    }
+    if (e != hipSuccess)
+        return pgx::fail(e == hipErrorOutOfMemory ? PGX_ERR_NOMEM : PGX_ERR_RUNTIME,
+                         std::string("hipMalloc: ") + hipGetErrorString(e));
+    {
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.live[p] = cls;
+    }
+    *dptr = p;
+    return PGX_OK;
+}
+
+int pgx_free(void *dptr) {
+    if (dptr == nullptr) return PGX_OK;
+    Runtime &r = rt();
+    if (!r.ready) return PGX_OK;   // shutdown already released everything
+    std::lock_guard<std::mutex> lock(r.mu);
+    auto it = r.live.find(dptr);
+    if (it == r.live.end()) return pgx::fail(PGX_ERR_INVALID, "pgx_free: unknown pointer");
+    size_t cls = it->second;
+    r.live.erase(it);
+    r.free_lists[cls].push_back(dptr);
+    r.bytes_cached += cls;
+    return PGX_OK;
+}
+
+int pgx_memset(void *dptr, int byte_value, size_t bytes) {
+    PGX_REQUIRE_INIT();
+    if (bytes == 0) return PGX_OK;
+    PGX_CHECK_ARG(dptr != nullptr, "pgx_memset: null pointer");
+    PGX_HIP(hipMemsetAsync(dptr, byte_value, bytes, rt().stream));
+    return PGX_OK;
+}
+
+int pgx_memcpy_h2d(void *dst, const void *src_host, size_t bytes) {
+    PGX_REQUIRE_INIT();
+    if (bytes == 0) return PGX_OK;
+    PGX_CHECK_ARG(dst != nullptr && src_host != nullptr, "pgx_memcpy_h2d: null pointer");
+    PGX_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, rt().stream));
+    PGX_HIP(hipStreamSynchronize(rt().stream));
+    return PGX_OK;
+}
+
+int pgx_memcpy_d2h(void *dst_host, const void *src, size_t bytes) {
+    PGX_REQUIRE_INIT();
+    if (bytes == 0) return PGX_OK;
+    PGX_CHECK_ARG(dst_host != nullptr && src != nullptr, "pgx_memcpy_d2h: null pointer");
+    PGX_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, rt().stream));
+    PGX_HIP(hipStreamSynchronize(rt().stream));
+    return PGX_OK;
+}
+
+int pgx_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    PGX_REQUIRE_INIT();
+    if (bytes == 0) return PGX_OK;
+    PGX_CHECK_ARG(dst != nullptr && src != nullptr, "pgx_memcpy_d2d: null pointer");
+    PGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().stream));
+    return PGX_OK;
+}
+
+int pgx_event_create(void **event) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(event != nullptr, "pgx_event_create: null output");
+    hipEvent_t ev;
+    PGX_HIP(hipEventCreate(&ev));
+    *event = (void *)ev;
+    return PGX_OK;
+}
+
+int pgx_event_destroy(void *event) {
+    if (event == nullptr) return PGX_OK;
+    PGX_HIP(hipEventDestroy((hipEvent_t)event));
+    return PGX_OK;
+}
+
+int pgx_event_record(void *event) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(event != nullptr, "pgx_event_record: null event");
+    PGX_HIP(hipEventRecord((hipEvent_t)event, rt().stream));
+    return PGX_OK;
+}
+
+int pgx_event_elapsed_ms(void *start, void *stop, float *ms) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(start && stop && ms, "pgx_event_elapsed_ms: null argument");
+    PGX_HIP(hipEventSynchronize((hipEvent_t)stop));
+    PGX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PGX_OK;
+}
+
+}  // extern "C"

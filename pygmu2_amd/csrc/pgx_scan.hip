@@ -1,0 +1,821 @@
+// pgx_scan.hip -- linear-recurrence PEs evaluated as parallel scans over affine state maps.
+//
+//   BiquadPE (constant)  : 2-state constant map      z' = A z + B x      (biquad_pe.py:383-404)
+//   BiquadPE (varying)   : 2-state time-varying map  [y;y1]' = M_n [y1;y2] + [ff_n;0] (biquad_pe.py:35-62)
+//   BlitSawPE            : prefix sum (phase) + 1-state constant map (leaky integrator)
+//                          (blit_saw_pe.py:150-264)
+//   SinePE (stateful)    : prefix sum (phase)        (sine_pe.py:177-232)
+//
+// Common structure (wave64, 256-thread workgroups = 4 waves):
+//   * a tile is 256 threads x T consecutive frames; every thread folds its T frames into one
+//     affine map starting from the zero state (pass 1),
+//   * the 64 per-lane maps of a wave are combined with a Kogge-Stone scan over __shfl_up
+//     (6 steps; for constant maps only the offset vector travels, the matrix powers
+//     A^(T*2^k) are loop invariants kept in LDS),
+//   * the 4 wave totals cross through LDS; the tile's carry-out feeds the next tile of the
+//     same chain in registers,
+//   * every thread then re-runs its T frames from its scanned carry-in in EXACTLY the
+//     reference's float64 operation order (pass 2) and stores float32.
+// So the only departure from the reference's sequential float64 arithmetic is the rounding
+// of each chunk's carry-in (O(1e-16) relative); everything is compiled with -ffp-contract=off.
+//
+// Long single chains (BiquadPE over 1M frames) are cut into segments, one workgroup each:
+// a reduce launch produces every segment's zero-state response, the apply launch folds the
+// preceding aggregates (binary powers of A^segment) into its carry-in.  Many short chains
+// (voices) use one workgroup per chain and no cross-workgroup traffic at all.
+
+#include "pgx_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+struct V2 {
+    double x, y;
+};
+struct M2 {
+    double a, b, c, d;   // [[a b],[c d]]
+};
+
+__device__ __forceinline__ M2 mm(const M2 &p, const M2 &q) {   // p*q
+    M2 r;
+    r.a = p.a * q.a + p.b * q.c;
+    r.b = p.a * q.b + p.b * q.d;
+    r.c = p.c * q.a + p.d * q.c;
+    r.d = p.c * q.b + p.d * q.d;
+    return r;
+}
+__device__ __forceinline__ V2 mv(const M2 &p, const V2 &v) {
+    V2 r;
+    r.x = p.a * v.x + p.b * v.y;
+    r.y = p.c * v.x + p.d * v.y;
+    return r;
+}
+__device__ __forceinline__ V2 vadd(const V2 &p, const V2 &q) { return V2{p.x + q.x, p.y + q.y}; }
+__device__ __forceinline__ M2 m_identity() { return M2{1.0, 0.0, 0.0, 1.0}; }
+
+__device__ __forceinline__ V2 shfl_up_v2(const V2 &v, int d) {
+    return V2{__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64)};
+}
+__device__ __forceinline__ M2 shfl_up_m2(const M2 &m, int d) {
+    return M2{__shfl_up(m.a, d, 64), __shfl_up(m.b, d, 64), __shfl_up(m.c, d, 64), __shfl_up(m.d, d, 64)};
+}
+
+__device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// Load / store T consecutive frames of one channel of a (frames, channels) float32 buffer.
+template <int T>
+__device__ __forceinline__ void load_frames(const float *base, int64_t f0, int64_t n, int channels, int ch,
+                                            float (&x)[T]) {
+    if (channels == 1 && f0 + T <= n && aligned16(base + f0)) {
+#pragma unroll
+        for (int j = 0; j < T; j += 4) {
+            float4 t = *reinterpret_cast<const float4 *>(base + f0 + j);
+            x[j] = t.x; x[j + 1] = t.y; x[j + 2] = t.z; x[j + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j) x[j] = (f0 + j < n) ? base[(f0 + j) * channels + ch] : 0.0f;
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void store_frames(float *base, int64_t f0, int64_t n, int channels, int ch,
+                                             const float (&y)[T]) {
+    if (channels == 1 && f0 + T <= n && aligned16(base + f0)) {
+#pragma unroll
+        for (int j = 0; j < T; j += 4)
+            *reinterpret_cast<float4 *>(base + f0 + j) = make_float4(y[j], y[j + 1], y[j + 2], y[j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+            if (f0 + j < n) base[(f0 + j) * channels + ch] = y[j];
+    }
+}
+
+// Store T frames of a mono result replicated over `channels` output channels (np.tile).
+template <int T>
+__device__ __forceinline__ void store_frames_tiled(float *base, int64_t f0, int64_t n, int channels,
+                                                   const float (&y)[T]) {
+    if (channels == 1) {
+        store_frames<T>(base, f0, n, 1, 0, y);
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+            if (f0 + j < n)
+                for (int c = 0; c < channels; ++c) base[(f0 + j) * channels + c] = y[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-wide exclusive prefix sum of one double per thread (sequential-in-lane order), plus the
+// block total.  `lds` must hold kWaves doubles.  Contains two __syncthreads.
+__device__ __forceinline__ double block_excl_sum(double v, double *lds, double &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = o + inc;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    double woff = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        double t = lds[w];
+        if (w < wave) woff = woff + t;
+        tot = tot + t;
+    }
+    __syncthreads();
+    total = tot;
+    double ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0.0;
+    return woff + ex;
+}
+
+// Block-wide scan for the scalar constant map y' = lam^len * y + b.  On entry `e` is this thread's
+// zero-state chunk response; lamp[k] = lam^(T*2^k) for k=0..5, lam_wave = lam^(T*64),
+// lam_lane = lam^(T*lane).  Returns this thread's carry-in given the tile carry-in `carry`, and
+// updates `carry` to the tile carry-out.  `lds` holds kWaves doubles.
+__device__ __forceinline__ double block_scan_scalar_affine(double e, const double (&lamp)[6], double lam_wave,
+                                                           double lam_lane, double *lds, double &carry) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = e;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double o = __shfl_up(inc, 1 << k, 64);
+        if (lane >= (1 << k)) inc = lamp[k] * o + inc;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    double cw = carry, cn = carry;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        double t = lds[w];
+        if (w < wave) cw = lam_wave * cw + t;
+        cn = lam_wave * cn + t;
+    }
+    __syncthreads();
+    carry = cn;
+    double ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0.0;
+    return lam_lane * cw + ex;
+}
+
+// ================================================================================================
+// BiquadPE, constant coefficients
+// ================================================================================================
+constexpr int kBqT = 16;                       // frames per thread per tile
+constexpr int kBqTile = kBlock * kBqT;         // 4096 frames
+constexpr int kBqMaxSeg = 1024;
+constexpr int kBqPow = 11;                     // binary powers of A^segment kept for the fold
+
+struct BqShared {
+    M2 pstep[6];       // A^(T*2^k)
+    M2 pwave;          // A^(T*64)
+    M2 ptile;          // A^(T*256)
+    M2 pseg[kBqPow];   // (A^segment)^(2^k)
+    V2 wave_tot[kWaves];
+    V2 red[kWaves];
+};
+
+// MODE 0: reduce (write the segment's zero-state response to agg); MODE 1: apply (produce output).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_stride, int64_t n, int channels,
+               const double *coef, double *state, const double *state_snapshot, double *agg, int seg_tiles,
+               int nseg) {
+    __shared__ BqShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chain = blockIdx.y;
+    const int inst = chain / channels, ch = chain - inst * channels;
+    const int seg = blockIdx.x;
+
+    const double b0 = coef[inst * 5 + 0], b1 = coef[inst * 5 + 1], b2 = coef[inst * 5 + 2];
+    const double a1 = coef[inst * 5 + 3], a2 = coef[inst * 5 + 4];
+
+    // ---- loop-invariant matrix powers (thread 0 -> LDS) ----
+    if (tid == 0) {
+        M2 A{-a1, 1.0, -a2, 0.0};
+        M2 p = A;
+#pragma unroll
+        for (int s = 1; s < kBqT; s <<= 1) p = mm(p, p);     // A^T (T is a power of two)
+        for (int k = 0; k < 6; ++k) {
+            sh.pstep[k] = p;
+            p = mm(p, p);
+        }
+        sh.pwave = p;                                        // A^(64 T)
+        p = mm(p, p);
+        p = mm(p, p);
+        sh.ptile = p;                                        // A^(256 T)
+        if (nseg > 1) {
+            // A^segment = ptile^seg_tiles (binary exponentiation), then its binary powers.
+            M2 r = m_identity(), q = p;
+            for (int e = seg_tiles; e > 0; e >>= 1) {
+                if (e & 1) r = mm(r, q);
+                q = mm(q, q);
+            }
+            for (int k = 0; k < kBqPow; ++k) {
+                sh.pseg[k] = r;
+                r = mm(r, r);
+            }
+        }
+    }
+    __syncthreads();
+
+    M2 mlane = m_identity();                                  // A^(T*lane)
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (lane & (1 << k)) mlane = mm(sh.pstep[k], mlane);
+
+    // ---- segment carry-in ----
+    V2 carry{0.0, 0.0};
+    if (MODE == 1) {
+        if (nseg == 1) {
+            carry = V2{state[chain * 2 + 0], state[chain * 2 + 1]};
+        } else {
+            // carry = (A^seg)^seg_index * z_init + sum_{j<seg} (A^seg)^(seg-1-j) * agg_j
+            V2 part{0.0, 0.0};
+            for (int j = tid; j <= seg; j += kBlock) {
+                V2 v;
+                int e;
+                if (j == seg) {                               // the initial-state term
+                    v = V2{state_snapshot[chain * 2 + 0], state_snapshot[chain * 2 + 1]};
+                    e = seg;
+                } else {
+                    v = V2{agg[((int64_t)chain * nseg + j) * 2 + 0], agg[((int64_t)chain * nseg + j) * 2 + 1]};
+                    e = seg - 1 - j;
+                }
+                for (int k = 0; k < kBqPow; ++k)
+                    if (e & (1 << k)) v = mv(sh.pseg[k], v);
+                part = vadd(part, v);
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                part.x += __shfl_down(part.x, d, 64);
+                part.y += __shfl_down(part.y, d, 64);
+            }
+            if (lane == 0) sh.red[wave] = part;
+            __syncthreads();
+            carry = V2{0.0, 0.0};
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) carry = vadd(carry, sh.red[w]);
+            __syncthreads();
+        }
+    }
+
+    const float *ib = in + (int64_t)inst * in_stride;
+    float *ob = out + (int64_t)inst * out_stride;
+    V2 final_state{0.0, 0.0};
+    bool have_final = false;
+
+    const int64_t tile0 = (int64_t)seg * seg_tiles;
+    for (int t = 0; t < seg_tiles; ++t) {
+        const int64_t base = (tile0 + t) * kBqTile;
+        if (base >= n) break;
+        const int64_t f0 = base + (int64_t)tid * kBqT;
+        float xf[kBqT];
+        load_frames<kBqT>(ib, f0, n, channels, ch, xf);
+
+        // pass 1: zero-state response of this chunk
+        V2 e{0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < kBqT; ++j) {
+            double x = (double)xf[j];
+            double y = e.x + b0 * x;
+            double z0 = (e.y + b1 * x) - a1 * y;
+            e.y = b2 * x - a2 * y;
+            e.x = z0;
+        }
+        // wave scan (offset vectors only; the matrices are the LDS-resident powers)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            V2 o = shfl_up_v2(e, 1 << k);
+            if (lane >= (1 << k)) e = vadd(mv(sh.pstep[k], o), e);
+        }
+        if (lane == 63) sh.wave_tot[wave] = e;
+        __syncthreads();
+        V2 cw = carry, cn = carry;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            V2 tot = sh.wave_tot[w];
+            if (w < wave) cw = vadd(mv(sh.pwave, cw), tot);
+            cn = vadd(mv(sh.pwave, cn), tot);
+        }
+        __syncthreads();
+        carry = cn;
+
+        if (MODE == 1) {
+            V2 ex = shfl_up_v2(e, 1);
+            if (lane == 0) ex = V2{0.0, 0.0};
+            V2 z = vadd(mv(mlane, cw), ex);
+            float yf[kBqT];
+            // pass 2: scipy lfilter DF-II-T operation order from the scanned carry-in
+#pragma unroll
+            for (int j = 0; j < kBqT; ++j) {
+                double x = (double)xf[j];
+                double y = z.x + b0 * x;
+                double z0 = (z.y + b1 * x) - a1 * y;
+                z.y = b2 * x - a2 * y;
+                z.x = z0;
+                yf[j] = (float)y;
+                if (f0 + j == n - 1) {
+                    final_state = z;
+                    have_final = true;
+                }
+            }
+            store_frames<kBqT>(ob, f0, n, channels, ch, yf);
+        }
+    }
+    if (MODE == 0) {
+        if (tid == 0) {
+            agg[((int64_t)chain * nseg + seg) * 2 + 0] = carry.x;
+            agg[((int64_t)chain * nseg + seg) * 2 + 1] = carry.y;
+        }
+    } else if (have_final) {
+        state[chain * 2 + 0] = final_state.x;
+        state[chain * 2 + 1] = final_state.y;
+    }
+}
+
+struct BqPlan {
+    int seg_tiles;
+    int nseg;
+};
+
+BqPlan biquad_plan(int batch, int64_t n, int channels) {
+    int64_t tiles = pgx::ceil_div(n, kBqTile);
+    int64_t chains = (int64_t)batch * channels;
+    int64_t want = 512 / chains;                  // aim for ~512 workgroups (2 per CU) in flight
+    if (want < 1) want = 1;
+    if (want > kBqMaxSeg) want = kBqMaxSeg;
+    if (want > tiles) want = tiles;
+    BqPlan p;
+    p.seg_tiles = (int)pgx::ceil_div(tiles, want);
+    p.nseg = (int)pgx::ceil_div(tiles, p.seg_tiles);
+    return p;
+}
+
+// ================================================================================================
+// BlitSawPE
+// ================================================================================================
+constexpr int kSawT = 8;
+constexpr int kSawTile = kBlock * kSawT;   // 2048 frames
+constexpr double kPi = 3.141592653589793;
+
+struct SawShared {
+    double sum[kWaves];
+    double aff[kWaves];
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, const pgx_blitsaw_params *params,
+          const float *freq, int64_t freq_stride, const float *amp, int64_t amp_stride, const float *mstream,
+          int64_t m_stride, double *state) {
+    __shared__ SawShared sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int inst = blockIdx.x;
+    const pgx_blitsaw_params p = params[inst];
+    float *ob = out + (int64_t)inst * out_stride;
+    const float *fs = freq ? freq + (int64_t)inst * freq_stride : nullptr;
+    const float *as = amp ? amp + (int64_t)inst * amp_stride : nullptr;
+    const float *ms = mstream ? mstream + (int64_t)inst * m_stride : nullptr;
+
+    const double phase0 = state[inst * 2 + 0];
+    double carry_sum = 0.0;                 // running np.cumsum(phase_inc) at the tile start
+    double carry_y = state[inst * 2 + 1];   // leaky integrator output y[n-1]
+
+    // powers of leak for the affine scan
+    const double leak = p.leak;
+    double lamp[6], lam_wave, lam_lane = 1.0;
+    {
+        double l = leak;
+#pragma unroll
+        for (int s = 1; s < kSawT; s <<= 1) l = l * l;      // leak^T
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            lamp[k] = l;
+            if (lane & (1 << k)) lam_lane = lam_lane * l;
+            l = l * l;
+        }
+        lam_wave = l;
+    }
+
+    double final_phase = 0.0, final_y = 0.0;
+    bool have_final = false;
+
+    for (int64_t base = 0; base < n; base += kSawTile) {
+        const int64_t f0 = base + (int64_t)tid * kSawT;
+        double fr[kSawT], inc[kSawT];
+        // ---- frequency and phase increment (blit_saw_pe.py:188) ----
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            double f = p.freq;
+            if (fs) f = (f0 + j < n) ? (double)fs[f0 + j] : 0.0;
+            fr[j] = f;
+            inc[j] = (f0 + j < n) ? f / sr : 0.0;
+        }
+        // local inclusive cumsum, then block exclusive offset (np.cumsum, :191)
+        double loc[kSawT];
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            run = run + inc[j];
+            loc[j] = run;
+        }
+        double tile_total;
+        double off = block_excl_sum(run, sh.sum, tile_total);
+        const double chunk_base = carry_sum + off;
+        carry_sum = carry_sum + tile_total;
+
+        // ---- Dirichlet kernel (blit_saw_pe.py:194-217) ----
+        double xb[kSawT];
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            double ph = phase0 + (chunk_base + loc[j]);
+            ph = fmod(ph, 1.0);
+            if (ph < 0.0) ph += 1.0;
+            double fmax1 = fr[j] > 1.0 ? fr[j] : 1.0;          // np.maximum(freq, 1.0)
+            double m;
+            if (ms) {
+                float mvf = (f0 + j < n) ? ms[f0 + j] : 1.0f;
+                int mi = (int)(double)mvf;                     // astype(int32): truncation
+                m = (double)(mi > 1 ? mi : 1);
+            } else if (p.m > 0.0) {
+                int mi = (int)p.m;
+                m = (double)(mi > 1 ? mi : 1);
+            } else {
+                double m_float = sr / (2.0 * fmax1);
+                int mi = (int)floor(m_float);
+                mi = mi - (1 - (mi % 2));
+                m = (double)(mi > 1 ? mi : 1);
+            }
+            double P = sr / fmax1;
+            double theta = kPi * ph;
+            double m_theta = m * theta;
+            double sin_num = sin(m_theta);
+            double sin_den = sin(theta);
+            double blit = (fabs(sin_den) < 1e-9) ? (m / P) : (sin_num / (P * sin_den));
+            xb[j] = blit - 1.0 / P;
+            if (f0 + j == n - 1) {
+                final_phase = ph;
+                have_final = true;
+            }
+            if (f0 + j >= n) xb[j] = 0.0;
+        }
+
+        // ---- leaky integrator y[n] = x[n] + leak*y[n-1] (blit_saw_pe.py:222-234) ----
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
+        double y = block_scan_scalar_affine(e, lamp, lam_wave, lam_lane, sh.aff, carry_y);
+
+        float yf[kSawT];
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            double z = leak * y;
+            y = z + xb[j];
+            double a = p.amp;
+            if (as) a = (f0 + j < n) ? (double)as[f0 + j] : 0.0;
+            yf[j] = (float)((y * 2.0) * a);
+            if (f0 + j == n - 1) final_y = y;
+        }
+        store_frames_tiled<kSawT>(ob, f0, n, channels, yf);
+    }
+    if (have_final) {
+        state[inst * 2 + 0] = final_phase;
+        state[inst * 2 + 1] = final_y;
+    }
+}
+
+// ================================================================================================
+// SinePE, stateful path
+// ================================================================================================
+constexpr int kSinT = 8;
+constexpr int kSinTile = kBlock * kSinT;
+
+__global__ void __launch_bounds__(kBlock)
+k_sine_stateful(float *out, int64_t n, int channels, double sr, const pgx_sine_stateful_params *params,
+                const float *freq, const float *amp, const float *phase_mod, double *state) {
+    __shared__ double lds[kWaves];
+    const int tid = threadIdx.x;
+    const pgx_sine_stateful_params p = params[0];
+    const double two_pi = 2.0 * kPi;
+    // sine_pe.py:203-214: first render starts from the scalar phase (0 when phase is a PE)
+    const bool inited = state[1] != 0.0;
+    const double initial = inited ? state[0] : (p.phase_is_stream ? 0.0 : p.phase);
+    double carry_sum = 0.0;
+    double final_phase = 0.0;
+    bool have_final = false;
+
+    for (int64_t base = 0; base < n; base += kSinTile) {
+        const int64_t f0 = base + (int64_t)tid * kSinT;
+        double loc[kSinT];
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSinT; ++j) {
+            double f = p.freq;
+            if (freq) f = (f0 + j < n) ? (double)freq[f0 + j] : 0.0;
+            double inc = (f0 + j < n) ? (two_pi * f) / sr : 0.0;
+            run = run + inc;
+            loc[j] = run;
+        }
+        double tile_total;
+        double off = block_excl_sum(run, lds, tile_total);
+        const double chunk_base = carry_sum + off;
+        carry_sum = carry_sum + tile_total;
+
+        float yf[kSinT];
+#pragma unroll
+        for (int j = 0; j < kSinT; ++j) {
+            double ph = (chunk_base + loc[j]) + initial;             // cumsum + initial_phase (:217)
+            double pm = p.phase;
+            if (phase_mod) pm = (f0 + j < n) ? (double)phase_mod[f0 + j] : 0.0;
+            ph = ph + pm;                                            // + phase_mod (:220-223)
+            double a = p.amp;
+            if (amp) a = (f0 + j < n) ? (double)amp[f0 + j] : 0.0;
+            yf[j] = (float)(a * sin(ph));
+            if (f0 + j == n - 1) {
+                final_phase = ph;
+                have_final = true;
+            }
+        }
+        store_frames_tiled<kSinT>(out, f0, n, channels, yf);
+    }
+    if (have_final) {
+        state[0] = final_phase;
+        state[1] = 1.0;
+    }
+}
+
+// ================================================================================================
+// BiquadPE, time-varying coefficients
+// ================================================================================================
+constexpr int kBvT = 4;
+constexpr int kBvTile = kBlock * kBvT;
+
+struct BvShared {
+    M2 wm[kWaves];
+    V2 wv[kWaves];
+};
+
+// RBJ cookbook coefficients for one sample (biquad_pe.py:217-335), normalised by a0.
+__device__ __forceinline__ void rbj(int mode, double f, double q, double A, double sqrtA, double sr, double &b0,
+                                    double &b1, double &b2, double &a1, double &a2) {
+    const double nyq99 = (sr / 2.0) * 0.99;
+    f = f < 1.0 ? 1.0 : (f > nyq99 ? nyq99 : f);              // np.clip(freq, 1.0, nyquist*0.99)
+    q = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
+    double omega = ((2.0 * kPi) * f) / sr;
+    double sn = sin(omega), cs = cos(omega);
+    double alpha = sn / (2.0 * q);
+    double a0;
+    switch (mode) {
+    case 0:
+        b0 = (1.0 - cs) / 2.0; b1 = 1.0 - cs; b2 = (1.0 - cs) / 2.0;
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha;
+        break;
+    case 1:
+        b0 = (1.0 + cs) / 2.0; b1 = -(1.0 + cs); b2 = (1.0 + cs) / 2.0;
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha;
+        break;
+    case 2:
+        b0 = alpha; b1 = 0.0; b2 = -alpha;
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha;
+        break;
+    case 3:
+        b0 = 1.0; b1 = -2.0 * cs; b2 = 1.0;
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha;
+        break;
+    case 4:
+        b0 = 1.0 - alpha; b1 = -2.0 * cs; b2 = 1.0 + alpha;
+        a0 = 1.0 + alpha; a1 = -2.0 * cs; a2 = 1.0 - alpha;
+        break;
+    case 5:
+        b0 = 1.0 + alpha * A; b1 = -2.0 * cs; b2 = 1.0 - alpha * A;
+        a0 = 1.0 + alpha / A; a1 = -2.0 * cs; a2 = 1.0 - alpha / A;
+        break;
+    case 6:
+        b0 = A * (((A + 1.0) - (A - 1.0) * cs) + (2.0 * sqrtA) * alpha);
+        b1 = (2.0 * A) * ((A - 1.0) - (A + 1.0) * cs);
+        b2 = A * (((A + 1.0) - (A - 1.0) * cs) - (2.0 * sqrtA) * alpha);
+        a0 = ((A + 1.0) + (A - 1.0) * cs) + (2.0 * sqrtA) * alpha;
+        a1 = -2.0 * ((A - 1.0) + (A + 1.0) * cs);
+        a2 = ((A + 1.0) + (A - 1.0) * cs) - (2.0 * sqrtA) * alpha;
+        break;
+    default:
+        b0 = A * (((A + 1.0) + (A - 1.0) * cs) + (2.0 * sqrtA) * alpha);
+        b1 = (-2.0 * A) * ((A - 1.0) + (A + 1.0) * cs);
+        b2 = A * (((A + 1.0) + (A - 1.0) * cs) - (2.0 * sqrtA) * alpha);
+        a0 = ((A + 1.0) - (A - 1.0) * cs) + (2.0 * sqrtA) * alpha;
+        a1 = 2.0 * ((A - 1.0) - (A + 1.0) * cs);
+        a2 = ((A + 1.0) - (A - 1.0) * cs) - (2.0 * sqrtA) * alpha;
+        break;
+    }
+    b0 = b0 / a0; b1 = b1 / a0; b2 = b2 / a0; a1 = a1 / a0; a2 = a2 / a0;
+}
+
+// One workgroup per channel chain.  State map per sample: (y1,y2) -> (y0,y1) with
+// y0 = ((ff - a1*y1) - a2*y2), ff = (b0*x + b1*x1) + b2*x2  (biquad_pe.py:53-55 grouping).
+__global__ void __launch_bounds__(kBlock)
+k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr,
+                 const pgx_biquad_var_params *params, const float *freq, const float *qs, double A,
+                 double sqrtA, double *state) {
+    __shared__ BvShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = blockIdx.x;
+    const pgx_biquad_var_params p = params[0];
+    double *st = state + ch * 4;                    // x1,x2,y1,y2
+    const double sx1 = st[0], sx2 = st[1];
+    V2 carry{st[2], st[3]};                         // (y1, y2)
+    V2 final_y{0.0, 0.0};
+    bool have_final = false;
+
+    for (int64_t base = 0; base < n; base += kBvTile) {
+        const int64_t f0 = base + (int64_t)tid * kBvT;
+        double ff[kBvT], ca1[kBvT], ca2[kBvT];
+        // x history for the feed-forward part
+        double xm1, xm2;
+        {
+            int64_t i1 = f0 - 1, i2 = f0 - 2;
+            xm1 = (i1 >= 0) ? ((i1 < n) ? (double)in[i1 * channels + ch] : 0.0) : (i1 == -1 ? sx1 : sx2);
+            xm2 = (i2 >= 0) ? ((i2 < n) ? (double)in[i2 * channels + ch] : 0.0) : (i2 == -1 ? sx1 : sx2);
+        }
+        M2 cm = m_identity();
+        V2 cv{0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < kBvT; ++j) {
+            const bool live = (f0 + j < n);
+            double x = live ? (double)in[(f0 + j) * channels + ch] : 0.0;
+            double f = p.freq, q = p.q;
+            if (freq) f = live ? (double)freq[f0 + j] : 1000.0;
+            if (qs) q = live ? (double)qs[f0 + j] : 1.0;
+            double b0, b1, b2, a1, a2;
+            rbj(p.mode, f, q, A, sqrtA, sr, b0, b1, b2, a1, a2);
+            ff[j] = (b0 * x + b1 * xm1) + b2 * xm2;
+            ca1[j] = a1;
+            ca2[j] = a2;
+            xm2 = xm1;
+            xm1 = x;
+            if (live) {
+                // compose: s' = M s + v with M = [[-a1,-a2],[1,0]], v = [ff,0]
+                M2 nm;
+                nm.a = -a1 * cm.a - a2 * cm.c;
+                nm.b = -a1 * cm.b - a2 * cm.d;
+                nm.c = cm.a;
+                nm.d = cm.b;
+                V2 nv;
+                nv.x = (ff[j] - a1 * cv.x) - a2 * cv.y;
+                nv.y = cv.x;
+                cm = nm;
+                cv = nv;
+            }
+        }
+        // inclusive wave scan over (matrix, vector) pairs: right o left
+        M2 im = cm;
+        V2 iv = cv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            M2 om = shfl_up_m2(im, 1 << k);
+            V2 ov = shfl_up_v2(iv, 1 << k);
+            if (lane >= (1 << k)) {
+                iv = vadd(mv(im, ov), iv);
+                im = mm(im, om);
+            }
+        }
+        if (lane == 63) {
+            sh.wm[wave] = im;
+            sh.wv[wave] = iv;
+        }
+        __syncthreads();
+        V2 cw = carry, cn = carry;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            M2 tm = sh.wm[w];
+            V2 tv = sh.wv[w];
+            if (w < wave) cw = vadd(mv(tm, cw), tv);
+            cn = vadd(mv(tm, cn), tv);
+        }
+        __syncthreads();
+        carry = cn;
+        // exclusive prefix within the wave applied to the wave carry-in
+        M2 em = shfl_up_m2(im, 1);
+        V2 ev = shfl_up_v2(iv, 1);
+        V2 s = cw;
+        if (lane > 0) s = vadd(mv(em, cw), ev);
+
+        float yf[kBvT];
+#pragma unroll
+        for (int j = 0; j < kBvT; ++j) {
+            double y0 = (ff[j] - ca1[j] * s.x) - ca2[j] * s.y;
+            yf[j] = (float)y0;
+            if (f0 + j < n) {
+                s.y = s.x;
+                s.x = y0;
+            }
+            if (f0 + j == n - 1) {
+                final_y = s;
+                have_final = true;
+            }
+        }
+        store_frames<kBvT>(out, f0, n, channels, ch, yf);
+    }
+    if (have_final) {
+        // x1 = x[n-1]; x2 = x[n-2] (or the previous x1 when n == 1), numba kernel semantics
+        double nx1 = (double)in[(n - 1) * channels + ch];
+        double nx2 = (n >= 2) ? (double)in[(n - 2) * channels + ch] : sx1;
+        st[0] = nx1;
+        st[1] = nx2;
+        st[2] = final_y.x;
+        st[3] = final_y.y;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels) {
+    if (batch <= 0 || n <= 0 || channels <= 0) return 0;
+    BqPlan p = biquad_plan(batch, n, channels);
+    if (p.nseg <= 1) return 0;
+    size_t chains = (size_t)batch * channels;
+    return (chains * 2 + chains * (size_t)p.nseg * 2) * sizeof(double);
+}
+
+int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
+                     int channels, const double *coef, double *state, void *workspace) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && coef && state && channels >= 1, "pgx_biquad_const: bad argument");
+    PGX_CHECK_ARG(batch == 1 || (out_stride >= n * channels && in_stride >= n * channels),
+                  "pgx_biquad_const: instance stride too small");
+    PGX_CHECK_ARG((int64_t)batch * channels <= 65535, "pgx_biquad_const: too many chains");
+    BqPlan p = biquad_plan(batch, n, channels);
+    int chains = batch * channels;
+    dim3 grid(p.nseg, chains);
+    if (p.nseg > 1) {
+        PGX_CHECK_ARG(workspace != nullptr, "pgx_biquad_const: workspace required for this size");
+        double *snap = (double *)workspace;
+        double *agg = snap + (size_t)chains * 2;
+        PGX_HIP(hipMemcpyAsync(snap, state, (size_t)chains * 2 * sizeof(double), hipMemcpyDeviceToDevice,
+                               pgx::stream()));
+        hipLaunchKernelGGL(k_biquad_const<0>, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, in,
+                           in_stride, n, channels, coef, state, (const double *)snap, agg, p.seg_tiles, p.nseg);
+        PGX_LAUNCH_CHECK("k_biquad_const<reduce>");
+        hipLaunchKernelGGL(k_biquad_const<1>, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, in,
+                           in_stride, n, channels, coef, state, (const double *)snap, agg, p.seg_tiles, p.nseg);
+        PGX_LAUNCH_CHECK("k_biquad_const<apply>");
+    } else {
+        hipLaunchKernelGGL(k_biquad_const<1>, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, in,
+                           in_stride, n, channels, coef, state, (const double *)nullptr, (double *)nullptr,
+                           p.seg_tiles, p.nseg);
+        PGX_LAUNCH_CHECK("k_biquad_const");
+    }
+    return PGX_OK;
+}
+
+// A = 10^(gain_db/40) is a host-side Python float pow in the reference (biquad_pe.py:250); the
+// binding passes it and its square root by value so the device never calls pow().
+int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, double sample_rate,
+                       const pgx_biquad_var_params *params, const float *freq, const float *q,
+                       double gain_a, double gain_sqrt_a, double *state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && params && state && channels >= 1 && sample_rate > 0,
+                  "pgx_biquad_varying: bad argument");
+    hipLaunchKernelGGL(k_biquad_varying, dim3(channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels,
+                       sample_rate, params, freq, q, gain_a, gain_sqrt_a, state);
+    PGX_LAUNCH_CHECK("k_biquad_varying");
+    return PGX_OK;
+}
+
+int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channels, double sample_rate,
+                const pgx_blitsaw_params *params, const float *freq, int64_t freq_stride, const float *amp,
+                int64_t amp_stride, const float *m, int64_t m_stride, double *state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && state && channels >= 1 && sample_rate > 0, "pgx_blitsaw: bad argument");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_blitsaw: out_stride too small");
+    hipLaunchKernelGGL(k_blitsaw, dim3(batch), dim3(kBlock), 0, pgx::stream(), out, out_stride, n, channels,
+                       sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state);
+    PGX_LAUNCH_CHECK("k_blitsaw");
+    return PGX_OK;
+}
+
+int pgx_sine_stateful(float *out, int64_t n, int channels, double sample_rate,
+                      const pgx_sine_stateful_params *params, const float *freq, const float *amp,
+                      const float *phase_mod, double *state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && state && channels >= 1 && sample_rate > 0, "pgx_sine_stateful: bad argument");
+    hipLaunchKernelGGL(k_sine_stateful, dim3(1), dim3(kBlock), 0, pgx::stream(), out, n, channels, sample_rate,
+                       params, freq, amp, phase_mod, state);
+    PGX_LAUNCH_CHECK("k_sine_stateful");
+    return PGX_OK;
+}
+
+}  // extern "C"

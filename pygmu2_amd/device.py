@@ -1,0 +1,280 @@
+"""
+ctypes binding of libpygmu_hip.so (include/pygmu_hip.h) and the device-array type that
+backs Snippet payloads.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X-class device can
+be initialised, every call that needs the device raises RuntimeError.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libpygmu_hip.so")
+
+_lib = None
+_lib_lock = threading.Lock()
+_initialised = False
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_i32_p = C.POINTER(C.c_int32)
+
+# (name, restype, argtypes).  Device pointers are passed as c_void_p integers.
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_D = C.c_double
+_F = C.c_float
+_Z = C.c_size_t
+
+_SIGNATURES = [
+    ("pgx_abi_version", _I, []),
+    ("pgx_last_error", C.c_char_p, []),
+    ("pgx_device_count", _I, [C.POINTER(_I)]),
+    ("pgx_init", _I, [_I]),
+    ("pgx_shutdown", _I, []),
+    ("pgx_device_name", _I, [C.c_char_p, _Z]),
+    ("pgx_stream_handle", _P, []),
+    ("pgx_stream_sync", _I, []),
+    ("pgx_malloc", _I, [C.POINTER(_P), _Z]),
+    ("pgx_free", _I, [_P]),
+    ("pgx_pool_trim", _I, []),
+    ("pgx_memset", _I, [_P, _I, _Z]),
+    ("pgx_memcpy_h2d", _I, [_P, _P, _Z]),
+    ("pgx_memcpy_d2h", _I, [_P, _P, _Z]),
+    ("pgx_memcpy_d2d", _I, [_P, _P, _Z]),
+    ("pgx_event_create", _I, [C.POINTER(_P)]),
+    ("pgx_event_destroy", _I, [_P]),
+    ("pgx_event_record", _I, [_P]),
+    ("pgx_event_elapsed_ms", _I, [_P, _P, C.POINTER(_F)]),
+    ("pgx_fill", _I, [_P, _L, _F]),
+    ("pgx_ramp", _I, [_P, _F, _F, _L, _I]),
+    ("pgx_dirac", _I, [_P, _L, _L, _I]),
+    ("pgx_window_copy", _I, [_P, _L, _L, _I, _P, _L, _L, _I, _I]),
+    ("pgx_extract_channel", _I, [_P, _P, _L, _I, _I]),
+    ("pgx_sine_render", _I, [_P, _L, _I, _L, _L, _I, _D, _P]),
+    ("pgx_sine_stateful", _I, [_P, _L, _I, _D, _P, _P, _P, _P, _P]),
+    ("pgx_gain_const", _I, [_P, _P, _L, _F]),
+    ("pgx_gain_vec", _I, [_P, _P, _P, _L, _I, _I]),
+    ("pgx_mix_n", _I, [_P, C.POINTER(_P), _I, _L]),
+    ("pgx_mix_batch", _I, [_P, _P, _L, _I, _L]),
+    ("pgx_biquad_workspace_bytes", _Z, [_I, _L, _I]),
+    ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _P]),
+    ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
+    ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P]),
+    ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
+    ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P]),
+    ("pgx_comb", _I, [_P, _P, _L, _I, _D, _D, _D, _P, _P, _D, _L, _P, _L, _P, _P, _P]),
+    ("pgx_periodic_gate", _I, [_P, _L, _I, _L, _L, _P]),
+    ("pgx_periodic_trigger", _I, [_P, _L, _L, _L, _L, _F]),
+    ("pgx_adsr_gated", _I, [_P, _L, _P, _L, _I, _L, _P, _P]),
+    ("pgx_adsr_triggered", _I, [_P, _L, _P, _L, _I, _L, _L, _P, _P]),
+    ("pgx_convolve_workspace_bytes", _Z, [_L, _L, _I]),
+    ("pgx_convolve", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P]),
+]
+
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+# numpy mirrors of the parameter structs in include/pygmu_hip.h
+SINE_PARAMS = np.dtype([("w", "<f8"), ("amp", "<f8"), ("phase0", "<f8")])
+SINE_STATEFUL_PARAMS = np.dtype([("freq", "<f8"), ("amp", "<f8"), ("phase", "<f8"),
+                                 ("phase_is_stream", "<i4"), ("pad", "<i4")])
+BIQUAD_VAR_PARAMS = np.dtype([("freq", "<f8"), ("q", "<f8"), ("gain_db", "<f8"),
+                              ("mode", "<i4"), ("pad", "<i4")])
+BLITSAW_PARAMS = np.dtype([("freq", "<f8"), ("amp", "<f8"), ("leak", "<f8"), ("m", "<f8")])
+LADDER_PARAMS = np.dtype([("freq", "<f8"), ("resonance", "<f8"), ("drive", "<f8"),
+                          ("passband_gain", "<f8"), ("oversample", "<i4"), ("mode", "<i4")])
+GATE_PARAMS = np.dtype([("dt", "<f8"), ("phase", "<f8"), ("duty", "<f8")])
+ADSR_PARAMS = np.dtype([("attack_dvdt", "<f8"), ("decay_dvdt", "<f8"), ("release_dvdt", "<f8"),
+                        ("sustain_level", "<f8"), ("sustain_samples", "<i8")])
+
+
+def load_library():
+    """dlopen libpygmu_hip.so and declare every prototype.  Does not touch the GPU."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP render library has not been built. "
+                "Run `python -m pygmu2_amd.build` (needs hipcc); there is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in _SIGNATURES:
+            fn = getattr(lib, name)      # AttributeError -> a missing export is a build bug
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class PgxError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str = "") -> None:
+    """Map a pgx_status to a Python exception (ValueError for bad arguments, as the
+    reference raises from render(); RuntimeError otherwise)."""
+    if code == 0:
+        return
+    msg = load_library().pgx_last_error().decode("utf-8", "replace")
+    text = f"{what}: {msg}" if what else msg
+    if code == -1:
+        raise ValueError(text)
+    raise PgxError(f"{text} (pgx status {code})")
+
+
+def default_device_index() -> int:
+    for var in ("PYGMU_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v != "":
+            return int(v)
+    return 0
+
+
+def ensure_init(device: int | None = None):
+    """Initialise the library on `device` (default: $PYGMU_DEVICE, $LOCAL_RANK, else 0)."""
+    global _initialised
+    lib = load_library()
+    if not _initialised:
+        dev = default_device_index() if device is None else int(device)
+        n = C.c_int(0)
+        rc = lib.pgx_device_count(C.byref(n))
+        if rc != 0 or n.value == 0:
+            raise RuntimeError(
+                "pygmu2_amd needs an AMD GPU (MI355X / gfx950): no HIP device is visible. "
+                "There is no CPU fallback for the render path.")
+        check(lib.pgx_init(dev % n.value if device is None else dev), "pgx_init")
+        _initialised = True
+    return lib
+
+
+def device_available() -> bool:
+    try:
+        lib = load_library()
+    except (RuntimeError, OSError, AttributeError):
+        return False
+    n = C.c_int(0)
+    return lib.pgx_device_count(C.byref(n)) == 0 and n.value > 0
+
+
+def synchronize() -> None:
+    check(ensure_init().pgx_stream_sync(), "pgx_stream_sync")
+
+
+def device_name() -> str:
+    lib = ensure_init()
+    buf = C.create_string_buffer(256)
+    check(lib.pgx_device_name(buf, 256))
+    return buf.value.decode()
+
+
+class DeviceBuffer:
+    """
+    A typed, shaped block of device memory owned by this Python object (returned to the
+    library's pool when the object dies).  Exposes __cuda_array_interface__ so that
+    torch.as_tensor(buf) wraps it without a copy (used for the RCCL reduction).
+    """
+
+    __slots__ = ("ptr", "shape", "dtype", "nbytes", "_owner", "__weakref__")
+
+    def __init__(self, shape, dtype=np.float32, *, zero: bool = False):
+        lib = ensure_init()
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        n = 1
+        for s in self.shape:
+            n *= s
+        self.nbytes = n * self.dtype.itemsize
+        p = C.c_void_p(0)
+        check(lib.pgx_malloc(C.byref(p), max(self.nbytes, 1)), "pgx_malloc")
+        self.ptr = p.value
+        self._owner = True
+        if zero and self.nbytes:
+            check(lib.pgx_memset(self.ptr, 0, self.nbytes), "pgx_memset")
+
+    @classmethod
+    def from_host(cls, array) -> "DeviceBuffer":
+        a = np.ascontiguousarray(array)
+        buf = cls(a.shape, a.dtype)
+        if a.nbytes:
+            check(ensure_init().pgx_memcpy_h2d(buf.ptr, a.ctypes.data, a.nbytes), "pgx_memcpy_h2d")
+        return buf
+
+    def upload(self, array) -> None:
+        a = np.ascontiguousarray(array, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError(f"upload size mismatch: {a.nbytes} != {self.nbytes}")
+        if a.nbytes:
+            check(ensure_init().pgx_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes), "pgx_memcpy_h2d")
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(ensure_init().pgx_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes), "pgx_memcpy_d2h")
+        return out
+
+    def zero_(self) -> None:
+        if self.nbytes:
+            check(ensure_init().pgx_memset(self.ptr, 0, self.nbytes), "pgx_memset")
+
+    def offset_ptr(self, n_elements: int) -> int:
+        return self.ptr + int(n_elements) * self.dtype.itemsize
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
+                "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owner", False) and self.ptr and _lib is not None:
+                _lib.pgx_free(self.ptr)
+        except Exception:
+            pass
+        self.ptr = 0
+
+    def __repr__(self):
+        return f"DeviceBuffer(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr or 0:x})"
+
+
+def upload_struct(dtype: np.dtype, **fields) -> DeviceBuffer:
+    """One parameter block (a C struct from pygmu_hip.h) -> device memory."""
+    rec = np.zeros(1, dtype=dtype)
+    for k, v in fields.items():
+        rec[k] = v
+    return DeviceBuffer.from_host(rec)
+
+
+def upload_structs(records: np.ndarray) -> DeviceBuffer:
+    return DeviceBuffer.from_host(np.ascontiguousarray(records))
+
+
+class Event:
+    """HIP event on the library stream (used by bench.py for kernel timing)."""
+
+    def __init__(self):
+        p = C.c_void_p(0)
+        check(ensure_init().pgx_event_create(C.byref(p)), "pgx_event_create")
+        self.ptr = p.value
+
+    def record(self):
+        check(_lib.pgx_event_record(self.ptr), "pgx_event_record")
+
+    def elapsed_ms_since(self, start: "Event") -> float:
+        ms = C.c_float(0)
+        check(_lib.pgx_event_elapsed_ms(start.ptr, self.ptr, C.byref(ms)), "pgx_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.pgx_event_destroy(self.ptr)
+        except Exception:
+            pass

@@ -1,0 +1,29 @@
+"""IdentityPE: sample value == sample index (identity_pe.py:40-60)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from ._kernels import check, lib, new_output
+from .snippet import Snippet
+from .source_pe import SourcePE
+
+
+class IdentityPE(SourcePE):
+    def __init__(self, channels: int = 1):
+        self._channels = channels
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        out = new_output(duration, self._channels)
+        # The reference builds np.arange(start, start+n, dtype=float32); numpy fills that as
+        # first + i*delta in float32 with first = float32(start), delta = float32(start+1) - first.
+        first = np.float32(start)
+        delta = np.float32(start + 1) - first
+        check(lib().pgx_ramp(out.ptr, float(first), float(delta), duration, self._channels), "pgx_ramp")
+        return Snippet(start, out)
+
+    def channel_count(self) -> int:
+        return self._channels
+
+    def __repr__(self) -> str:
+        return f"IdentityPE(channels={self._channels})"

@@ -1,0 +1,126 @@
+"""
+LadderPE: Moog-style 4-pole ladder with tanh feedback, oversampling and six responses
+(ladder_pe.py:210-625).  The recurrence is nonlinear, so each (instance, channel) chain
+runs sequentially on one lane in the reference's exact float64 operation order
+(pgx_ladder); independent chains (voices, channels) fill the lanes of a wave.
+"""
+
+from __future__ import annotations
+
+from enum import Enum
+
+import numpy as np
+
+from . import device as _dev
+from ._kernels import DeviceBuffer, check, lib, new_output, ptr
+from .extent import Extent
+from .processing_element import ProcessingElement
+from .snippet import Snippet
+
+
+class LadderMode(Enum):
+    LP24 = "lp24"
+    LP12 = "lp12"
+    BP24 = "bp24"
+    BP12 = "bp12"
+    HP24 = "hp24"
+    HP12 = "hp12"
+
+
+_MODE_INDEX = {m: i for i, m in enumerate(LadderMode)}
+
+
+class LadderPE(ProcessingElement):
+    _DEFAULT_OVERSAMPLE = 2
+    _RESONANCE_MULTIPLIER = 1.8
+    _MIN_CUTOFF_FREQ = 5.0
+    _STATE_DECAY = 0.95
+    _INPUT_THRESHOLD = 1e-5
+
+    def __init__(self, source: ProcessingElement, frequency, resonance=0.0,
+                 mode: LadderMode = LadderMode.LP24, drive=1.0, passband_gain: float = 0.5,
+                 oversample: int = _DEFAULT_OVERSAMPLE):
+        self._source = source
+        self._frequency = frequency
+        self._resonance = resonance
+        self._mode = mode
+        self._drive = drive
+        self._passband_gain = float(np.clip(passband_gain, 0.0, 0.5))
+        self._oversample = max(1, int(oversample))
+        self._freq_is_pe = isinstance(frequency, ProcessingElement)
+        self._res_is_pe = isinstance(resonance, ProcessingElement)
+        self._drive_is_pe = isinstance(drive, ProcessingElement)
+        self._params: DeviceBuffer | None = None
+        self._state: DeviceBuffer | None = None      # [C][9]: z0[4], z1[4], old_input
+        self._state_channels = 0
+
+    source = property(lambda self: self._source)
+    frequency = property(lambda self: self._frequency)
+    resonance = property(lambda self: self._resonance)
+    mode = property(lambda self: self._mode)
+    drive = property(lambda self: self._drive)
+    passband_gain = property(lambda self: self._passband_gain)
+    oversample = property(lambda self: self._oversample)
+
+    def inputs(self) -> list[ProcessingElement]:
+        out = [self._source]
+        for is_pe, p in ((self._freq_is_pe, self._frequency), (self._res_is_pe, self._resonance),
+                         (self._drive_is_pe, self._drive)):
+            if is_pe:
+                out.append(p)
+        return out
+
+    def is_pure(self) -> bool:
+        return False
+
+    def channel_count(self) -> int | None:
+        return self._source.channel_count()
+
+    def _compute_extent(self) -> Extent:
+        ext = self._source.extent()
+        for is_pe, p in ((self._freq_is_pe, self._frequency), (self._res_is_pe, self._resonance),
+                         (self._drive_is_pe, self._drive)):
+            if is_pe:
+                ext = ext.intersection(p.extent())      # strict: no fallback (ladder_pe.py:330-346)
+        return ext
+
+    def _reset_state(self) -> None:
+        if self._state is not None:
+            self._state.zero_()
+
+    _on_start = _reset_state
+    _on_stop = _reset_state
+
+    def _scalar_params(self) -> dict:
+        def scalar(is_pe, p):
+            return 0.0 if is_pe else float(p)
+        return dict(freq=scalar(self._freq_is_pe, self._frequency),
+                    resonance=scalar(self._res_is_pe, self._resonance),
+                    drive=scalar(self._drive_is_pe, self._drive),
+                    passband_gain=self._passband_gain, oversample=self._oversample,
+                    mode=_MODE_INDEX[self._mode])
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        src = self._source.render(start, duration)
+        ch = src.channels
+        if self._state is None or self._state_channels != ch:
+            self._state = DeviceBuffer((ch, 9), np.float64, zero=True)
+            self._state_channels = ch
+        if self._params is None:
+            self._params = _dev.upload_struct(_dev.LADDER_PARAMS, **self._scalar_params())
+        _, f_buf = self._control_stream(self._frequency, start, duration)
+        _, r_buf = self._control_stream(self._resonance, start, duration)
+        _, d_buf = self._control_stream(self._drive, start, duration)
+        out = new_output(duration, ch)
+        check(lib().pgx_ladder(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate),
+                               self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr),
+              "pgx_ladder")
+        return Snippet(start, out)
+
+    def __repr__(self) -> str:
+        def s(is_pe, p):
+            return f"{type(p).__name__}(...)" if is_pe else p
+        return (f"LadderPE(source={type(self._source).__name__}, "
+                f"frequency={s(self._freq_is_pe, self._frequency)}, "
+                f"resonance={s(self._res_is_pe, self._resonance)}, mode={self._mode.value}, "
+                f"drive={s(self._drive_is_pe, self._drive)}, oversample={self._oversample})")

@@ -1,0 +1,174 @@
+"""
+ProcessingElement: the pull-model contract every PE implements.
+
+Restates the reference's abstract base (processing_element.py:28-363): `render(start,
+duration)` always yields exactly `duration` frames (zeros outside `extent()`), rejects
+negative durations, short-circuits zero-length requests, and dispatches to the
+subclass's `_render`.  Construction requires the global sample rate.  Lifecycle hooks
+(`on_start`, `on_stop`, `reset_state`) call `_on_start` / `_on_stop` / `_reset_state`
+when a subclass defines them.
+
+Differences that come from running on the device: parameter streams are handed to the
+kernels as device pointers (`_control_stream`) instead of float64 numpy vectors; the
+float32 -> float64 widening the reference does on the host happens inside the kernels.
+"""
+
+from __future__ import annotations
+
+import time
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from . import device as _dev
+from .config import get_sample_rate, handle_error
+from .diagnostics import is_enabled, pull_count_enabled, record_pull, record_timing, timing_enabled
+from .extent import Extent
+from .snippet import Snippet
+
+
+class ProcessingElement(ABC):
+    _sample_rate: int | None = None
+    _cached_extent: Extent | None = None
+
+    def __new__(cls, *args, **kwargs):
+        rate = get_sample_rate()
+        if rate is None:
+            raise RuntimeError(
+                "Global sample_rate is required but not set. "
+                "Call pygmu2_amd.set_sample_rate(rate) before constructing PEs.")
+        obj = super().__new__(cls)
+        obj._sample_rate = rate
+        return obj
+
+    # ------------------------------------------------------------------ identity
+    @property
+    def sample_rate(self) -> int | None:
+        if self._sample_rate is not None:
+            return self._sample_rate
+        found = None
+        for pe in self.inputs():
+            r = pe.sample_rate
+            if r is None:
+                continue
+            if found is None:
+                found = r
+            elif found != r:
+                handle_error(f"{type(self).__name__}.sample_rate inferred conflicting input rates: "
+                             f"{found} vs {r}. Using {found}.", fatal=False)
+                break
+        return found
+
+    # ------------------------------------------------------------------ rendering
+    def render(self, start: int, duration: int) -> Snippet:
+        if duration < 0:
+            raise ValueError(f"duration must be >= 0, got {duration}")
+        if is_enabled() and pull_count_enabled():
+            record_pull(self)
+        if duration == 0:
+            ch = self.channel_count()
+            return Snippet.from_zeros(start, 0, int(ch) if ch is not None else 1)
+        if is_enabled() and timing_enabled():
+            t0 = time.perf_counter_ns()
+            out = self._render(start, duration)
+            record_timing(self, time.perf_counter_ns() - t0)
+            return out
+        return self._render(start, duration)
+
+    @abstractmethod
+    def _render(self, start: int, duration: int) -> Snippet:
+        ...
+
+    @abstractmethod
+    def inputs(self) -> list["ProcessingElement"]:
+        ...
+
+    # ------------------------------------------------------------------ static properties
+    def extent(self) -> Extent:
+        if self._cached_extent is None:
+            self._cached_extent = self._compute_extent()
+        return self._cached_extent
+
+    def _compute_extent(self) -> Extent:
+        return Extent(None, None)
+
+    def is_pure(self) -> bool:
+        return False
+
+    def channel_count(self) -> int | None:
+        return None
+
+    def required_input_channels(self) -> int | None:
+        return None
+
+    def resolve_channel_count(self, input_channel_counts: list[int]) -> int:
+        if input_channel_counts:
+            return input_channel_counts[0]
+        raise ValueError(f"{type(self).__name__} has no inputs but channel_count() is None")
+
+    # ------------------------------------------------------------------ lifecycle
+    def on_start(self) -> None:
+        hook = getattr(self, "_on_start", None)
+        if hook is not None:
+            hook()
+
+    def on_stop(self) -> None:
+        hook = getattr(self, "_on_stop", None)
+        if hook is not None:
+            hook()
+
+    def reset_state(self) -> None:
+        hook = getattr(self, "_reset_state", None)
+        if hook is not None:
+            hook()
+
+    # ------------------------------------------------------------------ parameter helpers
+    def _control_stream(self, param, start: int, duration: int, *, channel: int = 0):
+        """
+        Device-side counterpart of the reference's `_scalar_or_pe_values`
+        (processing_element.py:296-363) for 1-D control parameters.
+
+        Returns (scalar, stream): for a scalar parameter (float(param), None); for a PE
+        parameter (None, DeviceBuffer of shape (duration, 1)) holding the selected channel
+        of the rendered parameter.  The keep-alive of the rendered Snippet is the returned
+        buffer itself.
+        """
+        if isinstance(param, ProcessingElement):
+            snip = param.render(start, duration)
+            buf = snip.dev
+            ch = snip.channels
+            if ch < 1:
+                raise ValueError(f"param PE returned invalid shape {(snip.duration, ch)}")
+            if channel < 0 or channel >= ch:
+                raise ValueError(f"channel {channel} out of range for param with {ch} channels")
+            if ch == 1:
+                return None, buf
+            mono = _dev.DeviceBuffer((duration, 1), np.float32)
+            _dev.check(_dev.ensure_init().pgx_extract_channel(mono.ptr, buf.ptr, duration, ch, channel),
+                       "pgx_extract_channel")
+            return None, mono
+        return float(param), None
+
+    def _scalar_or_pe_values(self, param, start: int, duration: int, *, dtype=None, channel: int = 0,
+                             allow_multichannel: bool = False, channels: int | None = None):
+        """Host-side variant with the reference's exact signature and return values
+        (numpy arrays); used by host-only PEs and by tests of the contract."""
+        if dtype is None:
+            dtype = np.float64
+        if duration <= 0:
+            if allow_multichannel:
+                return np.zeros((0, channels if channels is not None else 1), dtype=dtype)
+            return np.zeros((0,), dtype=dtype)
+        if isinstance(param, ProcessingElement):
+            data = param.render(start, duration).data
+            if allow_multichannel:
+                return data.astype(dtype, copy=False)
+            if data.ndim != 2 or data.shape[1] < 1:
+                raise ValueError(f"param PE returned invalid shape {getattr(data, 'shape', None)}")
+            if channel < 0 or channel >= data.shape[1]:
+                raise ValueError(f"channel {channel} out of range for param with {data.shape[1]} channels")
+            return data[:, channel].astype(dtype, copy=False)
+        value = float(param)
+        if allow_multichannel:
+            return np.full((duration, channels if channels is not None else 1), value, dtype=dtype)
+        return np.full((duration,), value, dtype=dtype)

@@ -1,0 +1,94 @@
+"""
+SinePE: sine oscillator with scalar or PE-driven frequency / amplitude / phase
+(sine_pe.py:51-270).
+
+All-scalar parameters -> pure: phase is computed directly from the sample index in
+float64 on the device (pgx_sine_render).  Any PE parameter -> stateful: the frequency is
+integrated by a device prefix scan and the accumulated phase is carried between
+contiguous renders in a device-resident state blob (pgx_sine_stateful).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import device as _dev
+from ._kernels import DeviceBuffer, check, lib, new_output, ptr
+from .extent import Extent
+from .processing_element import ProcessingElement
+from .snippet import Snippet
+
+
+class SinePE(ProcessingElement):
+    def __init__(self, frequency=440.0, amplitude=1.0, phase=0.0, channels: int = 1):
+        self._frequency = frequency
+        self._amplitude = amplitude
+        self._phase = phase
+        self._channels = channels
+        self._params: DeviceBuffer | None = None      # uploaded once, lazily
+        self._state: DeviceBuffer | None = None       # {accumulated_phase, initialised}
+
+    frequency = property(lambda self: self._frequency)
+    amplitude = property(lambda self: self._amplitude)
+    initial_phase = property(lambda self: self._phase)
+
+    def _has_pe_inputs(self) -> bool:
+        return any(isinstance(p, ProcessingElement)
+                   for p in (self._frequency, self._amplitude, self._phase))
+
+    def inputs(self) -> list[ProcessingElement]:
+        return [p for p in (self._frequency, self._amplitude, self._phase)
+                if isinstance(p, ProcessingElement)]
+
+    def is_pure(self) -> bool:
+        return not self._has_pe_inputs()
+
+    def channel_count(self) -> int:
+        return self._channels
+
+    def _compute_extent(self) -> Extent:
+        ext = Extent(None, None)
+        for pe in self.inputs():
+            ext = ext.intersection(pe.extent())
+        return ext
+
+    def _reset_state(self) -> None:
+        if self._state is not None:
+            self._state.zero_()
+
+    _on_start = _reset_state
+    _on_stop = _reset_state
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        out = new_output(duration, self._channels)
+        L = lib()
+        if not self._has_pe_inputs():
+            if self._params is None:
+                # same host arithmetic as the reference: (2.0 * pi) * f, left to right
+                w = 2.0 * np.pi * float(self._frequency)
+                self._params = _dev.upload_struct(_dev.SINE_PARAMS, w=w, amp=float(self._amplitude),
+                                                  phase0=float(self._phase))
+            check(L.pgx_sine_render(out.ptr, 0, 1, start, duration, self._channels,
+                                    float(self.sample_rate), self._params.ptr), "pgx_sine_render")
+            return Snippet(start, out)
+
+        f_s, f_buf = self._control_stream(self._frequency, start, duration)
+        a_s, a_buf = self._control_stream(self._amplitude, start, duration)
+        p_s, p_buf = self._control_stream(self._phase, start, duration)
+        if self._params is None:
+            self._params = _dev.upload_struct(
+                _dev.SINE_STATEFUL_PARAMS, freq=0.0 if f_s is None else f_s,
+                amp=0.0 if a_s is None else a_s, phase=0.0 if p_s is None else p_s,
+                phase_is_stream=int(p_buf is not None))
+        if self._state is None:
+            self._state = DeviceBuffer((2,), np.float64, zero=True)
+        check(L.pgx_sine_stateful(out.ptr, duration, self._channels, float(self.sample_rate),
+                                  self._params.ptr, ptr(f_buf), ptr(a_buf), ptr(p_buf),
+                                  self._state.ptr), "pgx_sine_stateful")
+        return Snippet(start, out)
+
+    def __repr__(self) -> str:
+        def s(p):
+            return type(p).__name__ if isinstance(p, ProcessingElement) else str(p)
+        return (f"SinePE(frequency={s(self._frequency)}, amplitude={s(self._amplitude)}, "
+                f"phase={s(self._phase)}, channels={self._channels})")

@@ -1,0 +1,89 @@
+"""
+Snippet: `start` + a (frames, channels) float32 payload.
+
+Same contract as the reference's Snippet (snippet.py:26-109) -- 1-D input becomes
+(N, 1), every dtype is normalised to float32 -- but the payload normally lives in
+MI355X HBM (a DeviceBuffer produced by a HIP kernel).  `.data` is the reference's
+attribute: it returns a numpy view of the payload, copied device->host on first use and
+cached.  `.dev` returns the DeviceBuffer (uploading a host-constructed payload on first
+use), which is what downstream PEs consume, so a chain of PEs never leaves the device.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .device import DeviceBuffer
+
+
+class Snippet:
+    __slots__ = ("_start", "_host", "_dev", "_shape")
+
+    def __init__(self, start: int, data):
+        self._start = int(start)
+        if isinstance(data, DeviceBuffer):
+            if data.dtype != np.float32 or len(data.shape) != 2:
+                raise ValueError("device payload must be float32 of shape (frames, channels)")
+            self._dev = data
+            self._host = None
+            self._shape = data.shape
+            return
+        data = np.asarray(data)
+        if data.ndim == 1:
+            data = data.reshape(-1, 1)
+        elif data.ndim != 2:
+            raise ValueError(f"data must be 1D or 2D, got {data.ndim}D")
+        if data.dtype != np.float32:
+            data = data.astype(np.float32, copy=False)
+        self._host = data
+        self._dev = None
+        self._shape = data.shape
+
+    @property
+    def start(self) -> int:
+        return self._start
+
+    @property
+    def end(self) -> int:
+        return self._start + self._shape[0]
+
+    @property
+    def duration(self) -> int:
+        return self._shape[0]
+
+    @property
+    def channels(self) -> int:
+        return self._shape[1]
+
+    @property
+    def data(self) -> np.ndarray:
+        """Host view (frames, channels) float32; treat as immutable."""
+        if self._host is None:
+            self._host = self._dev.to_host()
+        return self._host
+
+    @property
+    def dev(self) -> DeviceBuffer:
+        """Device payload (uploads a host-built snippet once)."""
+        if self._dev is None:
+            self._dev = DeviceBuffer.from_host(np.ascontiguousarray(self._host))
+        return self._dev
+
+    @property
+    def on_device(self) -> bool:
+        return self._dev is not None
+
+    @classmethod
+    def from_zeros(cls, start: int, duration: int, channels: int = 1) -> "Snippet":
+        return cls(start, np.zeros((duration, channels), dtype=np.float32))
+
+    def __repr__(self) -> str:
+        return f"Snippet(start={self._start}, duration={self.duration}, channels={self.channels})"
+
+    def __eq__(self, other):
+        if not isinstance(other, Snippet):
+            return NotImplemented
+        return (self._start == other._start and self._shape == other._shape
+                and np.allclose(self.data, other.data))
+
+    __hash__ = None

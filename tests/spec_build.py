@@ -1,0 +1,58 @@
+"""Build a pygmu2_amd PE graph (the HIP product path) from a golden-case SPEC
+(see oracle/golden_cases.py for the format)."""
+
+import pygmu2_amd as pg
+from oracle.golden_cases import materialize_array
+
+_SIMPLE = {
+    "ConstantPE": pg.ConstantPE, "IdentityPE": pg.IdentityPE, "DiracPE": pg.DiracPE,
+    "ArrayPE": pg.ArrayPE, "CropPE": pg.CropPE, "SinePE": pg.SinePE, "GainPE": pg.GainPE,
+    "BlitSawPE": pg.BlitSawPE, "SuperSawPE": pg.SuperSawPE, "CombPE": pg.CombPE,
+    "AdsrGatedPE": pg.AdsrGatedPE, "AdsrTriggeredPE": pg.AdsrTriggeredPE,
+    "PeriodicGate": pg.PeriodicGate, "PeriodicTrigger": pg.PeriodicTrigger,
+}
+
+
+def build(spec):
+    kind = spec["pe"]
+    kw = {}
+    for k, v in spec.items():
+        if k == "pe":
+            continue
+        if isinstance(v, dict) and "pe" in v:
+            kw[k] = build(v)
+        elif isinstance(v, dict):
+            kw[k] = materialize_array(v)
+        elif k == "inputs":
+            kw[k] = [build(s) for s in v]
+        else:
+            kw[k] = v
+    if "extend_mode" in kw:
+        kw["extend_mode"] = pg.ExtendMode(kw["extend_mode"])
+    if kind in _SIMPLE:
+        return _SIMPLE[kind](**kw)
+    if kind == "MixPE":
+        return pg.MixPE(*kw["inputs"])
+    if kind == "BiquadPE":
+        if "mode" in kw:
+            kw["mode"] = pg.BiquadMode(kw["mode"])
+        return pg.BiquadPE(**kw)
+    if kind == "LadderPE":
+        if "mode" in kw:
+            kw["mode"] = pg.LadderMode(kw["mode"])
+        return pg.LadderPE(**kw)
+    if kind == "ConvolvePE":
+        return pg.ConvolvePE(kw.pop("src"), kw.pop("fir"), **kw)
+    raise KeyError(kind)
+
+
+def run_case(case):
+    """Render every block of a case through a started NullRenderer graph; list of arrays."""
+    pg.set_sample_rate(case["sr"])
+    pe = build(case["graph"])
+    r = pg.NullRenderer(sample_rate=case["sr"])
+    r.set_source(pe)
+    r.start()
+    outs = [pe.render(int(s), int(n)).data for s, n in case["blocks"]]
+    r.stop()
+    return outs

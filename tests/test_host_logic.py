@@ -1,0 +1,274 @@
+"""CPU: host-side contract of the PE layer (no device calls).
+
+Mirrors the behaviours the reference pins in tests/test_extent.py, tests/test_snippet.py,
+tests/test_processing_element.py:203-241 and tests/test_renderer.py:194-542, using
+hand-rolled host PEs so that nothing touches the GPU."""
+
+import numpy as np
+import pytest
+
+import pygmu2_amd as pg
+from pygmu2_amd import Extent, ExtendMode, NullRenderer, ProcessingElement, Snippet, SourcePE
+
+
+# ------------------------------------------------------------------ Extent
+def test_extent_basics_and_infinite_bounds():
+    e = Extent(10, 20)
+    assert (e.start, e.end, e.duration) == (10, 20, 10)
+    assert e.contains(10) and e.contains(19) and not e.contains(20) and not e.contains(9)
+    assert Extent(None, 5).contains(-10 ** 9) and not Extent(None, 5).contains(5)
+    assert Extent(None, None).duration is None
+    with pytest.raises(ValueError):
+        Extent(5, 4)
+
+
+def test_extent_empty_is_falsy_and_never_intersects():
+    z = Extent(7, 7)
+    assert z.is_empty() and not z and bool(Extent(0, 1))
+    assert not z.intersects(Extent(None, None)) and not Extent(0, 10).intersects(z)
+    assert Extent(0, 10).union(z) == Extent(0, 10) and z.union(Extent(0, 10)) == Extent(0, 10)
+
+
+def test_extent_intersection_union_spans():
+    a, b = Extent(0, 10), Extent(5, 15)
+    assert a.intersects(b) and a.intersection(b) == Extent(5, 10) and a.union(b) == Extent(0, 15)
+    assert not Extent(0, 5).intersects(Extent(5, 9))
+    d = Extent(0, 5).intersection(Extent(8, 9))
+    assert d.is_empty() and d.start == 8
+    assert Extent(None, 10).intersection(Extent(3, None)) == Extent(3, 10)
+    assert Extent(None, 10).union(Extent(3, 12)) == Extent(None, 12)
+    assert a.spans(2, 8) and not a.spans(2, 9) and a.spans(100, 0)
+    # the idiom the filters rely on: empty intersection falls back
+    assert (Extent(0, 5).intersection(Extent(9, 12)) or Extent(0, 5)) == Extent(0, 5)
+
+
+# ------------------------------------------------------------------ Snippet (host payloads)
+def test_snippet_normalises_shape_and_dtype():
+    s = Snippet(5, np.arange(4, dtype=np.float64))
+    assert s.data.shape == (4, 1) and s.data.dtype == np.float32
+    assert (s.start, s.end, s.duration, s.channels) == (5, 9, 4, 1)
+    assert not s.on_device
+    z = Snippet.from_zeros(-3, 0, 2)
+    assert z.duration == 0 and z.channels == 2 and z.end == -3
+    with pytest.raises(ValueError):
+        Snippet(0, np.zeros((2, 2, 2)))
+    assert Snippet(0, np.ones((3, 2))) == Snippet(0, np.ones((3, 2), np.float32))
+    assert Snippet(0, np.ones((3, 2))) != Snippet(1, np.ones((3, 2)))
+
+
+# ------------------------------------------------------------------ mock PEs (host only)
+class HostRamp(SourcePE):
+    def __init__(self, channels=1, pure=True):
+        self._ch, self._pure = channels, pure
+        self.events = []
+
+    def channel_count(self):
+        return self._ch
+
+    def is_pure(self):
+        return self._pure
+
+    def _render(self, start, duration):
+        idx = np.arange(start, start + duration, dtype=np.float32).reshape(-1, 1)
+        return Snippet(start, np.tile(idx, (1, self._ch)))
+
+    def _on_start(self):
+        self.events.append("start")
+
+    def _on_stop(self):
+        self.events.append("stop")
+
+
+class HostPass(ProcessingElement):
+    def __init__(self, *srcs, pure=True, need=None, log=None, name=""):
+        self._srcs, self._pure, self._need, self._log, self._name = list(srcs), pure, need, log, name
+
+    def inputs(self):
+        return self._srcs
+
+    def is_pure(self):
+        return self._pure
+
+    def required_input_channels(self):
+        return self._need
+
+    def _render(self, start, duration):
+        return self._srcs[0].render(start, duration)
+
+    def _on_start(self):
+        if self._log is not None:
+            self._log.append(("start", self._name))
+
+    def _on_stop(self):
+        if self._log is not None:
+            self._log.append(("stop", self._name))
+
+
+def test_sample_rate_required_before_construction():
+    pg.config._sample_rate = None
+    with pytest.raises(RuntimeError):
+        HostRamp()
+    pg.set_sample_rate(48000)
+    assert HostRamp().sample_rate == 48000
+
+
+def test_render_contract_negative_zero_and_dispatch():
+    pe = HostRamp(channels=2)
+    with pytest.raises(ValueError):
+        pe.render(0, -1)
+    z = pe.render(17, 0)
+    assert z.duration == 0 and z.channels == 2 and z.start == 17
+    s = pe.render(-2, 4)
+    assert s.data[:, 0].tolist() == [-2, -1, 0, 1]
+    assert pe.extent() == Extent(None, None)
+
+
+def test_scalar_or_pe_values_helper():
+    pe = HostPass(HostRamp())
+    v = pe._scalar_or_pe_values(0.5, 0, 4)
+    assert v.dtype == np.float64 and v.shape == (4,) and np.all(v == 0.5)
+    v = pe._scalar_or_pe_values(HostRamp(channels=2), 3, 4)
+    assert v.tolist() == [3, 4, 5, 6]
+    v = pe._scalar_or_pe_values(HostRamp(channels=2), 3, 4, allow_multichannel=True, dtype=np.float32)
+    assert v.shape == (4, 2) and v.dtype == np.float32
+    assert pe._scalar_or_pe_values(1.0, 0, 0).shape == (0,)
+    assert pe._scalar_or_pe_values(2, 0, 3, allow_multichannel=True, channels=2).shape == (3, 2)
+    with pytest.raises(ValueError):
+        pe._scalar_or_pe_values(HostRamp(), 0, 4, channel=1)
+
+
+# ------------------------------------------------------------------ Renderer
+def test_renderer_rejects_shared_stateful_pe_and_channel_mismatch():
+    shared = HostRamp(pure=False)
+    root = HostPass(HostPass(shared), HostPass(shared))
+    with pytest.raises(ValueError, match="multiple sinks"):
+        NullRenderer().set_source(root)
+    NullRenderer().set_source(HostPass(HostPass(HostRamp()), HostPass(HostRamp())))
+    pure_shared = HostRamp(pure=True)
+    NullRenderer().set_source(HostPass(HostPass(pure_shared), HostPass(pure_shared)))
+    with pytest.raises(ValueError, match="requires 1 channel"):
+        NullRenderer().set_source(HostPass(HostRamp(channels=2), need=1))
+    r = NullRenderer(sample_rate=48000)
+    r.set_source(HostPass(HostRamp(channels=2)))
+    assert r.channel_count == 2 and r.sample_rate == 48000
+
+
+def test_renderer_lifecycle_order_and_errors():
+    log = []
+    leaf = HostPass(HostRamp(), log=log, name="leaf")
+    mid = HostPass(leaf, log=log, name="mid")
+    root = HostPass(mid, leaf, log=log, name="root")          # diamond: leaf visited once
+    r = NullRenderer()
+    with pytest.raises(RuntimeError):
+        r.start()
+    r.set_source(root)
+    with pytest.raises(RuntimeError):
+        r.render(0, 16)
+    r.start()
+    assert log == [("start", "leaf"), ("start", "mid"), ("start", "root")]
+    with pytest.raises(RuntimeError):
+        r.start()
+    with pytest.raises(RuntimeError):
+        r.set_source(root)
+    with pytest.raises(ValueError):
+        r.render(0, 0)
+    r.render(0, 16)
+    assert r.last_snippet.duration == 16
+    log.clear()
+    r.stop()
+    assert log == [("stop", "root"), ("stop", "mid"), ("stop", "leaf")]
+    r.stop()                                                   # idempotent
+    assert log == [("stop", "root"), ("stop", "mid"), ("stop", "leaf")]
+    with NullRenderer() as ctx:
+        ctx.set_source(HostRamp())
+        ctx.start()
+    assert not ctx.started
+
+
+def test_renderer_lenient_mode_warns_instead_of_raising():
+    pg.set_error_mode(pg.ErrorMode.LENIENT)
+    try:
+        r = NullRenderer()
+        r.set_source(HostRamp())
+        r.start()
+        r.start()                      # warning only
+        with pytest.raises(RuntimeError):
+            NullRenderer().start()     # fatal regardless of mode
+    finally:
+        pg.set_error_mode(pg.ErrorMode.STRICT)
+
+
+def test_renderer_profiling_report():
+    r = NullRenderer(sample_rate=1000)
+    r.set_source(HostRamp())
+    r.enable_profiling()
+    r.start()
+    r.render(0, 100)
+    r.render(100, 100)
+    rep = r.get_profile_report()
+    assert rep.render_count == 2 and rep.total_samples == 200 and "whole graph" in rep.summary(1000)
+
+
+# ------------------------------------------------------------------ PE graph plumbing that needs no device
+def test_pe_static_properties_without_device():
+    pg.set_sample_rate(48000)
+    sine = pg.SinePE(440.0, channels=2)
+    assert sine.is_pure() and sine.channel_count() == 2 and sine.inputs() == []
+    fm = pg.SinePE(frequency=pg.SinePE(5.0))
+    assert not fm.is_pure() and len(fm.inputs()) == 1
+    with pytest.raises(ValueError):
+        pg.MixPE(sine)
+    mix = pg.MixPE([pg.CropPE(sine, 0, 100), pg.CropPE(sine, 50, 100)])
+    assert mix.extent() == Extent(0, 150) and mix.channel_count() == 2
+    with pytest.raises(ValueError, match="channel mismatch"):
+        mix.resolve_channel_count([1, 2])
+    assert mix.resolve_channel_count([2, 2]) == 2
+    arr = pg.ArrayPE([1.0, 2.0, 3.0])
+    assert arr.extent() == Extent(0, 3) and arr.channel_count() == 1
+    with pytest.raises(ValueError):
+        pg.ArrayPE([])
+    bq = pg.BiquadPE(arr, frequency=pg.CropPE(pg.ConstantPE(500.0), 10, 5), q=0.7)
+    assert bq.extent() == Extent(0, 3)                 # empty intersection falls back
+    lad = pg.LadderPE(arr, frequency=pg.CropPE(pg.ConstantPE(500.0), 10, 5))
+    assert lad.extent().is_empty()                     # strict intersection
+    conv = pg.ConvolvePE(pg.ArrayPE(np.zeros(10)), pg.ArrayPE([1.0, 0.5, 0.25]))
+    assert conv.extent() == Extent(0, 12) and not conv.is_pure()
+    with pytest.raises(ValueError):
+        pg.ConvolvePE(arr, pg.ConstantPE(1.0)).extent()
+    with pytest.raises(ValueError):
+        pg.ConvolvePE(arr, pg.CropPE(pg.ArrayPE([1, 0, 0]), 1, 2)).extent()
+    with pytest.raises(ValueError):
+        pg.CropPE(sine, 0, -1)
+    with pytest.raises(ValueError):
+        pg.PeriodicTrigger(0.0)
+    assert pg.PeriodicTrigger(7.0, phase=0.25)._period == 6857
+    with pytest.raises(ValueError):
+        pg.SuperSawPE(440.0, mix_mode="bogus")
+
+
+def test_supersaw_tables_match_reference_values():
+    """tests/test_super_saw_pe.py:221-327 style pins (+ the SURVEY KAT phases)."""
+    pg.set_sample_rate(44100)
+    s = pg.SuperSawPE(440.0, voices=7, seed=1234)
+    assert np.allclose([float(o.initial_phase[0]) for o in s._oscillators],
+                       [0.97669977, 0.38019574, 0.92324623, 0.26169242, 0.31909706, 0.11809123,
+                        0.24176629], atol=1e-8)
+    assert np.isclose(np.sum(np.asarray(s._mix_gains, dtype=np.float64) ** 2), 1.0, atol=1e-6)
+    assert np.isclose(s._detune_ratios[3], 1.0) and np.isclose(s._detune_ratios[0], 2 ** (-20 / 1200))
+    lin = pg.SuperSawPE(440.0, voices=5, mix_mode="linear")._mix_gains
+    assert np.allclose(lin / lin[2], [0.5, 0.75, 1.0, 0.75, 0.5])
+    ch = pg.SuperSawPE(440.0, voices=6, mix_mode="center_heavy")._mix_gains
+    assert np.allclose(ch / ch[2], [0.5, 0.5, 1, 1, 0.5, 0.5])
+    assert len(pg.SuperSawPE(440.0, voices=0)._oscillators) == 1
+    assert pg.SuperSawPE(440.0).inputs() == []          # internal oscillators are hidden
+
+
+def test_gate_validation_on_host_arrays():
+    pg.GateSignal._validate_gate_array(np.array([[0.0], [1.0]], np.float32))
+    with pytest.raises(ValueError):
+        pg.GateSignal._validate_gate_array(np.array([[0.5]], np.float32))
+    with pytest.raises(ValueError):
+        pg.GateSignal._validate_gate_array(np.zeros((4, 2), np.float32))
+    pg.TriggerSignal._validate_trigger_array(np.array([[0.0], [2.0], [-1.0]], np.float32))
+    with pytest.raises(ValueError):
+        pg.TriggerSignal._validate_trigger_array(np.array([[0.25]], np.float32))
