@@ -320,6 +320,15 @@ def main():
                                    ("single chain" if n_gpus == 1 else f"{n_gpus} independent replicas (replicas only)"))},
     })
 
+    if args.workload != "c5" and not args.no_extras:
+        # collective: every rank takes part.  512-voice mix sharded over the ranks (strong scaling).
+        from pygmu2_amd.sharding import bench_voice_mix
+        vdt, vframes, vname = bench_voice_mix(pg, dist, 10, 2)
+        result["voice_mix"] = {"value": round(vframes * 10 / vdt / 1e6, 3), "unit": "Msamples/s",
+                               "voice_msamples_s": round(512 * vframes * 10 / vdt / 1e6, 1),
+                               "ms_per_block": round(vdt / 10 * 1e3, 4), "scaling": "strong",
+                               "workload": vname, "steps": 10, "warmup": 2}
+
     if dist.rank == 0 and not args.no_extras:
         result["device"] = device.device_name()
         result["roofline"] = biquad_kernel_roofline(pg, 1_000_000, 200)

@@ -1,12 +1,379 @@
 """
 Voice bank: batched rendering of structurally identical voice sub-graphs under a MixPE.
 
-(Placeholder for the batched path; until it is enabled MixPE renders its inputs one by
-one.  See DESIGN.md, "voice banks".)
+The reference renders a MixPE of K voices by pulling K separate sub-graphs, one numpy
+call chain each (mix_pe.py:69-96).  On MI355X K x (PEs per voice) small launches would
+leave the chip idle, so when every input of a MixPE is the same tree of supported PEs
+with scalar parameters, the trees are walked in lock-step and each level is rendered by
+ONE batched launch: per-voice parameter blocks and state blobs are stacked [K] in HBM,
+intermediate signals are [K][frames][channels], and the final pgx_mix_batch adds the
+K voices in input order in float32 -- the same additions, in the same order, as MixPE.
+The batched kernels are the very same kernels the single PEs use (batch = 1 there), so a
+bank produces the same samples as rendering the voices one by one.
+
+Supported nodes: SinePE (scalar), BlitSawPE (scalar), SuperSawPE (scalar), BiquadPE
+(constant coefficients), LadderPE (scalar controls), GainPE (constant or PE gain),
+AdsrGatedPE, PeriodicGate.  Anything else -> `try_build_bank` returns None and MixPE
+falls back to per-input rendering.
 """
 
 from __future__ import annotations
 
+import numpy as np
+
+from . import device as _dev
+from ._kernels import DeviceBuffer, check, lib, ptr
+from .adsr_pe import AdsrGatedPE
+from .biquad_pe import BiquadPE, rbj_coefficients
+from .blit_saw_pe import BlitSawPE
+from .extent import Extent
+from .gain_pe import GainPE
+from .ladder_pe import LadderPE
+from .periodic_gate import PeriodicGate
+from .processing_element import ProcessingElement
+from .sine_pe import SinePE
+from .snippet import Snippet
+from .super_saw_pe import SuperSawPE
+
+MIN_VOICES = 4
+
+
+def _is_pe(x) -> bool:
+    return isinstance(x, ProcessingElement)
+
+
+class _Node:
+    """One level of the voice tree: K PE instances of the same class and static config."""
+
+    def __init__(self, pes, children):
+        self.pes = pes
+        self.k = len(pes)
+        self.children = children
+        self.sr = float(pes[0].sample_rate)
+
+    def reset(self):
+        for c in self.children.values():
+            c.reset()
+
+    def channels(self) -> int:
+        raise NotImplementedError
+
+    def render(self, start: int, n: int) -> DeviceBuffer:
+        """-> DeviceBuffer [K][n][channels] float32."""
+        raise NotImplementedError
+
+
+class _SineNode(_Node):
+    def __init__(self, pes):
+        super().__init__(pes, {})
+        rec = np.zeros(self.k, dtype=_dev.SINE_PARAMS)
+        for i, pe in enumerate(pes):
+            rec[i] = (2.0 * np.pi * float(pe._frequency), float(pe._amplitude), float(pe._phase))
+        self.params = _dev.upload_structs(rec)
+        self.ch = pes[0]._channels
+
+    def channels(self):
+        return self.ch
+
+    def render(self, start, n):
+        out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        check(lib().pgx_sine_render(out.ptr, n * self.ch, self.k, start, n, self.ch, self.sr,
+                                    self.params.ptr), "pgx_sine_render")
+        return out
+
+
+class _BlitSawNode(_Node):
+    def __init__(self, pes):
+        super().__init__(pes, {})
+        rec = np.zeros(self.k, dtype=_dev.BLITSAW_PARAMS)
+        for i, pe in enumerate(pes):
+            for key, v in pe._scalar_params().items():
+                rec[i][key] = v
+        self.params = _dev.upload_structs(rec)
+        self.init_state = np.stack([pe._initial_state() for pe in pes])
+        self.state = DeviceBuffer((self.k, 2), np.float64)
+        self.ch = pes[0]._channels
+        self.last_end = None
+
+    def reset(self):
+        self.last_end = None
+
+    def channels(self):
+        return self.ch
+
+    def render(self, start, n):
+        if self.last_end is None or start != self.last_end:
+            self.state.upload(self.init_state)
+        out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        check(lib().pgx_blitsaw(out.ptr, n * self.ch, self.k, n, self.ch, self.sr, self.params.ptr,
+                                None, 0, None, 0, None, 0, self.state.ptr), "pgx_blitsaw")
+        self.last_end = start + n
+        return out
+
+
+class _SuperSawNode(_Node):
+    def __init__(self, pes):
+        super().__init__(pes, {})
+        self.nv = len(pes[0]._oscillators)
+        self.params = _dev.upload_structs(np.concatenate([pe._voice_param_records() for pe in pes]))
+        self.init_state = np.concatenate([pe._voice_initial_state() for pe in pes])
+        self.state = DeviceBuffer((self.k * self.nv, 2), np.float64)
+        self.amp = DeviceBuffer.from_host(np.array([float(pe._amplitude) for pe in pes], dtype=np.float64))
+        self.ch = pes[0]._channels
+        self.last_end = None
+
+    def reset(self):
+        self.last_end = None
+
+    def channels(self):
+        return self.ch
+
+    def render(self, start, n):
+        L = lib()
+        if self.last_end is None or start != self.last_end:
+            self.state.upload(self.init_state)
+        voices = DeviceBuffer((self.k * self.nv, n), np.float32)
+        check(L.pgx_blitsaw(voices.ptr, n, self.k * self.nv, n, 1, self.sr, self.params.ptr,
+                            None, 0, None, 0, None, 0, self.state.ptr), "pgx_blitsaw")
+        out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        check(L.pgx_supersaw_sum(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, voices.ptr,
+                                 self.amp.ptr, None, 0), "pgx_supersaw_sum")
+        self.last_end = start + n
+        return out
+
+
+class _BiquadNode(_Node):
+    def __init__(self, pes, children):
+        super().__init__(pes, children)
+        coef = np.array([rbj_coefficients(pe._mode, pe._frequency, pe._q, pe._gain_db, self.sr)
+                         for pe in pes], dtype=np.float64)
+        self.coef = DeviceBuffer.from_host(coef)
+        self.state = None
+        self.ws = None
+
+    def reset(self):
+        super().reset()
+        if self.state is not None:
+            self.state.zero_()
+
+    def channels(self):
+        return self.children["source"].channels()
+
+    def render(self, start, n):
+        L = lib()
+        x = self.children["source"].render(start, n)
+        ch = x.shape[2]
+        if self.state is None:
+            self.state = DeviceBuffer((self.k, ch, 2), np.float64, zero=True)
+        need = L.pgx_biquad_workspace_bytes(self.k, n, ch)
+        if need and (self.ws is None or self.ws.nbytes < need):
+            self.ws = DeviceBuffer((need,), np.uint8)
+        out = DeviceBuffer((self.k, n, ch), np.float32)
+        check(L.pgx_biquad_const(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.coef.ptr,
+                                 self.state.ptr, ptr(self.ws) if need else None), "pgx_biquad_const")
+        return out
+
+
+class _LadderNode(_Node):
+    def __init__(self, pes, children):
+        super().__init__(pes, children)
+        rec = np.zeros(self.k, dtype=_dev.LADDER_PARAMS)
+        for i, pe in enumerate(pes):
+            for key, v in pe._scalar_params().items():
+                rec[i][key] = v
+        self.params = _dev.upload_structs(rec)
+        self.state = None
+
+    def reset(self):
+        super().reset()
+        if self.state is not None:
+            self.state.zero_()
+
+    def channels(self):
+        return self.children["source"].channels()
+
+    def render(self, start, n):
+        x = self.children["source"].render(start, n)
+        ch = x.shape[2]
+        if self.state is None:
+            self.state = DeviceBuffer((self.k, ch, 9), np.float64, zero=True)
+        out = DeviceBuffer((self.k, n, ch), np.float32)
+        check(lib().pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
+                               None, None, None, self.state.ptr), "pgx_ladder")
+        return out
+
+
+class _GateNode(_Node):
+    def __init__(self, pes):
+        super().__init__(pes, {})
+        rec = np.zeros(self.k, dtype=_dev.GATE_PARAMS)
+        for i, pe in enumerate(pes):
+            for key, v in pe._gate_params().items():
+                rec[i][key] = v
+        self.params = _dev.upload_structs(rec)
+
+    def channels(self):
+        return 1
+
+    def render(self, start, n):
+        out = DeviceBuffer((self.k, n, 1), np.float32)
+        check(lib().pgx_periodic_gate(out.ptr, n, self.k, start, n, self.params.ptr), "pgx_periodic_gate")
+        return out
+
+
+class _AdsrGatedNode(_Node):
+    def __init__(self, pes, children):
+        super().__init__(pes, children)
+        rec = np.zeros(self.k, dtype=_dev.ADSR_PARAMS)
+        for i, pe in enumerate(pes):
+            for key, v in pe._adsr_params().items():
+                rec[i][key] = v
+        self.params = _dev.upload_structs(rec)
+        self.state = DeviceBuffer((self.k, 3), np.float64, zero=True)
+
+    def reset(self):
+        super().reset()
+        self.state.zero_()
+
+    def channels(self):
+        return 1
+
+    def render(self, start, n):
+        gate = self.children["gate"].render(start, n)
+        out = DeviceBuffer((self.k, n, 1), np.float32)
+        check(lib().pgx_adsr_gated(out.ptr, n, gate.ptr, n, self.k, n, self.params.ptr, self.state.ptr),
+              "pgx_adsr_gated")
+        return out
+
+
+class _GainNode(_Node):
+    def __init__(self, pes, children):
+        super().__init__(pes, children)
+        self.gains = None
+        if "gain" not in children:
+            self.gains = [float(np.float32(pe._gain)) for pe in pes]
+
+    def channels(self):
+        return self.children["source"].channels()
+
+    def render(self, start, n):
+        L = lib()
+        x = self.children["source"].render(start, n)
+        ch = x.shape[2]
+        out = DeviceBuffer((self.k, n, ch), np.float32)
+        if self.gains is None:
+            g = self.children["gain"].render(start, n)
+            # elementwise over the stacked [K*n] frames: one launch for all voices
+            check(L.pgx_gain_vec(out.ptr, x.ptr, g.ptr, self.k * n, ch, g.shape[2]), "pgx_gain_vec")
+        elif len(set(self.gains)) == 1:
+            check(L.pgx_gain_const(out.ptr, x.ptr, self.k * n * ch, self.gains[0]), "pgx_gain_const")
+        else:
+            for i, gval in enumerate(self.gains):
+                check(L.pgx_gain_const(out.offset_ptr(i * n * ch), x.offset_ptr(i * n * ch), n * ch, gval),
+                      "pgx_gain_const")
+        return out
+
+
+# ------------------------------------------------------------------------------------ builder
+def _signature(pe):
+    """Structural key of a voice tree, or None when the tree cannot be batched."""
+    if pe.extent() != Extent(None, None):
+        return None          # MixPE's extent-skip rule is per input; banks need always-on voices
+    if isinstance(pe, SinePE):
+        if pe._has_pe_inputs():
+            return None
+        return ("sine", pe._channels)
+    if isinstance(pe, BlitSawPE):
+        if pe.inputs():
+            return None
+        return ("blitsaw", pe._channels)
+    if isinstance(pe, SuperSawPE):
+        if pe.inputs():
+            return None
+        return ("supersaw", pe._channels, len(pe._oscillators))
+    if isinstance(pe, BiquadPE):
+        if pe._freq_is_pe or pe._q_is_pe:
+            return None
+        sub = _signature(pe._source)
+        return None if sub is None else ("biquad", sub)
+    if isinstance(pe, LadderPE):
+        if pe._freq_is_pe or pe._res_is_pe or pe._drive_is_pe:
+            return None
+        sub = _signature(pe._source)
+        return None if sub is None else ("ladder", sub)
+    if isinstance(pe, PeriodicGate):
+        return ("gate",)
+    if isinstance(pe, AdsrGatedPE):
+        sub = _signature(pe._gate)
+        return None if sub is None else ("adsr_gated", sub)
+    if isinstance(pe, GainPE):
+        sub = _signature(pe._source)
+        if sub is None:
+            return None
+        if pe._gain_is_pe:
+            g = _signature(pe._gain)
+            return None if g is None else ("gain_pe", sub, g)
+        return ("gain", sub)
+    return None
+
+
+def _collect_ids(pe, seen):
+    if id(pe) in seen:
+        return False
+    seen.add(id(pe))
+    return all(_collect_ids(c, seen) for c in pe.inputs())
+
+
+def _build(pes):
+    pe = pes[0]
+    if isinstance(pe, SinePE):
+        return _SineNode(pes)
+    if isinstance(pe, BlitSawPE):
+        return _BlitSawNode(pes)
+    if isinstance(pe, SuperSawPE):
+        return _SuperSawNode(pes)
+    if isinstance(pe, BiquadPE):
+        return _BiquadNode(pes, {"source": _build([p._source for p in pes])})
+    if isinstance(pe, LadderPE):
+        return _LadderNode(pes, {"source": _build([p._source for p in pes])})
+    if isinstance(pe, PeriodicGate):
+        return _GateNode(pes)
+    if isinstance(pe, AdsrGatedPE):
+        return _AdsrGatedNode(pes, {"gate": _build([p._gate for p in pes])})
+    if isinstance(pe, GainPE):
+        children = {"source": _build([p._source for p in pes])}
+        if pe._gain_is_pe:
+            children["gain"] = _build([p._gain for p in pes])
+        return _GainNode(pes, children)
+    raise TypeError(type(pe).__name__)
+
+
+class VoiceBank:
+    def __init__(self, inputs):
+        self.k = len(inputs)
+        self.root = _build(list(inputs))
+
+    def reset(self) -> None:
+        self.root.reset()
+
+    def render_mix(self, start: int, duration: int) -> Snippet:
+        stacked = self.root.render(start, duration)              # [K][n][C]
+        ch = stacked.shape[2]
+        out = DeviceBuffer((duration, ch), np.float32)
+        check(lib().pgx_mix_batch(out.ptr, stacked.ptr, duration * ch, self.k, duration * ch),
+              "pgx_mix_batch")
+        return Snippet(start, out)
+
 
 def try_build_bank(inputs):
-    return None
+    """VoiceBank for `inputs` if they are >= MIN_VOICES identical, private, batchable trees."""
+    if len(inputs) < MIN_VOICES:
+        return None
+    sig0 = _signature(inputs[0])
+    if sig0 is None:
+        return None
+    seen = set()
+    for pe in inputs:
+        if _signature(pe) != sig0 or not _collect_ids(pe, seen):
+            return None          # different structure, or a node shared between voices
+    return VoiceBank(inputs)

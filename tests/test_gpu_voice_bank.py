@@ -1,0 +1,106 @@
+"""GPU: batched voice banks and the sharded mix produce the same samples as rendering the
+voices one by one, and stay within the parity budget of the CPU oracle."""
+
+import numpy as np
+import pytest
+
+import pygmu2_amd as pg
+from oracle.golden_cases import S
+from oracle.graph_eval import Node
+from pygmu2_amd.sharding import ShardedMixPE, c5_voice
+from spec_build import build
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_blocks(root, sr, blocks):
+    r = pg.NullRenderer(sample_rate=sr)
+    r.set_source(root)
+    r.start()
+    out = [root.render(s, n).data for s, n in blocks]
+    r.stop()
+    return out
+
+
+def test_c5_bank_equals_unbatched_and_oracle():
+    pg.set_sample_rate(48000)
+    idx = [0, 37, 101, 256, 300, 411, 480, 511]
+    blocks = [(0, 12000), (12000, 12000), (24000, 1000), (50000, 4096)]     # last one: a gap -> resets
+
+    banked = pg.MixPE(*[c5_voice(pg, i) for i in idx])
+    got_bank = _render_blocks(banked, 48000, blocks)
+    assert banked._bank, "voice bank was not built for identical C5 voices"
+
+    plain = pg.MixPE(*[c5_voice(pg, i) for i in idx])
+    plain._bank = False                                                     # force per-input rendering
+    got_plain = _render_blocks(plain, 48000, blocks)
+    for a, b in zip(got_bank, got_plain):
+        assert np.array_equal(a, b), f"bank differs from per-voice path, max|d|={np.max(np.abs(a - b))}"
+
+    spec = S("MixPE", inputs=[
+        S("GainPE", source=S("BiquadPE", source=S("BlitSawPE", frequency=27.5 * 2 ** (i / 48.0)),
+                             frequency=2000.0, q=0.707),
+          gain=S("AdsrGatedPE", gate=S("PeriodicGate", frequency=2.0 + 0.01 * i, duty_cycle=0.5),
+                 attack_time=0.01, decay_time=0.1, sustain_level=0.7, release_time=0.2)) for i in idx])
+    oracle = Node(spec, 48000)
+    for (s, n), g in zip(blocks, got_bank):
+        w = oracle.render(s, n)
+        assert np.max(np.abs(g.astype(np.float64) - w)) <= 1e-5 * np.max(np.abs(w)) + 1e-7
+
+
+def test_c4_bank_supersaw_ladder():
+    pg.set_sample_rate(48000)
+
+    def voice(i):
+        return pg.LadderPE(pg.SuperSawPE(55.0 * 2 ** (i / 12.0), voices=7, detune_cents=20.0, seed=i),
+                           frequency=1200.0, resonance=0.3, mode=pg.LadderMode.LP24, drive=1.0, oversample=2)
+
+    blocks = [(0, 4096), (4096, 4096)]
+    banked = pg.MixPE(*[voice(i) for i in range(6)])
+    got_bank = _render_blocks(banked, 48000, blocks)
+    assert banked._bank
+    plain = pg.MixPE(*[voice(i) for i in range(6)])
+    plain._bank = False
+    got_plain = _render_blocks(plain, 48000, blocks)
+    for a, b in zip(got_bank, got_plain):
+        assert np.array_equal(a, b)
+    spec = S("MixPE", inputs=[
+        S("LadderPE", source=S("SuperSawPE", frequency=55.0 * 2 ** (i / 12.0), voices=7, detune_cents=20.0, seed=i),
+          frequency=1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2) for i in range(6)])
+    oracle = Node(spec, 48000)
+    for (s, n), g in zip(blocks, got_bank):
+        w = oracle.render(s, n)
+        assert np.max(np.abs(g.astype(np.float64) - w)) <= 1e-5 * np.max(np.abs(w)) + 1e-7
+
+
+def test_bank_restart_reproduces_first_run():
+    pg.set_sample_rate(48000)
+    root = pg.MixPE(*[c5_voice(pg, i) for i in range(5)])
+    first = _render_blocks(root, 48000, [(0, 8000), (8000, 8000)])
+    again = _render_blocks(root, 48000, [(0, 8000), (8000, 8000)])
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+
+
+def test_not_batchable_graphs_fall_back():
+    pg.set_sample_rate(48000)
+    mixed = pg.MixPE(pg.SinePE(440.0), pg.BlitSawPE(220.0), pg.SinePE(330.0), pg.SinePE(550.0))
+    mixed.render(0, 256)
+    assert mixed._bank is False
+    shared = pg.SinePE(100.0)
+    m2 = pg.MixPE(shared, shared, shared, shared)               # one node reused: not private voices
+    m2.render(0, 256)
+    assert m2._bank is False
+    cropped = pg.MixPE(*[pg.CropPE(pg.SinePE(100.0 * (i + 1)), 0, 100) for i in range(4)])
+    cropped.render(0, 256)
+    assert cropped._bank is False
+
+
+def test_sharded_world1_equals_mix():
+    pg.set_sample_rate(48000)
+    a = ShardedMixPE([c5_voice(pg, i) for i in range(6)], 0, 1)
+    b = pg.MixPE(*[c5_voice(pg, i) for i in range(6)])
+    ga = _render_blocks(a, 48000, [(0, 6000), (6000, 6000)])
+    gb = _render_blocks(b, 48000, [(0, 6000), (6000, 6000)])
+    for x, y in zip(ga, gb):
+        assert np.array_equal(x, y)

@@ -1,0 +1,63 @@
+"""CPU: the multi-rank path (voice sharding + one all-reduce per block) on gloo, world_size 2
+and 3 (uneven shard, and a rank that owns a single voice), with host-side voices."""
+
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pygmu2_amd as pg
+from pygmu2_amd.sharding import ShardedMixPE, shard_indices
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _gloo_worker as W  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_indices_round_robin():
+    assert shard_indices(8, 0, 2) == [0, 2, 4, 6] and shard_indices(8, 1, 2) == [1, 3, 5, 7]
+    assert shard_indices(5, 2, 3) == [2] and shard_indices(2, 2, 3) == []
+    cover = sorted(i for r in range(8) for i in shard_indices(512, r, 8))
+    assert cover == list(range(512)) and len(shard_indices(512, 3, 8)) == 64
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
+
+
+def test_world_one_is_plain_local_mix():
+    pg.set_sample_rate(48000)
+    voices = W.make_voices(pg, 3, 1)
+    root = ShardedMixPE(voices, 0, 1, local_mixer=W.host_mixer(pg))
+    want = sum(v.render(0, 64).data for v in voices)
+    assert np.allclose(root.render(0, 64).data, want, atol=1e-6)
+    assert root.channel_count() == 1 and not root.is_pure()
+    with pytest.raises(ValueError):
+        ShardedMixPE(voices[:1], 0, 1)
+
+
+@pytest.mark.parametrize("world,n_voices", [(2, 6), (3, 4)])
+def test_sharded_mix_matches_full_mix_gloo(tmp_path, world, n_voices):
+    port = _free_port()
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(HERE))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(r), str(world),
+                               str(port), str(n_voices), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()[-2000:]
+    pg.set_sample_rate(48000)
+    voices = W.make_voices(pg, n_voices, 2)
+    want = np.concatenate([sum(v.render(i * 1000, 1000).data for v in voices) for i in range(3)])
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
