@@ -1,6 +1,5 @@
-// pgx_seq.hip -- PEs whose recurrences are not associative scans: LadderPE (nonlinear),
-// CombPE (integer-indexed delay line), AdsrGatedPE / AdsrTriggeredPE (state machines whose
-// float64 accumulation must be reproduced step by step to stay bit-exact).
+// pgx_seq.hip -- PEs whose recurrences are not associative scans: LadderPE (nonlinear) and
+// CombPE (integer-indexed delay line).  (The ADSR state machines live in pgx_adsr.hip.)
 //
 // Parallelism comes from independent chains (voices x channels); inside one chain the
 // reference's per-sample operation order is followed literally (-ffp-contract=off).
@@ -8,91 +7,6 @@
 #include "pgx_common.h"
 
 namespace {
-
-// ================================================================================================
-// ADSR (adsr_pe.py:124-196 gated, :279-335 triggered).  One lane per instance.
-// States: 0 IDLE, 1 ATTACK, 2 DECAY, 3 SUSTAIN, 4 RELEASE.
-// ================================================================================================
-__global__ void __launch_bounds__(64)
-k_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t gate_stride, int batch, int64_t n,
-             const pgx_adsr_params *params, double *state) {
-    const int inst = blockIdx.x * 64 + threadIdx.x;
-    if (inst >= batch) return;
-    const pgx_adsr_params p = params[inst];
-    const float *g = gate + (int64_t)inst * gate_stride;
-    float *o = out + (int64_t)inst * out_stride;
-    double *st = state + (int64_t)inst * 3;
-    int s = (int)st[0];
-    double env = st[1];
-    float prev = (float)st[2];
-    for (int64_t i = 0; i < n; ++i) {
-        o[i] = (float)env;
-        const float cur = g[i];
-        const bool new_attack = (prev == 0.0f && cur == 1.0f);
-        const bool new_release = (prev == 1.0f && cur == 0.0f);
-        prev = cur;
-        if (new_attack) s = 1;
-        else if (new_release) s = 4;
-        if (s == 0) {
-            env = 0.0;
-        } else if (s == 1) {
-            env += p.attack_dvdt;
-            if (env >= 1.0) { env = 1.0; s = 2; }
-        } else if (s == 2) {
-            env += p.decay_dvdt;
-            if (env <= p.sustain_level) { env = p.sustain_level; s = 3; }
-        } else if (s == 3) {
-            env = p.sustain_level;
-        } else {
-            env += p.release_dvdt;
-            if (env <= 0.0) { env = 0.0; s = 0; }
-        }
-    }
-    st[0] = (double)s;
-    st[1] = env;
-    st[2] = (double)prev;
-}
-
-__global__ void __launch_bounds__(64)
-k_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride, int batch,
-                 int64_t start, int64_t n, const pgx_adsr_params *params, double *state) {
-    const int inst = blockIdx.x * 64 + threadIdx.x;
-    if (inst >= batch) return;
-    const pgx_adsr_params p = params[inst];
-    const float *g = trig + (int64_t)inst * trig_stride;
-    float *o = out + (int64_t)inst * out_stride;
-    double *st = state + (int64_t)inst * 3;
-    int s = (int)st[0];
-    double env = st[1];
-    int64_t ends_at = (int64_t)st[2];
-    for (int64_t i = 0; i < n; ++i) {
-        o[i] = (float)env;
-        const int64_t now = start + i;
-        if (g[i] > 0.0f) s = 1;
-        if (s == 0) {
-            env = 0.0;
-        } else if (s == 1) {
-            env += p.attack_dvdt;
-            if (env >= 1.0) { env = 1.0; s = 2; }
-        } else if (s == 2) {
-            env += p.decay_dvdt;
-            if (env <= p.sustain_level) {
-                env = p.sustain_level;
-                ends_at = now + p.sustain_samples;
-                s = 3;
-            }
-        } else if (s == 3) {
-            env = p.sustain_level;
-            if (now >= ends_at) s = 4;
-        } else {
-            env += p.release_dvdt;
-            if (env <= 0.0) { env = 0.0; s = 0; }
-        }
-    }
-    st[0] = (double)s;
-    st[1] = env;
-    st[2] = (double)ends_at;
-}
 
 // ================================================================================================
 // LadderPE (ladder_pe.py:31-203).  One lane per (instance, channel) chain.
@@ -313,30 +227,6 @@ k_comb_apply(float *out, const float *in, int64_t n, int channels, double *ring,
 
 // ================================================================================================ C ABI
 extern "C" {
-
-int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t gate_stride, int batch, int64_t n,
-                   const pgx_adsr_params *params, double *state) {
-    PGX_REQUIRE_INIT();
-    if (n <= 0 || batch <= 0) return PGX_OK;
-    PGX_CHECK_ARG(out && gate && params && state, "pgx_adsr_gated: null pointer");
-    PGX_CHECK_ARG(batch == 1 || (out_stride >= n && gate_stride >= n), "pgx_adsr_gated: stride too small");
-    hipLaunchKernelGGL(k_adsr_gated, dim3((batch + 63) / 64), dim3(64), 0, pgx::stream(), out, out_stride, gate,
-                       gate_stride, batch, n, params, state);
-    PGX_LAUNCH_CHECK("k_adsr_gated");
-    return PGX_OK;
-}
-
-int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride, int batch,
-                       int64_t start, int64_t n, const pgx_adsr_params *params, double *state) {
-    PGX_REQUIRE_INIT();
-    if (n <= 0 || batch <= 0) return PGX_OK;
-    PGX_CHECK_ARG(out && trig && params && state, "pgx_adsr_triggered: null pointer");
-    PGX_CHECK_ARG(batch == 1 || (out_stride >= n && trig_stride >= n), "pgx_adsr_triggered: stride too small");
-    hipLaunchKernelGGL(k_adsr_triggered, dim3((batch + 63) / 64), dim3(64), 0, pgx::stream(), out, out_stride,
-                       trig, trig_stride, batch, start, n, params, state);
-    PGX_LAUNCH_CHECK("k_adsr_triggered");
-    return PGX_OK;
-}
 
 int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
                int channels, double sample_rate, const pgx_ladder_params *params, const float *freq,

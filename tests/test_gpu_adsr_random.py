@@ -1,0 +1,107 @@
+"""GPU: randomized bit-exact check of the wave-parallel ADSR kernels against the CPU oracle's
+literal per-sample loop (oracle/seq_kernels.c), through the batched C-ABI entry points.
+
+Covers what the closed-form "runs" must get right: accumulation rounding in every binade,
+ties, clamps that land exactly on a step count (attack_time * sr integral), gate edges on
+every chunk offset, arbitrary (non 0/1) gate values, sustain levels 0 and 1, re-triggers in
+every phase, and state carried across odd-sized blocks."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pe_oracle as O
+from pygmu2_amd import device
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000.0
+
+
+def _params(rng, k, triggered):
+    rec = np.zeros(k, dtype=device.ADSR_PARAMS)
+    for i in range(k):
+        kind = rng.integers(0, 4)
+        if kind == 0:      # times that are exact multiples of the sample period
+            at, dt, rt = (rng.integers(1, 2000, 3) / SR)
+        elif kind == 1:    # power-of-two step counts: exact additions, exact clamp hits
+            at, dt, rt = (2.0 ** rng.integers(3, 12, 3)) / SR
+        else:
+            at, dt, rt = 10 ** rng.uniform(-4, -0.5, 3)
+        sl = [0.0, 1.0, 0.5, 0.7, float(rng.uniform(0.01, 0.99))][rng.integers(0, 5)]
+        a, d, r = O.adsr_slopes(at, dt, sl, rt, SR)
+        rec[i] = (a, d, r, sl, int(round(float(rng.uniform(0, 0.05)) * SR)) if triggered else 0)
+    return rec
+
+
+def _gates(rng, k, n):
+    g = np.zeros((k, n), np.float32)
+    for i in range(k):
+        pos, level = 0, 0.0
+        while pos < n:
+            run = int(rng.integers(1, [40, 700, 6000][rng.integers(0, 3)]))
+            g[i, pos:pos + run] = level
+            pos += run
+            level = 1.0 - level if rng.random() < 0.9 else [0.5, 2.0, -1.0][rng.integers(0, 3)]
+    return g
+
+
+def _triggers(rng, k, n):
+    t = np.zeros((k, n), np.float32)
+    for i in range(k):
+        m = int(rng.integers(1, 40))
+        t[i, rng.integers(0, n, m)] = rng.choice([1.0, 2.0, 0.5], m)
+        t[i, rng.integers(0, n, 3)] = -1.0
+    return t
+
+
+@pytest.mark.parametrize("triggered", [False, True], ids=["gated", "triggered"])
+def test_adsr_batch_bit_exact_random(triggered):
+    lib = device.ensure_init()
+    rng = np.random.default_rng(1234 + int(triggered))
+    k, n = 192, 20000
+    rec = _params(rng, k, triggered)
+    ctl = _triggers(rng, k, n) if triggered else _gates(rng, k, n)
+    blocks = [1, 63, 64, 65, 1000, 4097, 129, 7000]
+    blocks.append(n - sum(blocks))
+    assert blocks[-1] > 0
+
+    # oracle: literal loop per envelope, state carried across the same blocks
+    want = np.zeros((k, n), np.float32)
+    for i in range(k):
+        st = np.zeros(3)
+        pos = 0
+        for b in blocks:
+            out = np.zeros(b, np.float32)
+            seg = np.ascontiguousarray(ctl[i, pos:pos + b])
+            if triggered:
+                O._c().orc_adsr_triggered(O._p(seg, C.c_float), O._p(out, C.c_float), C.c_int64(pos + 5),
+                                          C.c_int64(b), C.c_double(rec[i]["attack_dvdt"]),
+                                          C.c_double(rec[i]["decay_dvdt"]), C.c_double(rec[i]["release_dvdt"]),
+                                          C.c_double(rec[i]["sustain_level"]),
+                                          C.c_int64(int(rec[i]["sustain_samples"])), O._p(st))
+            else:
+                O._c().orc_adsr_gated(O._p(seg, C.c_float), O._p(out, C.c_float), C.c_int64(b),
+                                      C.c_double(rec[i]["attack_dvdt"]), C.c_double(rec[i]["decay_dvdt"]),
+                                      C.c_double(rec[i]["release_dvdt"]), C.c_double(rec[i]["sustain_level"]),
+                                      O._p(st))
+            want[i, pos:pos + b] = out
+            pos += b
+
+    params = device.DeviceBuffer.from_host(rec)
+    state = device.DeviceBuffer((k, 3), np.float64, zero=True)
+    got = np.zeros((k, n), np.float32)
+    pos = 0
+    for b in blocks:
+        cin = device.DeviceBuffer.from_host(np.ascontiguousarray(ctl[:, pos:pos + b]))
+        cout = device.DeviceBuffer((k, b), np.float32)
+        if triggered:
+            device.check(lib.pgx_adsr_triggered(cout.ptr, b, cin.ptr, b, k, pos + 5, b, params.ptr, state.ptr))
+        else:
+            device.check(lib.pgx_adsr_gated(cout.ptr, b, cin.ptr, b, k, b, params.ptr, state.ptr))
+        got[:, pos:pos + b] = cout.to_host()
+        pos += b
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (f"{len(bad)} samples differ; first at envelope {bad[0][0]} sample {bad[0][1]}: "
+                           f"got {got[tuple(bad[0])]!r} want {want[tuple(bad[0])]!r}, params {rec[bad[0][0]]}")
