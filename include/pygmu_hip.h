@@ -66,6 +66,10 @@ int pgx_event_destroy(void *event);
 int pgx_event_record(void *event);              /* on the library stream */
 int pgx_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
 
+/* Diagnostics: evaluate the library's float64 sine / cosine (the routine every oscillator and
+ * coefficient kernel uses in place of np.sin / np.cos) on n device doubles. */
+int pgx_selftest_sincos(double *out_sin, double *out_cos, const double *x, int64_t n);
+
 /* ------------------------------------------------------------------ sources / copies
  * ConstantPE._render (constant_pe.py:51-63), IdentityPE._render (identity_pe.py:43-60),
  * DiracPE._render (dirac_pe.py:48-67), ArrayPE._render (array_pe.py:74-129) and the
@@ -126,6 +130,10 @@ int pgx_mix_n(float *out, const float *const *ins_host, int k, int64_t n_elems);
 /* Sum of `batch` equally shaped voices stored [batch][n_elems] (stride in elements),
  * accumulated in float32 in voice order 0..batch-1 (== MixPE over the voices). */
 int pgx_mix_batch(float *out, const float *in, int64_t in_stride, int batch, int64_t n_elems);
+/* MixPE over voices that each end in GainPE(voice, gain=<PE>): out = sum_b float32(in_b * gain_b),
+ * products rounded to float32, added in voice order -- identical to pgx_gain_vec + pgx_mix_batch. */
+int pgx_gain_mix_batch(float *out, const float *in, int64_t in_stride, const float *gain,
+                       int64_t gain_stride, int batch, int64_t n, int channels, int gain_channels);
 
 /* ------------------------------------------------------------------ BiquadPE
  * Constant coefficients: BiquadPE._filter_constant_coeffs (biquad_pe.py:383-404), i.e.
@@ -228,8 +236,9 @@ int pgx_periodic_trigger(float *out, int64_t start, int64_t n, int64_t period,
                          int64_t phase_samples, float amplitude);
 
 /* AdsrGatedPE._render (adsr_pe.py:124-196) / AdsrTriggeredPE._render (adsr_pe.py:279-335):
- * sequential float64 accumulation, one lane per instance -> bit-exact.
- * state[instance] = {state enum, env, prev_gate | sustain_ends_at}. */
+ * the reference's sequential float64 accumulation reproduced bit for bit (binade-linear runs, see
+ * pgx_adsr.hip).  state[instance] = {state enum, env, prev_gate | sustain_ends_at}.
+ * workspace: >= pgx_adsr_workspace_bytes(batch, n) bytes of device scratch (edge masks). */
 typedef struct {
     double attack_dvdt;
     double decay_dvdt;
@@ -237,11 +246,17 @@ typedef struct {
     double sustain_level;
     int64_t sustain_samples;   /* triggered variant only */
 } pgx_adsr_params;
+size_t pgx_adsr_workspace_bytes(int batch, int64_t n);
 int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t gate_stride,
-                   int batch, int64_t n, const pgx_adsr_params *params, double *state);
+                   int batch, int64_t n, const pgx_adsr_params *params, double *state, void *workspace);
+/* AdsrGatedPE(PeriodicGate(scalar params)): the gate of pgx_periodic_gate is evaluated inside the
+ * envelope kernels, sample for sample the same values, without materialising the gate buffer. */
+int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
+                            const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
+                            void *workspace);
 int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride,
                        int batch, int64_t start, int64_t n, const pgx_adsr_params *params,
-                       double *state);
+                       double *state, void *workspace);
 
 /* ------------------------------------------------------------------ ConvolvePE
  * ConvolvePE._render (convolve_pe.py:250-342): y = x * h (linear, streaming).  The

@@ -43,6 +43,7 @@ class _AdsrBase(ProcessingElement):
             self._attack_time, self._decay_time, self._sustain_level, self._release_time)
         self._params: DeviceBuffer | None = None
         self._state: DeviceBuffer | None = None
+        self._workspace: DeviceBuffer | None = None
 
     def is_pure(self) -> bool:
         return False
@@ -74,6 +75,12 @@ class _AdsrBase(ProcessingElement):
         if self._state is None:
             self._state = DeviceBuffer((3,), np.float64, zero=True)
 
+    def _scratch(self, duration: int) -> DeviceBuffer:
+        need = lib().pgx_adsr_workspace_bytes(1, duration)
+        if self._workspace is None or self._workspace.nbytes < need:
+            self._workspace = DeviceBuffer((need,), np.uint8)
+        return self._workspace
+
     def _control_mono(self, start: int, duration: int) -> DeviceBuffer:
         snip = self._control.render(start=start, duration=duration)
         if snip.channels != 1:
@@ -92,7 +99,7 @@ class AdsrGatedPE(_AdsrBase):
         gate = self._control_mono(start, duration)
         out = new_output(duration, 1)
         check(lib().pgx_adsr_gated(out.ptr, 0, gate.ptr, 0, 1, duration, self._params.ptr,
-                                   self._state.ptr), "pgx_adsr_gated")
+                                   self._state.ptr, self._scratch(duration).ptr), "pgx_adsr_gated")
         return Snippet(start, out)
 
 
@@ -108,6 +115,6 @@ class AdsrTriggeredPE(_AdsrBase):
         self._ensure_device()
         trig = self._control_mono(start, duration)
         out = new_output(duration, 1)
-        check(lib().pgx_adsr_triggered(out.ptr, 0, trig.ptr, 0, 1, start, duration,
-                                       self._params.ptr, self._state.ptr), "pgx_adsr_triggered")
+        check(lib().pgx_adsr_triggered(out.ptr, 0, trig.ptr, 0, 1, start, duration, self._params.ptr,
+                                       self._state.ptr, self._scratch(duration).ptr), "pgx_adsr_triggered")
         return Snippet(start, out)

@@ -58,7 +58,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+    extra = os.environ.get("PGX_EXTRA_FLAGS", "").split()       # experiments: -DPGX_... switches
+    cmd = [_hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                                 "-o", LIB_PATH] + srcs
     if verbose:
         print("[pygmu2_amd.build]", " ".join(cmd), flush=True)

@@ -57,6 +57,79 @@ constexpr int kNumCU = 256;    // MI355X
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ------------------------------------------------------------------------------------------
+// float64 sine / cosine for the oscillator kernels.
+// Cody-Waite reduction by pi with a 33+33+53-bit split (q*PI_A and q*PI_B are exact for |q| < 2^20)
+// followed by the Taylor polynomials on |r| <= pi/2 (degree 21 / 22: truncation < 2e-18).
+// Error ~1-2 ulp, like the libm / SVML routines behind the reference's np.sin; arguments beyond
+// 3e6 rad (where the split stops being exact) fall back to the ocml routine.
+#ifdef __HIPCC__
+__device__ __forceinline__ double pgx_reduce_pi(double x, long long &qi) {
+    const double PI_A = 0x1.921fb54400000p+1, PI_B = 0x1.0b4611a600000p-33, PI_C = 0x1.3198a2e037073p-68;
+    const double q = rint(x * 0x1.45f306dc9c883p-2);
+    double r = __builtin_fma(-q, PI_A, x);
+    r = __builtin_fma(-q, PI_B, r);
+    r = __builtin_fma(-q, PI_C, r);
+    qi = (long long)q;
+    return r;
+}
+__device__ __forceinline__ double pgx_sin_poly(double r) {       // sin(r), |r| <= pi/2
+    const double s = r * r;
+    double p = -1.0 / 51090942171709440000.0;                    // -1/21!
+    p = __builtin_fma(p, s, 1.0 / 121645100408832000.0);         // +1/19!
+    p = __builtin_fma(p, s, -1.0 / 355687428096000.0);           // -1/17!
+    p = __builtin_fma(p, s, 1.0 / 1307674368000.0);              // +1/15!
+    p = __builtin_fma(p, s, -1.0 / 6227020800.0);                // -1/13!
+    p = __builtin_fma(p, s, 1.0 / 39916800.0);                   // +1/11!
+    p = __builtin_fma(p, s, -1.0 / 362880.0);                    // -1/9!
+    p = __builtin_fma(p, s, 1.0 / 5040.0);                       // +1/7!
+    p = __builtin_fma(p, s, -1.0 / 120.0);                       // -1/5!
+    p = __builtin_fma(p, s, 1.0 / 6.0);                          // +1/3!
+    // p = 1/3! - s/5! + s^2/7! - ... ; sin(r) = r - r^3 * p
+    return __builtin_fma(-(r * s), p, r);
+}
+__device__ __forceinline__ double pgx_cos_poly(double r) {       // cos(r), |r| <= pi/2
+    const double s = r * r;
+    double p = 1.0 / 1124000727777607680000.0;                   // +1/22!
+    p = __builtin_fma(p, s, -1.0 / 2432902008176640000.0);       // -1/20!
+    p = __builtin_fma(p, s, 1.0 / 6402373705728000.0);           // +1/18!
+    p = __builtin_fma(p, s, -1.0 / 20922789888000.0);            // -1/16!
+    p = __builtin_fma(p, s, 1.0 / 87178291200.0);                // +1/14!
+    p = __builtin_fma(p, s, -1.0 / 479001600.0);                 // -1/12!
+    p = __builtin_fma(p, s, 1.0 / 3628800.0);                    // +1/10!
+    p = __builtin_fma(p, s, -1.0 / 40320.0);                     // -1/8!
+    p = __builtin_fma(p, s, 1.0 / 720.0);                        // +1/6!
+    p = __builtin_fma(p, s, -1.0 / 24.0);                        // -1/4!
+    p = __builtin_fma(p, s, 0.5);                                // +1/2!
+    return __builtin_fma(-s, p, 1.0);                            // 1 - s*p
+}
+// np.mod(a, 1.0) (result in [0, 1], sign of the divisor): a - floor(a) is the same value --
+// fmod(a,1) is exact, and numpy's "+1 if negative" rounds once, exactly like this subtraction.
+__device__ __forceinline__ double pgx_mod1(double a) {
+    const double r = a - floor(a);
+    return (r == 0.0) ? 0.0 : r;      // +0 for integers and for -0.0
+}
+__device__ __forceinline__ double pgx_sin(double x) {
+    if (!(fabs(x) < 3.0e6)) return sin(x);
+    long long qi;
+    const double r = pgx_reduce_pi(x, qi);
+    const double v = pgx_sin_poly(r);
+    return (qi & 1) ? -v : v;
+}
+__device__ __forceinline__ void pgx_sincos(double x, double &sn, double &cs) {
+    if (!(fabs(x) < 3.0e6)) {
+        sn = sin(x);
+        cs = cos(x);
+        return;
+    }
+    long long qi;
+    const double r = pgx_reduce_pi(x, qi);
+    const double a = pgx_sin_poly(r), b = pgx_cos_poly(r);
+    sn = (qi & 1) ? -a : a;
+    cs = (qi & 1) ? -b : b;
+}
+#endif
+
 // Grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
 inline int grid_for(int64_t work_items, int block) {
     int64_t g = ceil_div(work_items, block);

@@ -40,15 +40,15 @@ __host__ __device__ inline bool is_aligned16(const void *p) {
     return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-// numpy's float remainder (np.mod): result takes the sign of the divisor.
-__device__ __forceinline__ double np_mod1(double a) {
-    double r = fmod(a, 1.0);
-    if (r != 0.0) {
-        if (r < 0.0) r += 1.0;
-    } else {
-        r = 0.0;   // copysign(0, +1)
+__global__ void __launch_bounds__(kBlock) k_selftest_sincos(double *os, double *oc, const double *x, int64_t n) {
+    int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        double sn, cs;
+        pgx::pgx_sincos(x[i], sn, cs);
+        os[i] = pgx::pgx_sin(x[i]);
+        oc[i] = cs;
+        if (sn != os[i]) oc[i] = __builtin_nan("");      // the two entry points must agree
     }
-    return r;
 }
 
 // ------------------------------------------------------------------------------ fill / ramp / dirac
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride,
             if (f != prev_f) {
                 double t = (double)(start + f) / sr;
                 double ph = p.phase0 + p.w * t;
-                prev_v = (float)(p.amp * sin(ph));
+                prev_v = (float)(p.amp * pgx::pgx_sin(ph));
                 prev_f = f;
             }
             v[j] = prev_v;
@@ -192,18 +192,77 @@ __global__ void __launch_bounds__(kBlock) k_mix_n(float *out, MixPtrs ins, int k
     }
 }
 
+// VEC = 4: 16 B/lane (large mixes); VEC = 1: one float per lane so that a 48 000-frame block still
+// spreads over ~190 workgroups.  The voice loop is unrolled 8x: the loads are independent of the
+// (ordered, float32) additions, so 8 of them are in flight per lane.
+template <int VEC>
 __global__ void __launch_bounds__(kBlock) k_mix_batch(float *out, const float *in, int64_t in_stride, int batch,
                                                       int64_t n_elems, bool aligned) {
-    int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
-    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
-        float acc[4], v[4];
-        load4(in, e, n_elems, aligned, acc);
-        for (int b = 1; b < batch; ++b) {
-            load4(in + (int64_t)b * in_stride, e, n_elems, aligned, v);
+    int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+    for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC; e < n_elems; e += stride) {
+        if (VEC == 4) {
+            float acc[4], v[8][4];
+            load4(in, e, n_elems, aligned, acc);
+            int b = 1;
+            for (; b + 8 <= batch; b += 8) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + v[j];
+                for (int u = 0; u < 8; ++u) load4(in + (int64_t)(b + u) * in_stride, e, n_elems, aligned, v[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = acc[j] + v[u][j];
+            }
+            for (; b < batch; ++b) {
+                load4(in + (int64_t)b * in_stride, e, n_elems, aligned, v[0]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = acc[j] + v[0][j];
+            }
+            store4(out, e, n_elems, aligned, acc);
+        } else {
+            float acc = in[e], v[8];
+            int b = 1;
+            for (; b + 8 <= batch; b += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = in[(int64_t)(b + u) * in_stride + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = acc + v[u];
+            }
+            for (; b < batch; ++b) acc = acc + in[(int64_t)b * in_stride + e];
+            out[e] = acc;
         }
-        store4(out, e, n_elems, aligned, acc);
+    }
+}
+
+// out = sum_b float32(x_b * g_b): GainPE(voice, gain=<PE>) fused into the mix (gain_pe.py:104-119 then
+// mix_pe.py:91-94).  Each product is rounded to float32 before the ordered float32 addition, exactly as
+// when the two PEs run separately.  g is (frames, 1) or (frames, channels) per voice.
+__global__ void __launch_bounds__(kBlock) k_gain_mix_batch(float *out, const float *x, const float *g,
+                                                           int64_t x_stride, int64_t g_stride, int batch,
+                                                           int64_t n, int channels, int gain_channels) {
+    const int64_t n_elems = n * channels;
+    int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elems; e += stride) {
+        const int64_t ge = (gain_channels == channels) ? e : e / channels;
+        float acc = x[e] * g[ge];
+        float xv[8], gv[8];
+        int b = 1;
+        for (; b + 8 <= batch; b += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xv[u] = x[(int64_t)(b + u) * x_stride + e];
+                gv[u] = g[(int64_t)(b + u) * g_stride + ge];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float prod = xv[u] * gv[u];
+                acc = acc + prod;
+            }
+        }
+        for (; b < batch; ++b) {
+            float prod = x[(int64_t)b * x_stride + e] * g[(int64_t)b * g_stride + ge];
+            acc = acc + prod;
+        }
+        out[e] = acc;
     }
 }
 
@@ -220,8 +279,8 @@ __global__ void __launch_bounds__(kBlock) k_periodic_gate(float *out, int64_t ou
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double idx = (double)(start + e + j);
-            double base = np_mod1(idx * p.dt);
-            double ph = np_mod1(base + p.phase);
+            double base = pgx::pgx_mod1(idx * p.dt);
+            double ph = pgx::pgx_mod1(base + p.phase);
             v[j] = (ph < p.duty) ? 1.0f : 0.0f;
         }
         store4(o, e, n, aligned, v);
@@ -268,6 +327,16 @@ __global__ void __launch_bounds__(kBlock) k_supersaw_sum(float *out, int64_t out
 
 // ================================================================================ C ABI
 extern "C" {
+
+int pgx_selftest_sincos(double *out_sin, double *out_cos, const double *x, int64_t n) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out_sin && out_cos && x, "pgx_selftest_sincos: null pointer");
+    hipLaunchKernelGGL(k_selftest_sincos, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out_sin,
+                       out_cos, x, n);
+    PGX_LAUNCH_CHECK("k_selftest_sincos");
+    return PGX_OK;
+}
 
 int pgx_fill(float *out, int64_t n_elems, float value) {
     PGX_REQUIRE_INIT();
@@ -386,10 +455,30 @@ int pgx_mix_batch(float *out, const float *in, int64_t in_stride, int batch, int
     PGX_REQUIRE_INIT();
     if (n_elems <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && batch >= 1 && in_stride >= n_elems, "pgx_mix_batch: bad argument");
-    bool al = is_aligned16(out) && is_aligned16(in) && (in_stride % 4 == 0);
-    hipLaunchKernelGGL(k_mix_batch, dim3(pgx::grid_for(pgx::ceil_div(n_elems, kVec), kBlock)), dim3(kBlock), 0,
-                       pgx::stream(), out, in, in_stride, batch, n_elems, al);
+    if (n_elems >= (int64_t)1 << 20) {
+        bool al = is_aligned16(out) && is_aligned16(in) && (in_stride % 4 == 0);
+        hipLaunchKernelGGL(k_mix_batch<4>, dim3(pgx::grid_for(pgx::ceil_div(n_elems, 4), kBlock)), dim3(kBlock),
+                           0, pgx::stream(), out, in, in_stride, batch, n_elems, al);
+    } else {
+        hipLaunchKernelGGL(k_mix_batch<1>, dim3(pgx::grid_for(n_elems, kBlock)), dim3(kBlock), 0, pgx::stream(),
+                           out, in, in_stride, batch, n_elems, false);
+    }
     PGX_LAUNCH_CHECK("k_mix_batch");
+    return PGX_OK;
+}
+
+int pgx_gain_mix_batch(float *out, const float *in, int64_t in_stride, const float *gain, int64_t gain_stride,
+                       int batch, int64_t n, int channels, int gain_channels) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && gain && batch >= 1 && channels >= 1, "pgx_gain_mix_batch: bad argument");
+    PGX_CHECK_ARG(gain_channels == 1 || gain_channels == channels,
+                  "pgx_gain_mix_batch: gain must be mono or match the source channel count");
+    PGX_CHECK_ARG(in_stride >= n * channels && gain_stride >= n * gain_channels,
+                  "pgx_gain_mix_batch: stride too small");
+    hipLaunchKernelGGL(k_gain_mix_batch, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0,
+                       pgx::stream(), out, in, gain, in_stride, gain_stride, batch, n, channels, gain_channels);
+    PGX_LAUNCH_CHECK("k_gain_mix_batch");
     return PGX_OK;
 }
 

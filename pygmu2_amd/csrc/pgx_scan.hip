@@ -371,6 +371,34 @@ struct SawShared {
     double aff[kWaves];
 };
 
+// Per-sample constants of the Dirichlet kernel derived from the frequency (blit_saw_pe.py:166-173,196).
+struct SawConst {
+    double inc, m, P, invP;
+};
+__device__ __forceinline__ SawConst saw_const(double f, double sr, double m_param, bool has_m, double m_stream) {
+    SawConst c;
+    c.inc = f / sr;
+    const double fmax1 = f > 1.0 ? f : 1.0;                    // np.maximum(freq, 1.0)
+    if (has_m) {
+        int mi = (int)m_stream;                                // astype(int32): truncation
+        c.m = (double)(mi > 1 ? mi : 1);
+    } else if (m_param > 0.0) {
+        int mi = (int)m_param;
+        c.m = (double)(mi > 1 ? mi : 1);
+    } else {
+        double m_float = sr / (2.0 * fmax1);
+        int mi = (int)floor(m_float);
+        mi = mi - (1 - (mi % 2));
+        c.m = (double)(mi > 1 ? mi : 1);
+    }
+    c.P = sr / fmax1;
+    c.invP = 1.0 / c.P;
+    return c;
+}
+
+// STREAMS = false: scalar frequency / amplitude / M (every voice-bank and SuperSaw launch): the
+// per-voice constants are hoisted out of the sample loops.
+template <bool STREAMS>
 __global__ void __launch_bounds__(kBlock)
 k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, const pgx_blitsaw_params *params,
           const float *freq, int64_t freq_stride, const float *amp, int64_t amp_stride, const float *mstream,
@@ -380,13 +408,14 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     const int inst = blockIdx.x;
     const pgx_blitsaw_params p = params[inst];
     float *ob = out + (int64_t)inst * out_stride;
-    const float *fs = freq ? freq + (int64_t)inst * freq_stride : nullptr;
-    const float *as = amp ? amp + (int64_t)inst * amp_stride : nullptr;
-    const float *ms = mstream ? mstream + (int64_t)inst * m_stride : nullptr;
+    const float *fs = (STREAMS && freq) ? freq + (int64_t)inst * freq_stride : nullptr;
+    const float *as = (STREAMS && amp) ? amp + (int64_t)inst * amp_stride : nullptr;
+    const float *ms = (STREAMS && mstream) ? mstream + (int64_t)inst * m_stride : nullptr;
 
     const double phase0 = state[inst * 2 + 0];
     double carry_sum = 0.0;                 // running np.cumsum(phase_inc) at the tile start
     double carry_y = state[inst * 2 + 1];   // leaky integrator output y[n-1]
+    const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
 
     // powers of leak for the affine scan
     const double leak = p.leak;
@@ -409,21 +438,20 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 
     for (int64_t base = 0; base < n; base += kSawTile) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
-        double fr[kSawT], inc[kSawT];
-        // ---- frequency and phase increment (blit_saw_pe.py:188) ----
-#pragma unroll
-        for (int j = 0; j < kSawT; ++j) {
-            double f = p.freq;
-            if (fs) f = (f0 + j < n) ? (double)fs[f0 + j] : 0.0;
-            fr[j] = f;
-            inc[j] = (f0 + j < n) ? f / sr : 0.0;
-        }
-        // local inclusive cumsum, then block exclusive offset (np.cumsum, :191)
+        SawConst kc[kSawT];
+        // ---- phase increment and inclusive local cumsum (blit_saw_pe.py:188-191) ----
         double loc[kSawT];
         double run = 0.0;
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) {
-            run = run + inc[j];
+            const bool live = (f0 + j < n);
+            if (STREAMS) {
+                double f = fs ? (live ? (double)fs[f0 + j] : 0.0) : p.freq;
+                kc[j] = saw_const(f, sr, p.m, ms != nullptr, ms ? (live ? (double)ms[f0 + j] : 1.0) : 0.0);
+            } else {
+                kc[j] = k0;
+            }
+            run = run + (live ? kc[j].inc : 0.0);
             loc[j] = run;
         }
         double tile_total;
@@ -435,36 +463,17 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         double xb[kSawT];
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) {
-            double ph = phase0 + (chunk_base + loc[j]);
-            ph = fmod(ph, 1.0);
-            if (ph < 0.0) ph += 1.0;
-            double fmax1 = fr[j] > 1.0 ? fr[j] : 1.0;          // np.maximum(freq, 1.0)
-            double m;
-            if (ms) {
-                float mvf = (f0 + j < n) ? ms[f0 + j] : 1.0f;
-                int mi = (int)(double)mvf;                     // astype(int32): truncation
-                m = (double)(mi > 1 ? mi : 1);
-            } else if (p.m > 0.0) {
-                int mi = (int)p.m;
-                m = (double)(mi > 1 ? mi : 1);
-            } else {
-                double m_float = sr / (2.0 * fmax1);
-                int mi = (int)floor(m_float);
-                mi = mi - (1 - (mi % 2));
-                m = (double)(mi > 1 ? mi : 1);
-            }
-            double P = sr / fmax1;
-            double theta = kPi * ph;
-            double m_theta = m * theta;
-            double sin_num = sin(m_theta);
-            double sin_den = sin(theta);
-            double blit = (fabs(sin_den) < 1e-9) ? (m / P) : (sin_num / (P * sin_den));
-            xb[j] = blit - 1.0 / P;
+            const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));      // np.mod(phase, 1.0)
+            const double theta = kPi * ph;
+            const double m_theta = kc[j].m * theta;
+            const double sin_num = pgx::pgx_sin(m_theta);
+            const double sin_den = pgx::pgx_sin(theta);
+            const double blit = (fabs(sin_den) < 1e-9) ? (kc[j].m / kc[j].P) : (sin_num / (kc[j].P * sin_den));
+            xb[j] = (f0 + j < n) ? (blit - kc[j].invP) : 0.0;
             if (f0 + j == n - 1) {
                 final_phase = ph;
                 have_final = true;
             }
-            if (f0 + j >= n) xb[j] = 0.0;
         }
 
         // ---- leaky integrator y[n] = x[n] + leak*y[n-1] (blit_saw_pe.py:222-234) ----
@@ -479,7 +488,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             double z = leak * y;
             y = z + xb[j];
             double a = p.amp;
-            if (as) a = (f0 + j < n) ? (double)as[f0 + j] : 0.0;
+            if (STREAMS && as) a = (f0 + j < n) ? (double)as[f0 + j] : 0.0;
             yf[j] = (float)((y * 2.0) * a);
             if (f0 + j == n - 1) final_y = y;
         }
@@ -537,7 +546,7 @@ k_sine_stateful(float *out, int64_t n, int channels, double sr, const pgx_sine_s
             ph = ph + pm;                                            // + phase_mod (:220-223)
             double a = p.amp;
             if (amp) a = (f0 + j < n) ? (double)amp[f0 + j] : 0.0;
-            yf[j] = (float)(a * sin(ph));
+            yf[j] = (float)(a * pgx::pgx_sin(ph));
             if (f0 + j == n - 1) {
                 final_phase = ph;
                 have_final = true;
@@ -569,7 +578,8 @@ __device__ __forceinline__ void rbj(int mode, double f, double q, double A, doub
     f = f < 1.0 ? 1.0 : (f > nyq99 ? nyq99 : f);              // np.clip(freq, 1.0, nyquist*0.99)
     q = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
     double omega = ((2.0 * kPi) * f) / sr;
-    double sn = sin(omega), cs = cos(omega);
+    double sn, cs;
+    pgx::pgx_sincos(omega, sn, cs);
     double alpha = sn / (2.0 * q);
     double a0;
     switch (mode) {
@@ -800,8 +810,13 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && params && state && channels >= 1 && sample_rate > 0, "pgx_blitsaw: bad argument");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_blitsaw: out_stride too small");
-    hipLaunchKernelGGL(k_blitsaw, dim3(batch), dim3(kBlock), 0, pgx::stream(), out, out_stride, n, channels,
-                       sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state);
+    if (freq || amp || m) {
+        hipLaunchKernelGGL(k_blitsaw<true>, dim3(batch), dim3(kBlock), 0, pgx::stream(), out, out_stride, n,
+                           channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state);
+    } else {
+        hipLaunchKernelGGL(k_blitsaw<false>, dim3(batch), dim3(kBlock), 0, pgx::stream(), out, out_stride, n,
+                           channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state);
+    }
     PGX_LAUNCH_CHECK("k_blitsaw");
     return PGX_OK;
 }

@@ -53,6 +53,7 @@ _SIGNATURES = [
     ("pgx_event_destroy", _I, [_P]),
     ("pgx_event_record", _I, [_P]),
     ("pgx_event_elapsed_ms", _I, [_P, _P, C.POINTER(_F)]),
+    ("pgx_selftest_sincos", _I, [_P, _P, _P, _L]),
     ("pgx_fill", _I, [_P, _L, _F]),
     ("pgx_ramp", _I, [_P, _F, _F, _L, _I]),
     ("pgx_dirac", _I, [_P, _L, _L, _I]),
@@ -64,6 +65,7 @@ _SIGNATURES = [
     ("pgx_gain_vec", _I, [_P, _P, _P, _L, _I, _I]),
     ("pgx_mix_n", _I, [_P, C.POINTER(_P), _I, _L]),
     ("pgx_mix_batch", _I, [_P, _P, _L, _I, _L]),
+    ("pgx_gain_mix_batch", _I, [_P, _P, _L, _P, _L, _I, _L, _I, _I]),
     ("pgx_biquad_workspace_bytes", _Z, [_I, _L, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
@@ -73,8 +75,10 @@ _SIGNATURES = [
     ("pgx_comb", _I, [_P, _P, _L, _I, _D, _D, _D, _P, _P, _D, _L, _P, _L, _P, _P, _P]),
     ("pgx_periodic_gate", _I, [_P, _L, _I, _L, _L, _P]),
     ("pgx_periodic_trigger", _I, [_P, _L, _L, _L, _L, _F]),
-    ("pgx_adsr_gated", _I, [_P, _L, _P, _L, _I, _L, _P, _P]),
-    ("pgx_adsr_triggered", _I, [_P, _L, _P, _L, _I, _L, _L, _P, _P]),
+    ("pgx_adsr_workspace_bytes", _Z, [_I, _L]),
+    ("pgx_adsr_gated", _I, [_P, _L, _P, _L, _I, _L, _P, _P, _P]),
+    ("pgx_adsr_gated_periodic", _I, [_P, _L, _I, _L, _L, _P, _P, _P, _P]),
+    ("pgx_adsr_triggered", _I, [_P, _L, _P, _L, _I, _L, _L, _P, _P, _P]),
     ("pgx_convolve_workspace_bytes", _Z, [_L, _L, _I]),
     ("pgx_convolve", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P]),
 ]

@@ -230,6 +230,13 @@ class _AdsrGatedNode(_Node):
                 rec[i][key] = v
         self.params = _dev.upload_structs(rec)
         self.state = DeviceBuffer((self.k, 3), np.float64, zero=True)
+        self.ws = None
+
+    def _scratch(self, n):
+        need = lib().pgx_adsr_workspace_bytes(self.k, n)
+        if self.ws is None or self.ws.nbytes < need:
+            self.ws = DeviceBuffer((need,), np.uint8)
+        return self.ws
 
     def reset(self):
         super().reset()
@@ -239,10 +246,17 @@ class _AdsrGatedNode(_Node):
         return 1
 
     def render(self, start, n):
-        gate = self.children["gate"].render(start, n)
         out = DeviceBuffer((self.k, n, 1), np.float32)
-        check(lib().pgx_adsr_gated(out.ptr, n, gate.ptr, n, self.k, n, self.params.ptr, self.state.ptr),
-              "pgx_adsr_gated")
+        gate_node = self.children["gate"]
+        if isinstance(gate_node, _GateNode):
+            # PeriodicGate feeding the envelope: evaluate the gate inside the envelope kernel
+            check(lib().pgx_adsr_gated_periodic(out.ptr, n, self.k, start, n, gate_node.params.ptr,
+                                                self.params.ptr, self.state.ptr, self._scratch(n).ptr),
+                  "pgx_adsr_gated_periodic")
+            return out
+        gate = gate_node.render(start, n)
+        check(lib().pgx_adsr_gated(out.ptr, n, gate.ptr, n, self.k, n, self.params.ptr, self.state.ptr,
+                                   self._scratch(n).ptr), "pgx_adsr_gated")
         return out
 
 
@@ -357,7 +371,17 @@ class VoiceBank:
         self.root.reset()
 
     def render_mix(self, start: int, duration: int) -> Snippet:
-        stacked = self.root.render(start, duration)              # [K][n][C]
+        root = self.root
+        if isinstance(root, _GainNode) and root.gains is None:
+            # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix
+            x = root.children["source"].render(start, duration)
+            g = root.children["gain"].render(start, duration)
+            ch, gch = x.shape[2], g.shape[2]
+            out = DeviceBuffer((duration, ch), np.float32)
+            check(lib().pgx_gain_mix_batch(out.ptr, x.ptr, duration * ch, g.ptr, duration * gch, self.k,
+                                           duration, ch, gch), "pgx_gain_mix_batch")
+            return Snippet(start, out)
+        stacked = root.render(start, duration)                   # [K][n][C]
         ch = stacked.shape[2]
         out = DeviceBuffer((duration, ch), np.float32)
         check(lib().pgx_mix_batch(out.ptr, stacked.ptr, duration * ch, self.k, duration * ch),

@@ -91,15 +91,16 @@ def test_adsr_batch_bit_exact_random(triggered):
 
     params = device.DeviceBuffer.from_host(rec)
     state = device.DeviceBuffer((k, 3), np.float64, zero=True)
+    ws = device.DeviceBuffer((lib.pgx_adsr_workspace_bytes(k, max(blocks)),), np.uint8)
     got = np.zeros((k, n), np.float32)
     pos = 0
     for b in blocks:
         cin = device.DeviceBuffer.from_host(np.ascontiguousarray(ctl[:, pos:pos + b]))
         cout = device.DeviceBuffer((k, b), np.float32)
         if triggered:
-            device.check(lib.pgx_adsr_triggered(cout.ptr, b, cin.ptr, b, k, pos + 5, b, params.ptr, state.ptr))
+            device.check(lib.pgx_adsr_triggered(cout.ptr, b, cin.ptr, b, k, pos + 5, b, params.ptr, state.ptr, ws.ptr))
         else:
-            device.check(lib.pgx_adsr_gated(cout.ptr, b, cin.ptr, b, k, b, params.ptr, state.ptr))
+            device.check(lib.pgx_adsr_gated(cout.ptr, b, cin.ptr, b, k, b, params.ptr, state.ptr, ws.ptr))
         got[:, pos:pos + b] = cout.to_host()
         pos += b
     bad = np.argwhere(got != want)
