@@ -160,38 +160,67 @@ k_conv_mfma(double *partial, const float *eP, const float *hp, int64_t L, int64_
         __syncthreads();
 
         // ---- MFMA over the chunk ----
+        // K-slabs are walked in groups of 4 (16 taps): within a group the e' residue pattern of a lane
+        // is loop invariant, so the per-slab address arithmetic collapses to one subtraction, and the
+        // operands of group g+1 are fetched from LDS while the 16 MFMAs of group g issue.
         floatx4 acc[kCvNT];
 #pragma unroll
         for (int t = 0; t < kCvNT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
         // local e' index (relative to 16*qbase) of tile (4*wave), q = 0, at j-local 0, kk of this lane
         const int vb = (int)((int64_t)256 * (kCvTiles * tg + kCvNT * wave) + Lm1 + 15 - k0 + fp - 16 * qbase) - kk;
-        const int abase = kk + p16;
-        int since_flush = 0;
-#pragma unroll 4
-        for (int s = 0; s < G::kSlabs; ++s) {
-            const int jl = 4 * s;
-            const float a = hs[jl + abase];
-            const int v = vb - jl;
-            const int addr = (v & 15) * G::kRowStride + (v >> 4) + p16;
+        int off[4];                       // es index of slab j of group 0 (per lane, loop invariant)
 #pragma unroll
-            for (int t = 0; t < kCvNT; ++t) {
-                const float b = es[addr + 16 * t];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-            }
-            if (++since_flush == kCvFlush) {
-                since_flush = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int vj = vb - 4 * j;
+            off[j] = (vj & 15) * G::kRowStride + (vj >> 4) + p16;
+        }
+        const float *ap = hs + kk + p16;  // A fragment of slab 0; +16 floats per group
+        constexpr int kGroups = G::kSlabs / 4;
+        static_assert(G::kSlabs % 4 == 0, "K-slabs per chunk must be a multiple of 4");
+
+        float a_cur[4], b_cur[4][kCvNT], a_nxt[4], b_nxt[4][kCvNT];
 #pragma unroll
-                for (int t = 0; t < kCvNT; ++t) {
+        for (int j = 0; j < 4; ++j) {
+            a_cur[j] = ap[4 * j];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dacc[t][r] += (double)acc[t][r];
-                    acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < kCvNT; ++t) b_cur[j][t] = es[off[j] + 16 * t];
+        }
+        for (int g0 = 0; g0 < kGroups; g0 += kCvFlush / 4) {
+            const int g1 = (g0 + kCvFlush / 4 < kGroups) ? g0 + kCvFlush / 4 : kGroups;
+            for (int g = g0; g < g1; ++g) {
+                const bool more = (g + 1 < kGroups);
+                if (more) {
+                    ap += 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a_nxt[j] = ap[4 * j];
+                        const float *bp = es + (off[j] - (g + 1));          // v drops by 16 per group: Q - 1
+#pragma unroll
+                        for (int t = 0; t < kCvNT; ++t) b_nxt[j][t] = bp[16 * t];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < kCvNT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j], b_cur[j][t], acc[t], 0, 0, 0);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a_cur[j] = a_nxt[j];
+#pragma unroll
+                        for (int t = 0; t < kCvNT; ++t) b_cur[j][t] = b_nxt[j][t];
+                    }
                 }
             }
+            // fold the f32 accumulators into float64 every kCvFlush slabs (1024 taps)
+#pragma unroll
+            for (int t = 0; t < kCvNT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dacc[t][r] += (double)acc[t][r];
+                acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
         }
-#pragma unroll
-        for (int t = 0; t < kCvNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dacc[t][r] += (double)acc[t][r];
         __syncthreads();       // LDS is overwritten by the next chunk
     }
 
