@@ -102,6 +102,10 @@ typedef struct {
 } pgx_sine_params;
 int pgx_sine_render(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                     int channels, double sample_rate, const pgx_sine_params *params);
+/* GainPE(SinePE(scalars), gain=<scalar>) in one launch: float32(float32(amp*sin) * float32 gain),
+ * the same two roundings as pgx_sine_render followed by pgx_gain_const (gain_pe.py:121-123). */
+int pgx_sine_gain_render(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
+                         int channels, double sample_rate, const pgx_sine_params *params, float gain);
 
 /* Stateful path: _compute_phase_stateful (sine_pe.py:177-232).  freq/amp/phase_mod are
  * optional per-sample float32 control streams (frames, 1); NULL -> the scalar in params.

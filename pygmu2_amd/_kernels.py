@@ -10,8 +10,14 @@ from . import device as _dev
 from .device import DeviceBuffer, check
 
 
+_LIB = None
+
+
 def lib():
-    return _dev.ensure_init()
+    global _LIB
+    if _LIB is None:
+        _LIB = _dev.ensure_init()
+    return _LIB
 
 
 def new_output(frames: int, channels: int) -> DeviceBuffer:

@@ -12,6 +12,8 @@ from .source_pe import SourcePE
 
 
 class ArrayPE(SourcePE):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, data, extend_mode: ExtendMode = ExtendMode.ZERO):
         arr = np.asarray(data, dtype=np.float32)
         if arr.ndim == 1:

@@ -8,6 +8,8 @@ from .source_pe import SourcePE
 
 
 class ConstantPE(SourcePE):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, value: float, channels: int = 1):
         self._value = value
         self._channels = channels

@@ -104,8 +104,11 @@ __global__ void __launch_bounds__(kBlock) k_extract_channel(float *out, const fl
 
 // ------------------------------------------------------------------------------ SinePE (pure)
 // sine_pe.py:159-175 + :141: phase = phase0 + w * (double(n)/sr); y = amp * sin(phase).
+// post_gain: GainPE(SinePE, gain=<scalar>) fused -- the sine is rounded to float32 first and THEN
+// multiplied by the float32 gain, i.e. the two roundings of the separate PEs (gain_pe.py:121-123).
 __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride, int64_t start, int64_t n,
-                                                 int channels, double sr, const pgx_sine_params *params) {
+                                                 int channels, double sr, const pgx_sine_params *params,
+                                                 int has_gain, float post_gain) {
     const pgx_sine_params p = params[blockIdx.y];
     float *o = out + (int64_t)blockIdx.y * out_stride;
     const bool aligned = is_aligned16(o);
@@ -122,6 +125,7 @@ __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride,
                 double t = (double)(start + f) / sr;
                 double ph = p.phase0 + p.w * t;
                 prev_v = (float)(p.amp * pgx::pgx_sin(ph));
+                if (has_gain) prev_v = prev_v * post_gain;
                 prev_f = f;
             }
             v[j] = prev_v;
@@ -400,8 +404,22 @@ int pgx_sine_render(float *out, int64_t out_stride, int batch, int64_t start, in
     PGX_CHECK_ARG(batch <= 65535, "pgx_sine_render: batch too large");
     dim3 grid(pgx::grid_for(pgx::ceil_div(n * channels, kVec), kBlock), batch);
     hipLaunchKernelGGL(k_sine, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, start, n, channels,
-                       sample_rate, params);
+                       sample_rate, params, 0, 1.0f);
     PGX_LAUNCH_CHECK("k_sine");
+    return PGX_OK;
+}
+
+int pgx_sine_gain_render(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int channels,
+                         double sample_rate, const pgx_sine_params *params, float gain) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && channels >= 1 && sample_rate > 0, "pgx_sine_gain_render: bad argument");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_sine_gain_render: out_stride too small");
+    PGX_CHECK_ARG(batch <= 65535, "pgx_sine_gain_render: batch too large");
+    dim3 grid(pgx::grid_for(pgx::ceil_div(n * channels, kVec), kBlock), batch);
+    hipLaunchKernelGGL(k_sine, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, start, n, channels,
+                       sample_rate, params, 1, gain);
+    PGX_LAUNCH_CHECK("k_sine<gain>");
     return PGX_OK;
 }
 

@@ -60,6 +60,7 @@ _SIGNATURES = [
     ("pgx_window_copy", _I, [_P, _L, _L, _I, _P, _L, _L, _I, _I]),
     ("pgx_extract_channel", _I, [_P, _P, _L, _I, _I]),
     ("pgx_sine_render", _I, [_P, _L, _I, _L, _L, _I, _D, _P]),
+    ("pgx_sine_gain_render", _I, [_P, _L, _I, _L, _L, _I, _D, _P, _F]),
     ("pgx_sine_stateful", _I, [_P, _L, _I, _D, _P, _P, _P, _P, _P]),
     ("pgx_gain_const", _I, [_P, _P, _L, _F]),
     ("pgx_gain_vec", _I, [_P, _P, _P, _L, _I, _I]),
@@ -231,6 +232,19 @@ class DeviceBuffer:
     def offset_ptr(self, n_elements: int) -> int:
         return self.ptr + int(n_elements) * self.dtype.itemsize
 
+    def rows(self, first: int, count: int) -> "DeviceBuffer":
+        """Non-owning view of `count` leading-dimension rows starting at `first` (keeps self alive)."""
+        view = object.__new__(DeviceBuffer)
+        row_elems = 1
+        for s in self.shape[1:]:
+            row_elems *= s
+        view.shape = (int(count),) + tuple(self.shape[1:])
+        view.dtype = self.dtype
+        view.nbytes = int(count) * row_elems * self.dtype.itemsize
+        view.ptr = self.ptr + int(first) * row_elems * self.dtype.itemsize
+        view._owner = self          # a DeviceBuffer here means "borrowed": never freed by the view
+        return view
+
     @property
     def __cuda_array_interface__(self):
         return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False),
@@ -238,7 +252,7 @@ class DeviceBuffer:
 
     def __del__(self):
         try:
-            if getattr(self, "_owner", False) and self.ptr and _lib is not None:
+            if getattr(self, "_owner", False) is True and self.ptr and _lib is not None:
                 _lib.pgx_free(self.ptr)
         except Exception:
             pass

@@ -8,6 +8,8 @@ from .source_pe import SourcePE
 
 
 class DiracPE(SourcePE):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, channels: int = 1):
         self._channels = channels
 

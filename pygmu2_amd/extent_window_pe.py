@@ -10,6 +10,8 @@ from .snippet import Snippet
 
 
 class _ExtentWindowPE(ProcessingElement):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, source: ProcessingElement, extent: Extent,
                  extend_mode: ExtendMode = ExtendMode.ZERO):
         self._source = source

@@ -12,6 +12,8 @@ from .snippet import Snippet
 
 
 class GainPE(ProcessingElement):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, source: ProcessingElement, gain=1.0):
         self._source = source
         self._gain = gain
@@ -34,6 +36,11 @@ class GainPE(ProcessingElement):
         return ext.intersection(self._gain.extent()) if self._gain_is_pe else ext
 
     def _render(self, start: int, duration: int) -> Snippet:
+        if not self._gain_is_pe and duration > 0:
+            fused = getattr(self._source, "_render_with_gain", None)
+            if fused is not None and self._source.is_pure():
+                # producer + constant gain in one launch (same float32 roundings as two launches)
+                return fused(start, duration, float(np.float32(self._gain)))
         src = self._source.render(start, duration)
         ch = src.channels
         out = new_output(duration, ch)

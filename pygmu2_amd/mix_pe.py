@@ -20,6 +20,8 @@ from .snippet import Snippet
 
 
 class MixPE(ProcessingElement):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, *inputs: ProcessingElement):
         if len(inputs) == 1 and isinstance(inputs[0], (list, tuple)):
             inputs = tuple(inputs[0])

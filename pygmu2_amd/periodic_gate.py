@@ -21,6 +21,8 @@ from .snippet import Snippet
 
 
 class PeriodicGate(GateSignal):
+    _READ_AHEAD_SAFE = True
+
     _TRUSTED_DOMAIN = True          # the kernel emits exactly 0.0f or 1.0f
 
     def __init__(self, frequency=1.0, duty_cycle=0.5, phase=0.0):

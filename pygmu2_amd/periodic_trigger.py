@@ -12,6 +12,8 @@ from .trigger_signal import TriggerSignal
 
 
 class PeriodicTrigger(TriggerSignal):
+    _READ_AHEAD_SAFE = True
+
     _TRUSTED_DOMAIN = True
 
     def __init__(self, hz: float, phase: float = 0.0, amplitude: int = 1):

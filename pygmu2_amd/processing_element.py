@@ -21,6 +21,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import device as _dev
+from . import read_ahead as _read_ahead
 from .config import get_sample_rate, handle_error
 from .diagnostics import is_enabled, pull_count_enabled, record_pull, record_timing, timing_enabled
 from .extent import Extent
@@ -30,6 +31,7 @@ from .snippet import Snippet
 class ProcessingElement(ABC):
     _sample_rate: int | None = None
     _cached_extent: Extent | None = None
+    _READ_AHEAD_SAFE = False      # see read_ahead.py: set by PEs whose frames depend on the index alone
 
     def __new__(cls, *args, **kwargs):
         rate = get_sample_rate()
@@ -73,6 +75,10 @@ class ProcessingElement(ABC):
             out = self._render(start, duration)
             record_timing(self, time.perf_counter_ns() - t0)
             return out
+        if duration <= _read_ahead.SMALL_BLOCK:
+            ahead = _read_ahead.render(self, start, duration)     # pure sub-graphs, sequential small pulls
+            if ahead is not None:
+                return ahead
         return self._render(start, duration)
 
     @abstractmethod
@@ -108,11 +114,13 @@ class ProcessingElement(ABC):
 
     # ------------------------------------------------------------------ lifecycle
     def on_start(self) -> None:
+        _read_ahead.forget(self)
         hook = getattr(self, "_on_start", None)
         if hook is not None:
             hook()
 
     def on_stop(self) -> None:
+        _read_ahead.forget(self)
         hook = getattr(self, "_on_stop", None)
         if hook is not None:
             hook()

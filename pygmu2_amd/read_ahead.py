@@ -1,0 +1,79 @@
+"""
+Read-ahead for small-block streaming of PURE sub-graphs.
+
+A 1024-frame block is ~4 kB: at that size a render is nothing but launch latency and Python
+overhead (the reference's own profile_biquad_vs_svfilter.py / AudioRenderer loops pull exactly
+such blocks).  A pure PE is a function of (start, duration) only, so when a pure sub-graph is
+pulled sequentially in small blocks the root of that sub-graph renders 64 blocks in ONE launch
+sequence and hands out row-views of the resident result.  The samples are the same samples: every
+kernel on these paths computes a frame from its absolute index alone (IdentityPE is excluded: its
+numpy `arange` fill rule depends on the block start for |index| >= 2^24).
+
+Scope: SinePE with scalar parameters, GainPE, MixPE, ConstantPE, DiracPE, ArrayPE, CropPE,
+PeriodicGate, PeriodicTrigger -- and only when every input is itself eligible.
+Disable with PYGMU_READ_AHEAD=0.
+"""
+
+from __future__ import annotations
+
+import os
+import threading
+
+SMALL_BLOCK = 4096          # requests up to this many frames are considered "small"
+AHEAD_BLOCKS = 64           # how many blocks one refill renders
+
+_tls = threading.local()
+_ENABLED = os.environ.get("PYGMU_READ_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")
+
+
+def enabled() -> bool:
+    return _ENABLED
+
+
+def set_enabled(flag: bool) -> None:
+    global _ENABLED
+    _ENABLED = bool(flag)
+
+
+def eligible(pe) -> bool:
+    """Pure, allow-listed, and all inputs eligible (cached on the instance; graphs are static)."""
+    cached = pe.__dict__.get("_ra_ok")
+    if cached is None:
+        cached = bool(getattr(pe, "_READ_AHEAD_SAFE", False)) and pe.is_pure() and all(
+            eligible(child) for child in pe.inputs())
+        pe.__dict__["_ra_ok"] = cached
+    return cached
+
+
+def render(pe, start: int, duration: int):
+    """Serve (start, duration) from the PE's resident window, refilling it when the pull is
+    sequential.  Returns None when the request should take the normal path."""
+    if not _ENABLED or duration > SMALL_BLOCK or getattr(_tls, "busy", False) or not eligible(pe):
+        return None
+    from .snippet import Snippet
+    st = pe.__dict__.get("_ra_state")
+    if st is not None:
+        w_start, w_snip, last_end = st
+        if start >= w_start and start + duration <= w_start + w_snip.duration and w_snip.on_device:
+            pe.__dict__["_ra_state"] = (w_start, w_snip, start + duration)
+            return Snippet(start, w_snip.dev.rows(start - w_start, duration))
+        sequential = (last_end == start)
+    else:
+        sequential = False
+    if not sequential:
+        # first pull / random access: render normally, remember where it ended
+        pe.__dict__["_ra_state"] = (start, Snippet.from_zeros(start, 0, 1), start + duration)
+        return None
+    _tls.busy = True
+    try:
+        big = pe._render(start, duration * AHEAD_BLOCKS)
+    finally:
+        _tls.busy = False
+    pe.__dict__["_ra_state"] = (start, big, start + duration)
+    if not big.on_device:
+        return Snippet(start, big.data[:duration])
+    return Snippet(start, big.dev.rows(0, duration))
+
+
+def forget(pe) -> None:
+    pe.__dict__.pop("_ra_state", None)

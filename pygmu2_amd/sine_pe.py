@@ -20,6 +20,8 @@ from .snippet import Snippet
 
 
 class SinePE(ProcessingElement):
+    _READ_AHEAD_SAFE = True
+
     def __init__(self, frequency=440.0, amplitude=1.0, phase=0.0, channels: int = 1):
         self._frequency = frequency
         self._amplitude = amplitude
@@ -59,17 +61,28 @@ class SinePE(ProcessingElement):
     _on_start = _reset_state
     _on_stop = _reset_state
 
+    def _pure_params(self) -> DeviceBuffer:
+        if self._params is None:
+            # same host arithmetic as the reference: (2.0 * pi) * f, left to right
+            w = 2.0 * np.pi * float(self._frequency)
+            self._params = _dev.upload_struct(_dev.SINE_PARAMS, w=w, amp=float(self._amplitude),
+                                              phase0=float(self._phase))
+        return self._params
+
+    def _render_with_gain(self, start: int, duration: int, gain32: float) -> Snippet:
+        """GainPE(self, gain=<scalar>) in one launch (pure path only); same roundings as two PEs."""
+        out = new_output(duration, self._channels)
+        check(lib().pgx_sine_gain_render(out.ptr, 0, 1, start, duration, self._channels,
+                                         float(self.sample_rate), self._pure_params().ptr, gain32),
+              "pgx_sine_gain_render")
+        return Snippet(start, out)
+
     def _render(self, start: int, duration: int) -> Snippet:
         out = new_output(duration, self._channels)
         L = lib()
         if not self._has_pe_inputs():
-            if self._params is None:
-                # same host arithmetic as the reference: (2.0 * pi) * f, left to right
-                w = 2.0 * np.pi * float(self._frequency)
-                self._params = _dev.upload_struct(_dev.SINE_PARAMS, w=w, amp=float(self._amplitude),
-                                                  phase0=float(self._phase))
             check(L.pgx_sine_render(out.ptr, 0, 1, start, duration, self._channels,
-                                    float(self.sample_rate), self._params.ptr), "pgx_sine_render")
+                                    float(self.sample_rate), self._pure_params().ptr), "pgx_sine_render")
             return Snippet(start, out)
 
         f_s, f_buf = self._control_stream(self._frequency, start, duration)

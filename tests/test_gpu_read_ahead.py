@@ -1,0 +1,55 @@
+"""GPU: read-ahead of pure sub-graphs (pygmu2_amd/read_ahead.py) hands out exactly the samples a
+plain per-block render produces, for sequential, overlapping and random pulls."""
+
+import numpy as np
+import pytest
+
+import pygmu2_amd as pg
+from pygmu2_amd import read_ahead
+
+pytestmark = pytest.mark.gpu
+
+
+def _hello():
+    mix = pg.MixPE(pg.SinePE(440.0), pg.SinePE(550.0), pg.SinePE(660.0))
+    return pg.CropPE(pg.GainPE(mix, 0.3), 0, 8 * 44100)
+
+
+def _pull(pe, requests):
+    r = pg.NullRenderer(44100)
+    r.set_source(pe)
+    r.start()
+    out = [pe.render(s, n).data.copy() for s, n in requests]
+    r.stop()
+    return out
+
+
+@pytest.mark.parametrize("graph", ["c1", "hello"])
+def test_read_ahead_is_sample_identical(graph):
+    pg.set_sample_rate(44100)
+    make = (lambda: pg.GainPE(pg.SinePE(440.0, 1.0, 0.0, channels=2), gain=0.5)) if graph == "c1" else _hello
+    seq = [(i * 1024, 1024) for i in range(200)]
+    seq += [(204800, 17), (204817, 1000), (100, 64), (164, 64), (228, 4096), (8 * 44100 - 100, 512)]
+    read_ahead.set_enabled(True)
+    try:
+        a = _pull(make(), seq)
+        pe = make()
+        assert read_ahead.eligible(pe)
+        read_ahead.set_enabled(False)
+        b = _pull(make(), seq)
+    finally:
+        read_ahead.set_enabled(True)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+
+
+def test_read_ahead_skips_stateful_and_index_quirk_graphs():
+    pg.set_sample_rate(44100)
+    assert not read_ahead.eligible(pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707))
+    assert not read_ahead.eligible(pg.GainPE(pg.IdentityPE(), 2.0))
+    assert not read_ahead.eligible(pg.SinePE(frequency=pg.SinePE(5.0)))
+    # stateful chain streamed in small blocks still matches one big render within the budget
+    a = pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707)
+    parts = _pull(a, [(i * 512, 512) for i in range(40)])
+    whole = pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707).render(0, 40 * 512).data
+    assert np.max(np.abs(np.concatenate(parts) - whole)) <= 1e-6 * np.max(np.abs(whole))
