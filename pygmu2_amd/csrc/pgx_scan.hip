@@ -334,6 +334,13 @@ k_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_strid
         if (tid == 0) {
             agg[((int64_t)chain * nseg + seg) * 2 + 0] = carry.x;
             agg[((int64_t)chain * nseg + seg) * 2 + 1] = carry.y;
+            if (seg == 0) {
+                // snapshot of the carried state for the apply launch (whose last segment overwrites
+                // `state` while other segments may not have started yet)
+                double *snap = const_cast<double *>(state_snapshot);
+                snap[chain * 2 + 0] = state[chain * 2 + 0];
+                snap[chain * 2 + 1] = state[chain * 2 + 1];
+            }
         }
     } else if (have_final) {
         state[chain * 2 + 0] = final_state.x;
@@ -771,8 +778,6 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
         PGX_CHECK_ARG(workspace != nullptr, "pgx_biquad_const: workspace required for this size");
         double *snap = (double *)workspace;
         double *agg = snap + (size_t)chains * 2;
-        PGX_HIP(hipMemcpyAsync(snap, state, (size_t)chains * 2 * sizeof(double), hipMemcpyDeviceToDevice,
-                               pgx::stream()));
         hipLaunchKernelGGL(k_biquad_const<0>, grid, dim3(kBlock), 0, pgx::stream(), out, out_stride, in,
                            in_stride, n, channels, coef, state, (const double *)snap, agg, p.seg_tiles, p.nseg);
         PGX_LAUNCH_CHECK("k_biquad_const<reduce>");
