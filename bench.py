@@ -122,6 +122,15 @@ def bench_c2(pg, dist, steps, warmup, frames=1_000_000):
     return dt, frames
 
 
+def pmc_traffic(entry: str, frames: int):
+    """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(entry, {}).get(str(frames))
+    except (OSError, ValueError):
+        return None
+
+
 def biquad_kernel_roofline(pg, frames, launches):
     """HIP-event timing of the pgx_biquad_const entry point alone (input resident in HBM)."""
     from pygmu2_amd import device
@@ -150,7 +159,7 @@ def biquad_kernel_roofline(pg, frames, launches):
     algo_bytes = 8.0 * frames                      # read f32 + write f32 per frame
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("pgx_biquad_const", frames),
             "kernel": "k_biquad_const<reduce>+<apply> (pgx_biquad_const)",
             "frames_per_launch": frames, "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(ms, 6)}
@@ -161,7 +170,7 @@ def cpu_c2(frames, budget_s=12.0):
     from oracle import pe_oracle as O
     st = O.biquad_state(1)
     t_all, reps, pos = 0.0, 0, 0
-    while t_all < budget_s and reps < 200:
+    while t_all < budget_s and reps < 5000:
         t0 = time.perf_counter()
         x = O.sine_pure(pos, frames, 440.0, sr=44100)
         O.biquad_const(st, x, 1000.0, 0.707, "lowpass", 0.0, 44100)
