@@ -172,6 +172,36 @@ int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, dou
                        const pgx_biquad_var_params *params, const float *freq, const float *q,
                        double gain_a, double gain_sqrt_a, double *state /* [channels][4] */);
 
+/* ------------------------------------------------------------------ SVFilterPE / EnvelopePE / TransformPE
+ * (the PEs of benchmarks/profile_biquad_vs_svfilter.py)
+ * SVFilterPE: _svf_coefficients_batch_numba + _svf_varying_numba (svfilter_pe.py:65-205).
+ * params reuses pgx_biquad_var_params; mode: 0 lowpass,1 highpass,2 bandpass,3 notch,4 peaking,
+ * 5 lowshelf,6 highshelf.  gain_a = 10^(gain_db/40).  state[channel] = {s0, s1}. */
+int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_rate,
+            const pgx_biquad_var_params *params, const float *freq, const float *q, double gain_a,
+            const double *coef /* NULL, or {a00,a01,a10,a11,b0,b1,c0,c1,c2} evaluated by the host
+                                  (constant frequency and q; freq and q must then be NULL) */,
+            double *state /* [channels][2] */);
+
+/* EnvelopePE._render (envelope_pe.py:128-206) on the (already look-ahead shifted) source block.
+ * one_pole != 0: attack == release, scipy lfilter one-pole as a scan; else the attack/release
+ * switch of _envelope_ar_numba (envelope_pe.py:259-271), one lane per channel.
+ * rms_window > 0 selects DetectionMode.RMS (block-local uniform_filter1d, mode='nearest').
+ * state[channel] = envelope; scratch: n*channels doubles. */
+int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
+                 double release_coeff, int one_pole, int rms_window, double *state, double *scratch);
+
+/* TransformPE._render (transform_pe.py:96-152) for chains of named element-wise operations:
+ * float32 -> float64 -> ops in order -> float32.
+ * code: 0 affine (p1 + p0*x), 1 clip [p0,p1], 2 sqrt, 3 square, 4 abs, 5 tanh, 6 one_minus. */
+typedef struct {
+    int32_t code;
+    int32_t pad;
+    double p0;
+    double p1;
+} pgx_transform_op;
+int pgx_transform(float *out, const float *in, int64_t n_elems, const pgx_transform_op *ops, int nops);
+
 /* ------------------------------------------------------------------ BlitSawPE / SuperSawPE
  * BlitSawPE._render (blit_saw_pe.py:150-264): phase cumsum -> mod 1 -> Dirichlet kernel
  * -> leaky integrator -> *2 *amp -> float32.  state[instance] = {phase, integrator}.

@@ -57,7 +57,8 @@ def load_reference():
     for name in ("config", "extent", "snippet", "null_renderer", "constant_pe", "identity_pe",
                  "dirac_pe", "array_pe", "crop_pe", "sine_pe", "gain_pe", "mix_pe", "biquad_pe",
                  "blit_saw_pe", "super_saw_pe", "ladder_pe", "comb_pe", "adsr_pe",
-                 "periodic_gate", "periodic_trigger", "convolve_pe"):
+                 "periodic_gate", "periodic_trigger", "convolve_pe", "svfilter_pe", "envelope_pe",
+                 "transform_pe"):
         mods[name] = importlib.import_module(f"pygmu2.{name}")
     return mods
 
@@ -120,7 +121,42 @@ def build(spec, M):
         return M["periodic_trigger"].PeriodicTrigger(**kw)
     if kind == "ConvolvePE":
         return M["convolve_pe"].ConvolvePE(kw.pop("src"), kw.pop("fir"), **kw)
+    if kind == "SVFilterPE":
+        if "mode" in kw:
+            kw["mode"] = M["biquad_pe"].BiquadMode(kw["mode"])
+        return M["svfilter_pe"].SVFilterPE(**kw)
+    if kind == "EnvelopePE":
+        if "mode" in kw:
+            kw["mode"] = M["envelope_pe"].DetectionMode(kw["mode"])
+        return M["envelope_pe"].EnvelopePE(**kw)
+    if kind == "TransformPE":
+        return M["transform_pe"].TransformPE(kw["source"], func=numpy_func(kw["ops"]), name="ops")
     raise KeyError(kind)
+
+
+def numpy_func(ops):
+    """The plain numpy callable a reference user would pass to TransformPE for this op list."""
+    def f(v):
+        for op in ops:
+            name = op[0]
+            if name == "affine":
+                v = op[2] + op[1] * v
+            elif name == "clip":
+                v = np.clip(v, op[1], op[2])
+            elif name == "sqrt":
+                v = v ** 0.5
+            elif name == "square":
+                v = v ** 2
+            elif name == "abs":
+                v = np.abs(v)
+            elif name == "tanh":
+                v = np.tanh(v)
+            elif name == "one_minus":
+                v = 1.0 - v
+            else:
+                raise KeyError(name)
+        return v
+    return f
 
 
 def has_kind(spec, kind):

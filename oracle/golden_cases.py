@@ -314,6 +314,52 @@ def cases():
     add("c5_mix4", 48000, S("MixPE", inputs=[c5_voice(i) for i in (0, 171, 342, 511)]),
         blocks_contig(0, [8192, 8192]))
 
+    # ---------------------------------------------------------------- SVFilter / Envelope / Transform
+    for mode in ("lowpass", "highpass", "bandpass", "notch", "peaking", "lowshelf", "highshelf"):
+        add(f"svf_const_{mode}", 44100,
+            S("SVFilterPE", source=S("ArrayPE", data=noise2), frequency=1500.0, q=1.3, mode=mode, gain_db=4.5),
+            blocks_contig(0, [1024, 1024, 17, 23, 19, 41, 7, 93, 2000]))
+    add("svf_var_freq", 44100,
+        S("SVFilterPE", source=S("SinePE", frequency=440.0),
+          frequency=S("SinePE", frequency=5.0, amplitude=500.0), q=0.707, mode="lowpass"),
+        blocks_contig(0, [4096, 1024, 17, 2, 2000]))
+    add("svf_var_peaking_q", 48000,
+        S("SVFilterPE", source=S("ArrayPE", data=noise2), frequency=fsweep,
+          q=S("MixPE", inputs=[S("ConstantPE", value=2.0), S("SinePE", frequency=1.0, amplitude=1.5)]),
+          mode="peaking", gain_db=-6.0),
+        blocks_contig(0, [3000, 3000]))
+    add("svf_var_highshelf", 48000,
+        S("SVFilterPE", source=S("ArrayPE", data=noise2), frequency=fsweep, q=0.9, mode="highshelf", gain_db=9.0),
+        blocks_contig(0, [3000, 3000]))
+    burst = {"rng": 31, "n": 9000, "ch": 2, "scale": 0.6, "decay": 1500.0}
+    add("envelope_peak", 44100,
+        S("EnvelopePE", source=S("ArrayPE", data=burst), attack=0.005, release=0.05, mode="peak"),
+        blocks_contig(0, [1024, 1024, 17, 4000, 4000]))
+    add("envelope_rms_lookahead", 44100,
+        S("EnvelopePE", source=S("ArrayPE", data=burst), attack=0.01, release=0.1, lookahead=0.004, mode="rms"),
+        blocks_contig(0, [2048, 2048, 93, 3000]))
+    add("envelope_equal_times", 48000,
+        S("EnvelopePE", source=S("SinePE", frequency=220.0, amplitude=0.8), attack=0.02, release=0.02),
+        blocks_contig(0, [4096, 4096]))
+    add("envelope_instant_attack", 48000,
+        S("EnvelopePE", source=S("ArrayPE", data=burst), attack=0.0, release=0.03),
+        blocks_contig(0, [3000, 3000]))
+    env_to_freq = [["clip", 0.0, 1.0], ["sqrt"], ["affine", 2900.0, 100.0]]
+    add("transform_chain", 44100,
+        S("TransformPE", source=S("ArrayPE", data={"rng": 32, "n": 4000, "ch": 2, "scale": 0.7}), ops=env_to_freq),
+        [[0, 4000]])
+    add("transform_tanh_abs", 44100,
+        S("TransformPE", source=S("SinePE", frequency=330.0, amplitude=3.0), ops=[["tanh"], ["abs"], ["one_minus"], ["square"]]),
+        [[0, 4096]])
+
+    def autowah(filter_kind):
+        src = S("SinePE", frequency=220.0, amplitude=0.8)
+        env = S("EnvelopePE", source=src, attack=0.005, release=0.05, mode="peak")
+        ctl = S("TransformPE", source=env, ops=env_to_freq)
+        return S("GainPE", source=S(filter_kind, source=src, frequency=ctl, q=10.0, mode="lowpass"), gain=1.0)
+    add("autowah_biquad", 44100, autowah("BiquadPE"), blocks_contig(0, [1024] * 8))
+    add("autowah_svf", 44100, autowah("SVFilterPE"), blocks_contig(0, [1024] * 8))
+
     # ---------------------------------------------------------------- Convolve
     add("conv_kat", 10000,
         S("ConvolvePE", src=S("ArrayPE", data={"values": [1.0, 2.0, 3.0, 4.0]}),

@@ -89,8 +89,10 @@ class Node:
                                                    kw.get("randomize_phase", True), kw.get("seed"))
             r, g, p = self._ss_proto
             self.state = {"ratios": r, "gains": g, "osc": [O.blitsaw_state(x) for x in p]}
-        elif k in ("BiquadPE", "LadderPE", "CombPE"):
+        elif k in ("BiquadPE", "LadderPE", "CombPE", "SVFilterPE"):
             self.state = None          # lazily sized by channel count
+        elif k == "EnvelopePE":
+            self.state = O.envelope_state()
         elif k in ("AdsrGatedPE", "AdsrTriggeredPE"):
             self.state = O.adsr_state()
         elif k == "ConvolvePE":
@@ -133,7 +135,7 @@ class Node:
             if "gain" in self.sub:
                 ext = _isect(ext, self.sub["gain"].extent())
             return ext
-        if k in ("BiquadPE", "CombPE"):
+        if k in ("BiquadPE", "CombPE", "SVFilterPE"):
             ext = self.sub["source"].extent()
             for name in ("frequency", "q", "feedback"):
                 if name in self.sub:
@@ -214,6 +216,20 @@ class Node:
             if "frequency" in self.sub or "q" in self.sub:
                 return O.biquad_varying(self.state, x, f, q, mode, gdb, sr)
             return O.biquad_const(self.state, x, f, q, mode, gdb, sr)
+        if k == "SVFilterPE":
+            x = self.sub["source"].render(start, n)
+            if self.state is None or self.state["s"].shape[1] != x.shape[1]:
+                self.state = O.svf_state(x.shape[1])
+            return O.svf(self.state, x, self._param("frequency", start, n), self._param("q", start, n),
+                         kw.get("mode", "lowpass"), kw.get("gain_db", 0.0), sr)
+        if k == "EnvelopePE":
+            attack = max(0.0, kw.get("attack", 0.01))
+            look = int(max(0.0, min(kw.get("lookahead", 0.0), attack)) * sr)
+            x = self.sub["source"].render(start + look, n)
+            return O.envelope(self.state, x, kw.get("attack", 0.01), kw.get("release", 0.1),
+                              kw.get("mode", "peak"), sr)
+        if k == "TransformPE":
+            return O.transform(self.sub["source"].render(start, n), kw["ops"])
         if k == "BlitSawPE":
             return O.blitsaw(self.state, start, n, self._param("frequency", start, n),
                              self._param("amplitude", start, n, 1.0), self._param("m", start, n, None),

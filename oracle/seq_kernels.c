@@ -278,3 +278,49 @@ void orc_adsr_triggered(const float *trig, float *out, int64_t start, int64_t n,
     st[1] = env;
     st[2] = (double)sustain_ends_at;
 }
+
+/* ---------------------------------------------------------------------------
+ * State variable filter, per-sample (A, B, C).  Follows svfilter_pe.py:65-90
+ * (_svf_varying_numba; the constant kernel :41-62 is the same loop with one set).
+ * A_arr (n,2,2), B_arr (n,2), C_arr (n,3) row-major; stride 0 -> constant set.
+ * state is (2, c) row-major, updated in place.
+ */
+void orc_svf(const double *x, double *y, int64_t n, int c,
+             const double *A_arr, const double *B_arr, const double *C_arr, int varying,
+             double *state)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const double *A = A_arr + (varying ? i * 4 : 0);
+        const double *B = B_arr + (varying ? i * 2 : 0);
+        const double *C = C_arr + (varying ? i * 3 : 0);
+        double a00 = A[0], a01 = A[1], a10 = A[2], a11 = A[3];
+        double b0 = B[0], b1 = B[1];
+        double c0 = C[0], c1 = C[1], c2 = C[2];
+        for (int ch = 0; ch < c; ++ch) {
+            double xn = x[i * c + ch];
+            double y0 = state[ch], y1 = state[c + ch];
+            y[i * c + ch] = c0 * xn + c1 * y0 + c2 * y1;
+            state[ch] = b0 * xn + a00 * y0 + a01 * y1;
+            state[c + ch] = b1 * xn + a10 * y0 + a11 * y1;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * Attack/release envelope follower.  Follows envelope_pe.py:259-271
+ * (_envelope_ar_numba).  env is (c,), updated in place.
+ */
+void orc_envelope_ar(const double *x, double *out, int64_t n, int c,
+                     double attack_coeff, double release_coeff, double *env)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        for (int ch = 0; ch < c; ++ch) {
+            double target = x[i * c + ch];
+            double e = env[ch];
+            if (target > e) e = e + attack_coeff * (target - e);
+            else e = e + release_coeff * (target - e);
+            env[ch] = e;
+            out[i * c + ch] = e;
+        }
+    }
+}

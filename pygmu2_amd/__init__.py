@@ -5,7 +5,7 @@ Same public names as the reference package for the accelerated hot path:
 ProcessingElement / SourcePE / Snippet / Extent / Renderer / NullRenderer and the PEs
 SinePE, BlitSawPE, SuperSawPE, BiquadPE, LadderPE, CombPE, MixPE, GainPE, ConvolvePE,
 AdsrGatedPE, AdsrTriggeredPE, PeriodicGate, PeriodicTrigger, ConstantPE, ArrayPE,
-DiracPE, IdentityPE, CachePE, CropPE.  Snippet payloads live in HBM; all DSP runs in
+DiracPE, IdentityPE, CachePE, CropPE, SVFilterPE, EnvelopePE, TransformPE.  Snippet payloads live in HBM; all DSP runs in
 hand-written HIP kernels for gfx950 behind the C ABI of include/pygmu_hip.h.
 """
 
@@ -37,6 +37,10 @@ from .periodic_gate import PeriodicGate
 from .periodic_trigger import PeriodicTrigger
 from .adsr_pe import AdsrGatedPE, AdsrTriggeredPE
 from .convolve_pe import ConvolvePE
+from .svfilter_pe import SVFilterPE
+from .envelope_pe import DetectionMode, EnvelopePE
+from .transform_pe import TransformPE
+from . import transforms
 from . import device, diagnostics
 
 __all__ = [
@@ -45,5 +49,6 @@ __all__ = [
     "Renderer", "NullRenderer", "GateSignal", "TriggerSignal", "ConstantPE", "IdentityPE", "DiracPE",
     "ArrayPE", "CachePE", "CropPE", "SinePE", "GainPE", "MixPE", "BiquadMode", "BiquadPE", "BlitSawPE",
     "SuperSawPE", "LadderMode", "LadderPE", "CombPE", "PeriodicGate", "PeriodicTrigger", "AdsrGatedPE",
-    "AdsrTriggeredPE", "ConvolvePE", "device", "diagnostics",
+    "AdsrTriggeredPE", "ConvolvePE", "SVFilterPE", "DetectionMode", "EnvelopePE", "TransformPE",
+    "transforms", "device", "diagnostics",
 ]

@@ -750,6 +750,296 @@ k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr
     }
 }
 
+// ================================================================================================
+// SVFilterPE (svfilter_pe.py:41-205, 404-500): trapezoidal state variable filter,
+//   out = c0*x + c1*s0 + c2*s1;   s' = B*x + A*s   with a full (possibly per-sample) 2x2 A.
+// One workgroup per channel chain, time-varying 2x2 affine scan like the varying biquad.
+// ================================================================================================
+constexpr int kSvT = 4;
+constexpr int kSvTile = kBlock * kSvT;
+
+struct SvCoef {
+    double a00, a01, a10, a11, b0, b1, c0, c1, c2;
+};
+
+// svfilter_pe.py:120-205, per-sample scalar arithmetic in the reference's order.
+__device__ __forceinline__ SvCoef svf_coef(int mode, double freq, double q, double a_lin, double sr) {
+    double f_norm = freq / sr;
+    if (f_norm < 1e-6) f_norm = 1e-6;
+    if (f_norm > 0.5) f_norm = 0.5;
+    double res;
+    if (mode == 4) {                                   // peaking ("bell")
+        double qc = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
+        const double k_bell = 1.0 / (qc * a_lin);
+        res = 1.0 - 0.5 * k_bell;
+    } else {
+        double qc = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
+        res = 1.0 - 0.5 / qc;
+    }
+    if (res < 0.0) res = 0.0;
+    if (res > 0.999) res = 0.999;
+    const double k = 2.0 - 2.0 * res;
+    double sn, cs;
+    pgx::pgx_sincos(kPi * f_norm, sn, cs);
+    double g = sn / cs;                                // tan(pi * f_norm)
+    double shelf_a = 1.0;
+    if (mode == 5) shelf_a = 1.0 / sqrt(a_lin);
+    else if (mode == 6) shelf_a = sqrt(a_lin);
+    g = g * shelf_a;
+    const double a1 = 1.0 / (1.0 + g * (g + k));
+    const double a2 = g * a1;
+    const double a3 = g * a2;
+    SvCoef c;
+    c.a00 = 2.0 * a1 - 1.0;
+    c.a01 = -2.0 * a2;
+    c.a10 = 2.0 * a2;
+    c.a11 = 1.0 - 2.0 * a3;
+    c.b0 = 2.0 * a2;
+    c.b1 = 2.0 * a3;
+    double m0, m1, m2;
+    switch (mode) {
+    case 0: m0 = 0.0; m1 = 0.0; m2 = 1.0; break;
+    case 1: m0 = 1.0; m1 = -k; m2 = -1.0; break;
+    case 2: m0 = 0.0; m1 = 1.0; m2 = 0.0; break;
+    case 3: m0 = 1.0; m1 = -k; m2 = 0.0; break;
+    case 4: m0 = 1.0; m1 = k * (a_lin * a_lin - 1.0); m2 = 0.0; break;
+    case 5: m0 = 1.0; m1 = k * (a_lin - 1.0); m2 = a_lin * a_lin - 1.0; break;
+    default: {
+        const double A2 = a_lin * a_lin;
+        m0 = A2; m1 = k * (a_lin - A2); m2 = 1.0 - A2;
+    } break;
+    }
+    c.c0 = m0 * 1.0 + m1 * a2 + m2 * a3;
+    c.c1 = m1 * a1 + m2 * a2;
+    c.c2 = -m1 * a2 + m2 * (1.0 - a3);
+    return c;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx_biquad_var_params *params,
+      const float *freq, const float *qs, double a_lin, const double *coef, double *state) {
+    __shared__ BvShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = blockIdx.x;
+    const pgx_biquad_var_params p = params[0];
+    double *st = state + ch * 2;
+    V2 carry{st[0], st[1]};
+    V2 final_s{0.0, 0.0};
+    bool have_final = false;
+    const bool varying = (freq != nullptr) || (qs != nullptr);
+    SvCoef cconst;
+    if (coef) {                                          // host-evaluated constant coefficients
+        cconst = SvCoef{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
+    } else {
+        cconst = svf_coef(p.mode, p.freq, p.q, a_lin, sr);
+    }
+
+    for (int64_t base = 0; base < n; base += kSvTile) {
+        const int64_t f0 = base + (int64_t)tid * kSvT;
+        SvCoef cf[kSvT];
+        double xs[kSvT];
+        M2 cm = m_identity();
+        V2 cv{0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < kSvT; ++j) {
+            const bool live = (f0 + j < n);
+            xs[j] = live ? (double)in[(f0 + j) * channels + ch] : 0.0;
+            if (varying) {
+                double f = p.freq, q = p.q;
+                if (freq) f = live ? (double)freq[f0 + j] : 1000.0;
+                if (qs) q = live ? (double)qs[f0 + j] : 1.0;
+                cf[j] = svf_coef(p.mode, f, q, a_lin, sr);
+            } else {
+                cf[j] = cconst;
+            }
+            if (live) {                                      // compose s' = A s + B x
+                const M2 A{cf[j].a00, cf[j].a01, cf[j].a10, cf[j].a11};
+                const V2 bx{cf[j].b0 * xs[j], cf[j].b1 * xs[j]};
+                cv = vadd(mv(A, cv), bx);
+                cm = mm(A, cm);
+            }
+        }
+        M2 im = cm;
+        V2 iv = cv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            M2 om = shfl_up_m2(im, 1 << k);
+            V2 ov = shfl_up_v2(iv, 1 << k);
+            if (lane >= (1 << k)) {
+                iv = vadd(mv(im, ov), iv);
+                im = mm(im, om);
+            }
+        }
+        if (lane == 63) {
+            sh.wm[wave] = im;
+            sh.wv[wave] = iv;
+        }
+        __syncthreads();
+        V2 cw = carry, cn = carry;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            M2 tm = sh.wm[w];
+            V2 tv = sh.wv[w];
+            if (w < wave) cw = vadd(mv(tm, cw), tv);
+            cn = vadd(mv(tm, cn), tv);
+        }
+        __syncthreads();
+        carry = cn;
+        M2 em = shfl_up_m2(im, 1);
+        V2 ev = shfl_up_v2(iv, 1);
+        V2 s = cw;
+        if (lane > 0) s = vadd(mv(em, cw), ev);
+
+        float yf[kSvT];
+#pragma unroll
+        for (int j = 0; j < kSvT; ++j) {
+            const double xn = xs[j];
+            const double y = cf[j].c0 * xn + cf[j].c1 * s.x + cf[j].c2 * s.y;      // svfilter_pe.py:58,86
+            yf[j] = (float)y;
+            if (f0 + j < n) {
+                const double n0 = cf[j].b0 * xn + cf[j].a00 * s.x + cf[j].a01 * s.y;
+                const double n1 = cf[j].b1 * xn + cf[j].a10 * s.x + cf[j].a11 * s.y;
+                s.x = n0;
+                s.y = n1;
+            }
+            if (f0 + j == n - 1) {
+                final_s = s;
+                have_final = true;
+            }
+        }
+        store_frames<kSvT>(out, f0, n, channels, ch, yf);
+    }
+    if (have_final) {
+        st[0] = final_s.x;
+        st[1] = final_s.y;
+    }
+}
+
+// ================================================================================================
+// EnvelopePE (envelope_pe.py:128-271)
+// ================================================================================================
+// Detector: |x| (peak) or the block-local centred running RMS of scipy.ndimage.uniform_filter1d(x^2,
+// size=window, mode='nearest') (envelope_pe.py:208-225).  Output float64 (frames, channels).
+__global__ void __launch_bounds__(kBlock)
+k_env_detect(double *det, const float *in, int64_t n, int channels, int rms_window) {
+    const int64_t total = n * channels;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / channels;
+        const int c = (int)(e - i * channels);
+        if (rms_window <= 0) {
+            det[e] = fabs((double)in[e]);
+        } else {
+            // window [i - size/2, i - size/2 + size) with indices clamped to the block ('nearest')
+            const int64_t lo = i - rms_window / 2;
+            double acc = 0.0;
+            for (int w = 0; w < rms_window; ++w) {
+                int64_t j = lo + w;
+                j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+                const double v = fabs((double)in[j * channels + c]);
+                acc += v * v;
+            }
+            det[e] = sqrt(acc / (double)rms_window);
+        }
+    }
+}
+
+constexpr int kEnvT = 8;
+constexpr int kEnvTile = kBlock * kEnvT;
+
+// attack == release (envelope_pe.py:167-180): one-pole lfilter  y = z + c*x;  z = (1-c)*y.
+__global__ void __launch_bounds__(kBlock)
+k_env_onepole(float *out, const double *det, int64_t n, int channels, double coeff, double *state) {
+    __shared__ double lds[kWaves];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ch = blockIdx.x;
+    const double lam = 1.0 - coeff;
+    double lamp[6], lam_wave, lam_lane = 1.0;
+    {
+        double l = lam;
+#pragma unroll
+        for (int s = 1; s < kEnvT; s <<= 1) l = l * l;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            lamp[k] = l;
+            if (lane & (1 << k)) lam_lane = lam_lane * l;
+            l = l * l;
+        }
+        lam_wave = l;
+    }
+    double carry = state[ch];
+    double final_y = 0.0;
+    bool have_final = false;
+    for (int64_t base = 0; base < n; base += kEnvTile) {
+        const int64_t f0 = base + (int64_t)tid * kEnvT;
+        double xs[kEnvT];
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < kEnvT; ++j) {
+            xs[j] = (f0 + j < n) ? det[(f0 + j) * channels + ch] : 0.0;
+            // dead samples must act as the identity map, so the zero-state response only folds live ones
+            if (f0 + j < n) e = lam * e + coeff * xs[j];
+            else e = lam * e;
+        }
+        double y = block_scan_scalar_affine(e, lamp, lam_wave, lam_lane, lds, carry);
+        float yf[kEnvT];
+#pragma unroll
+        for (int j = 0; j < kEnvT; ++j) {
+            const double z = lam * y;
+            const double yn = z + coeff * xs[j];
+            yf[j] = (float)yn;
+            if (f0 + j < n) y = yn;
+            if (f0 + j == n - 1) {
+                final_y = yn;
+                have_final = true;
+            }
+        }
+        store_frames<kEnvT>(out, f0, n, channels, ch, yf);
+    }
+    if (have_final) state[ch] = final_y;
+}
+
+// attack != release (envelope_pe.py:259-271): data-dependent switch -> one lane per channel.
+__global__ void __launch_bounds__(64)
+k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_coeff, double release_coeff,
+         double *state) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= channels) return;
+    double e = state[ch];
+    for (int64_t i = 0; i < n; ++i) {
+        const double target = det[i * channels + ch];
+        if (target > e) e = e + attack_coeff * (target - e);
+        else e = e + release_coeff * (target - e);
+        out[i * channels + ch] = (float)e;
+    }
+    state[ch] = e;
+}
+
+// ================================================================================================
+// TransformPE: chains of named element-wise float64 operations (pygmu2_amd/transforms.py)
+// ================================================================================================
+__global__ void __launch_bounds__(kBlock)
+k_transform(float *out, const float *in, int64_t n_elems, const pgx_transform_op *ops, int nops) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elems; e += stride) {
+        double v = (double)in[e];
+        for (int k = 0; k < nops; ++k) {
+            const pgx_transform_op op = ops[k];
+            switch (op.code) {
+            case 0: v = op.p1 + op.p0 * v; break;                              // affine: offset + scale*x
+            case 1: v = v < op.p0 ? op.p0 : (v > op.p1 ? op.p1 : v); break;    // clip (NaN passes through)
+            case 2: v = sqrt(v); break;                                        // x ** 0.5 (numpy -> sqrt)
+            case 3: v = v * v; break;                                          // x ** 2 (numpy -> square)
+            case 4: v = fabs(v); break;
+            case 5: v = tanh(v); break;
+            case 6: v = 1.0 - v; break;
+            default: break;
+            }
+        }
+        out[e] = (float)v;
+    }
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -835,6 +1125,50 @@ int pgx_sine_stateful(float *out, int64_t n, int channels, double sample_rate,
     hipLaunchKernelGGL(k_sine_stateful, dim3(1), dim3(kBlock), 0, pgx::stream(), out, n, channels, sample_rate,
                        params, freq, amp, phase_mod, state);
     PGX_LAUNCH_CHECK("k_sine_stateful");
+    return PGX_OK;
+}
+
+
+int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_rate,
+            const pgx_biquad_var_params *params, const float *freq, const float *q, double gain_a,
+            const double *coef, double *state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && params && state && channels >= 1 && sample_rate > 0, "pgx_svf: bad argument");
+    PGX_CHECK_ARG(!(coef && (freq || q)), "pgx_svf: constant coefficients exclude control streams");
+    hipLaunchKernelGGL(k_svf, dim3(channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels, sample_rate,
+                       params, freq, q, gain_a, coef, state);
+    PGX_LAUNCH_CHECK("k_svf");
+    return PGX_OK;
+}
+
+int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
+                 double release_coeff, int one_pole, int rms_window, double *state, double *scratch) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && state && scratch && channels >= 1, "pgx_envelope: bad argument");
+    hipLaunchKernelGGL(k_env_detect, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(),
+                       scratch, in, n, channels, rms_window);
+    PGX_LAUNCH_CHECK("k_env_detect");
+    if (one_pole) {
+        hipLaunchKernelGGL(k_env_onepole, dim3(channels), dim3(kBlock), 0, pgx::stream(), out,
+                           (const double *)scratch, n, channels, attack_coeff, state);
+        PGX_LAUNCH_CHECK("k_env_onepole");
+    } else {
+        hipLaunchKernelGGL(k_env_ar, dim3((channels + 63) / 64), dim3(64), 0, pgx::stream(), out,
+                           (const double *)scratch, n, channels, attack_coeff, release_coeff, state);
+        PGX_LAUNCH_CHECK("k_env_ar");
+    }
+    return PGX_OK;
+}
+
+int pgx_transform(float *out, const float *in, int64_t n_elems, const pgx_transform_op *ops, int nops) {
+    PGX_REQUIRE_INIT();
+    if (n_elems <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && (ops || nops == 0) && nops >= 0, "pgx_transform: bad argument");
+    hipLaunchKernelGGL(k_transform, dim3(pgx::grid_for(n_elems, kBlock)), dim3(kBlock), 0, pgx::stream(), out,
+                       in, n_elems, ops, nops);
+    PGX_LAUNCH_CHECK("k_transform");
     return PGX_OK;
 }
 

@@ -70,6 +70,9 @@ _SIGNATURES = [
     ("pgx_biquad_workspace_bytes", _Z, [_I, _L, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
+    ("pgx_svf", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _P, _P]),
+    ("pgx_envelope", _I, [_P, _P, _L, _I, _D, _D, _I, _I, _P, _P]),
+    ("pgx_transform", _I, [_P, _P, _L, _P, _I]),
     ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P]),
     ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
     ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P]),
@@ -95,6 +98,7 @@ BIQUAD_VAR_PARAMS = np.dtype([("freq", "<f8"), ("q", "<f8"), ("gain_db", "<f8"),
 BLITSAW_PARAMS = np.dtype([("freq", "<f8"), ("amp", "<f8"), ("leak", "<f8"), ("m", "<f8")])
 LADDER_PARAMS = np.dtype([("freq", "<f8"), ("resonance", "<f8"), ("drive", "<f8"),
                           ("passband_gain", "<f8"), ("oversample", "<i4"), ("mode", "<i4")])
+TRANSFORM_OP = np.dtype([("code", "<i4"), ("pad", "<i4"), ("p0", "<f8"), ("p1", "<f8")])
 GATE_PARAMS = np.dtype([("dt", "<f8"), ("phase", "<f8"), ("duty", "<f8")])
 ADSR_PARAMS = np.dtype([("attack_dvdt", "<f8"), ("decay_dvdt", "<f8"), ("release_dvdt", "<f8"),
                         ("sustain_level", "<f8"), ("sustain_samples", "<i8")])

@@ -1,0 +1,90 @@
+"""
+EnvelopePE: causal attack/release envelope follower with optional look-ahead
+(envelope_pe.py:19-271).
+
+The source is rendered `int(lookahead * sr)` samples ahead, rectified (PEAK) or reduced to
+a block-local running RMS (RMS) and smoothed:
+  * attack == release: a one-pole low-pass, run as a time-parallel scalar affine scan;
+  * otherwise: e += (target > e ? attack_coeff : release_coeff) * (target - e), which
+    switches on its own output and runs one lane per channel.
+The per-channel envelope lives in HBM and is zeroed by on_start / on_stop.
+"""
+
+from __future__ import annotations
+
+from enum import Enum
+
+import numpy as np
+
+from ._kernels import DeviceBuffer, check, lib, new_output
+from .extent import Extent
+from .processing_element import ProcessingElement
+from .snippet import Snippet
+
+
+class DetectionMode(Enum):
+    PEAK = "peak"
+    RMS = "rms"
+
+
+class EnvelopePE(ProcessingElement):
+    def __init__(self, source: ProcessingElement, attack: float = 0.01, release: float = 0.1,
+                 lookahead: float = 0.0, mode: DetectionMode = DetectionMode.PEAK):
+        self._source = source
+        self._attack = max(0.0, attack)
+        self._release = max(0.0, release)
+        self._lookahead = max(0.0, min(lookahead, self._attack))
+        self._mode = mode
+        self._state: DeviceBuffer | None = None
+        self._state_channels = 0
+        self._scratch_buf: DeviceBuffer | None = None
+
+    source = property(lambda self: self._source)
+    attack = property(lambda self: self._attack)
+    release = property(lambda self: self._release)
+    lookahead = property(lambda self: self._lookahead)
+    mode = property(lambda self: self._mode)
+
+    def inputs(self) -> list[ProcessingElement]:
+        return [self._source]
+
+    def is_pure(self) -> bool:
+        return False
+
+    def channel_count(self) -> int | None:
+        return self._source.channel_count()
+
+    def _compute_extent(self) -> Extent:
+        return self._source.extent()
+
+    def _reset_state(self) -> None:
+        if self._state is not None:
+            self._state.zero_()
+
+    _on_start = _reset_state
+    _on_stop = _reset_state
+
+    def _render(self, start: int, duration: int) -> Snippet:
+        sr = self.sample_rate
+        src = self._source.render(start + int(self._lookahead * sr), duration)
+        ch = src.channels
+        if self._state is None or self._state_channels != ch:
+            self._state = DeviceBuffer((ch,), np.float64, zero=True)
+            self._state_channels = ch
+        need = duration * ch
+        if self._scratch_buf is None or self._scratch_buf.nbytes < need * 8:
+            self._scratch_buf = DeviceBuffer((need,), np.float64)
+        # envelope_pe.py:153-158
+        attack_coeff = float(1.0 - np.exp(-1.0 / (self._attack * sr))) if self._attack > 0 else 1.0
+        release_coeff = float(1.0 - np.exp(-1.0 / (self._release * sr))) if self._release > 0 else 1.0
+        one_pole = self._attack == self._release and attack_coeff < 1.0
+        window = max(1, int(min(0.01, self._attack) * sr)) if self._mode == DetectionMode.RMS else 0
+        out = new_output(duration, ch)
+        check(lib().pgx_envelope(out.ptr, src.dev.ptr, duration, ch, attack_coeff, release_coeff,
+                                 1 if one_pole else 0, window, self._state.ptr, self._scratch_buf.ptr),
+              "pgx_envelope")
+        return Snippet(start, out)
+
+    def __repr__(self) -> str:
+        return (f"EnvelopePE(source={type(self._source).__name__}, attack={self._attack}, "
+                f"release={self._release}, lookahead={self._lookahead}, mode={self._mode.value})")

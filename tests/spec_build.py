@@ -41,6 +41,16 @@ def build(spec):
         if "mode" in kw:
             kw["mode"] = pg.LadderMode(kw["mode"])
         return pg.LadderPE(**kw)
+    if kind == "SVFilterPE":
+        if "mode" in kw:
+            kw["mode"] = pg.BiquadMode(kw["mode"])
+        return pg.SVFilterPE(**kw)
+    if kind == "EnvelopePE":
+        if "mode" in kw:
+            kw["mode"] = pg.DetectionMode(kw["mode"])
+        return pg.EnvelopePE(**kw)
+    if kind == "TransformPE":
+        return pg.TransformPE(kw["source"], func=pg.transforms.from_spec(kw["ops"]), name="ops")
     if kind == "ConvolvePE":
         return pg.ConvolvePE(kw.pop("src"), kw.pop("fir"), **kw)
     raise KeyError(kind)

@@ -34,6 +34,7 @@ BIT_EXACT = {
     "adsr_full_cycle", "adsr_early_release_chunked", "adsr_bad_gate_values", "adsr_periodic_gate",
     "adsr_sustain_edges", "adsr_triggered", "adsr_triggered_retrigger",
     "comb_kat", "comb_high_freq", "comb_step",
+    "envelope_peak", "envelope_instant_attack", "transform_chain",
 }
 
 

@@ -272,3 +272,55 @@ def test_gate_validation_on_host_arrays():
     pg.TriggerSignal._validate_trigger_array(np.array([[0.0], [2.0], [-1.0]], np.float32))
     with pytest.raises(ValueError):
         pg.TriggerSignal._validate_trigger_array(np.array([[0.25]], np.float32))
+
+
+# ------------------------------------------------------------------ SVF / envelope / transform host logic
+
+def test_svf_rejects_allpass_and_lists_inputs():
+    src = pg.ConstantPE(0.5)
+    with pytest.raises(ValueError, match="ALLPASS"):
+        pg.SVFilterPE(src, 1000.0, 0.7, mode=pg.BiquadMode.ALLPASS)
+    f = pg.SinePE(frequency=2.0, amplitude=100.0)
+    pe = pg.SVFilterPE(src, f, 0.7)
+    assert pe.inputs() == [src, f] and not pe.is_pure() and pe.channel_count() == 1
+    assert "SVFilterPE" in repr(pe) and "SinePE(...)" in repr(pe)
+
+
+def test_svf_host_coefficients_match_oracle():
+    from oracle import pe_oracle
+    from pygmu2_amd.svfilter_pe import svf_coefficients
+    for mode in pe_oracle.SVF_MODES:
+        for f, q, g in ((1500.0, 1.3, 4.5), (30000.0, 0.001, -9.0), (0.01, 500.0, 12.0)):
+            A, B, Cc = pe_oracle.svf_coefficients_batch([f], [q], mode, g, 44100)
+            want = (A[0, 0, 0], A[0, 0, 1], A[0, 1, 0], A[0, 1, 1], B[0, 0], B[0, 1], Cc[0, 0], Cc[0, 1], Cc[0, 2])
+            got = svf_coefficients(pg.BiquadMode(mode), f, q, g, 44100)
+            assert got == tuple(float(v) for v in want), (mode, f, q, g)
+
+
+def test_envelope_clamps_parameters():
+    src = pg.ConstantPE(0.5)
+    pe = pg.EnvelopePE(src, attack=-1.0, release=0.2, lookahead=5.0)
+    assert pe.attack == 0.0 and pe.lookahead == 0.0 and pe.release == 0.2
+    pe = pg.EnvelopePE(src, attack=0.01, release=0.2, lookahead=5.0, mode=pg.DetectionMode.RMS)
+    assert pe.lookahead == 0.01 and pe.mode is pg.DetectionMode.RMS and not pe.is_pure()
+    assert pe.extent().start is None
+
+
+def test_transform_descriptors_are_numpy_callables():
+    from pygmu2_amd import transforms as tf
+    from oracle import pe_oracle
+    x = np.linspace(-2, 2, 41, dtype=np.float32).reshape(-1, 1)
+    spec = [["clip", 0.0, 1.0], ["sqrt"], ["affine", 2900.0, 100.0], ["one_minus"], ["square"], ["abs"], ["tanh"]]
+    chain = tf.from_spec(spec)
+    assert [op[0] for op in chain.ops()] == [tf.CLIP, tf.SQRT, tf.AFFINE, tf.ONE_MINUS, tf.SQUARE, tf.ABS, tf.TANH]
+    want = pe_oracle.transform(x, spec)
+    assert np.array_equal(chain(x.astype(np.float64)).astype(np.float32), want)
+    assert isinstance(tf.lower(np.abs), tf.Abs) and isinstance(tf.lower(np.tanh), tf.Tanh)
+    assert tf.lower(lambda v: v * 2) is None
+    with pytest.raises(ValueError):
+        tf.Clip(1.0, 0.0)
+    with pytest.raises(TypeError):
+        tf.Chain(np.abs)
+    pe = pg.TransformPE(pg.ConstantPE(1.0), func=tf.Affine(2.0, 1.0))
+    assert pe.is_pure() and pe.name == "affine" and "func=affine" in repr(pe)
+    assert pg.TransformPE(pg.ConstantPE(1.0), func=np.tanh, name="soft").name == "soft"
