@@ -131,22 +131,31 @@ def pmc_traffic(entry: str, frames: int):
         return None
 
 
-def biquad_kernel_roofline(pg, frames, launches):
-    """HIP-event timing of the pgx_biquad_const entry point alone (input resident in HBM)."""
+def biquad_kernel_roofline(pg, frames, launches, settled=True):
+    """HIP-event timing of the pgx_biquad_const entry point alone (input resident in HBM).
+
+    settled=True is what BiquadPE passes for the C2 section (one k_biquad_settled launch);
+    settled=False times the exact reduce + apply pair that slowly decaying sections use."""
     from pygmu2_amd import device
-    from pygmu2_amd.biquad_pe import rbj_coefficients
+    from pygmu2_amd.biquad_pe import rbj_coefficients, settle_frames
     lib = device.ensure_init()
     pg.set_sample_rate(44100)
     x = pg.SinePE(frequency=440.0).render(0, frames).dev
     out = device.DeviceBuffer((frames, 1), np.float32)
-    coef = device.DeviceBuffer.from_host(np.asarray(
-        rbj_coefficients(pg.BiquadMode.LOWPASS, 1000.0, 0.707, 0.0, 44100.0), dtype=np.float64))
+    c = rbj_coefficients(pg.BiquadMode.LOWPASS, 1000.0, 0.707, 0.0, 44100.0)
+    coef = device.DeviceBuffer.from_host(np.asarray(c, dtype=np.float64))
+    settle = settle_frames(c[3], c[4]) if settled else 0
     state = device.DeviceBuffer((1, 2), np.float64, zero=True)
-    need = lib.pgx_biquad_workspace_bytes(1, frames, 1)
+    tables = device.DeviceBuffer((lib.pgx_biquad_table_doubles(),), np.float64)
+    device.check(lib.pgx_biquad_tables(tables.ptr, coef.ptr, 1))
+    need = lib.pgx_biquad_workspace_bytes(1, frames, 1, settle)
     ws = device.DeviceBuffer((max(need, 1),), np.uint8)
+    kernel = ("k_biquad_const<reduce>+<apply> (pgx_biquad_const, settle_frames=0)" if need else
+              f"k_biquad_settled (pgx_biquad_const, settle_frames={settle})")
 
     def launch():
-        device.check(lib.pgx_biquad_const(out.ptr, 0, x.ptr, 0, 1, frames, 1, coef.ptr, state.ptr, ws.ptr))
+        device.check(lib.pgx_biquad_const(out.ptr, 0, x.ptr, 0, 1, frames, 1, coef.ptr, tables.ptr if settle else None, settle, state.ptr,
+                                          ws.ptr))
 
     for _ in range(3):
         launch()
@@ -159,8 +168,9 @@ def biquad_kernel_roofline(pg, frames, launches):
     algo_bytes = 8.0 * frames                      # read f32 + write f32 per frame
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("pgx_biquad_const", frames),
-            "kernel": "k_biquad_const<reduce>+<apply> (pgx_biquad_const)",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc_traffic("pgx_biquad_const" if need else "pgx_biquad_const_settled", frames),
+            "kernel": kernel,
             "frames_per_launch": frames, "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(ms, 6)}
 

@@ -147,12 +147,21 @@ int pgx_gain_mix_batch(float *out, const float *in, int64_t in_stride, const flo
  * exactly this operation order from its scanned carry-in.
  * coef[instance] = {b0,b1,b2,a1,a2} (host computes them, biquad_pe.py:217-335);
  * state[instance][channel] = {z0,z1}.  workspace: device scratch of at least
- * pgx_biquad_workspace_bytes(batch, n, channels) bytes (may be NULL when that is 0). */
-size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels);
+ * pgx_biquad_workspace_bytes(batch, n, channels, settle_frames) bytes (may be NULL when that is 0).
+ * settle_frames: 0, or a frame count W for which every entry of A^W (A = [[-a1,1],[-a2,0]], all
+ * instances) is below 2^-90, evaluated by the host from the coefficients it computed.  With W > 0 a
+ * long chain is rendered in one launch: each workgroup rebuilds its carry-in from the W frames before
+ * its range, which is exact to far below one float64 ulp; W = 0 (or a W above 65536) uses the
+ * reduce + apply launch pair, exact for any section.
+ * tables: NULL, or [batch][pgx_biquad_table_doubles()] doubles filled once per coefficient set by
+ * pgx_biquad_tables (the powers of A the scan uses); saves the single-launch path its prologue. */
+size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames);
+size_t pgx_biquad_table_doubles(void);
+int pgx_biquad_tables(double *tables, const double *coef /* [batch][5] */, int batch);
 int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_stride,
                      int batch, int64_t n, int channels,
-                     const double *coef /* [batch][5] */, double *state /* [batch][channels][2] */,
-                     void *workspace);
+                     const double *coef /* [batch][5] */, const double *tables, int64_t settle_frames,
+                     double *state /* [batch][channels][2] */, void *workspace);
 
 /* Time-varying coefficients: _compute_coefficients per sample (biquad_pe.py:217-335) +
  * the direct-form-I recurrence of _biquad_varying_numba (biquad_pe.py:35-62).

@@ -93,6 +93,25 @@ def rbj_coefficients(mode: BiquadMode, freq: float, q: float, gain_db: float, sa
     return tuple(float(np.atleast_1d(v)[0]) for v in (b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0))
 
 
+def settle_frames(a1: float, a2: float, limit: int = 1 << 16) -> int:
+    """
+    Smallest power of two W <= limit for which every entry of A^W, A = [[-a1, 1], [-a2, 0]] (the
+    state matrix of the DF-II-transposed section), is below 2^-90; 0 when there is none (slowly
+    decaying or unstable section).  pgx_biquad_const uses it to render long blocks in one launch.
+    """
+    p = np.array([[-a1, 1.0], [-a2, 0.0]], dtype=np.float64)
+    w = 1
+    with np.errstate(over="ignore", invalid="ignore"):
+        while w <= limit:
+            if w >= 16 and np.all(np.abs(p) < 2.0 ** -90):
+                return w
+            p = p @ p
+            if not np.all(np.isfinite(p)):
+                return 0
+            w *= 2
+    return 0
+
+
 class BiquadPE(ProcessingElement):
     def __init__(self, source: ProcessingElement, frequency, q,
                  mode: BiquadMode = BiquadMode.LOWPASS, gain_db: float = 0.0):
@@ -104,6 +123,8 @@ class BiquadPE(ProcessingElement):
         self._freq_is_pe = isinstance(frequency, ProcessingElement)
         self._q_is_pe = isinstance(q, ProcessingElement)
         self._coef: DeviceBuffer | None = None        # [5] float64 (constant path)
+        self._settle = 0                              # settle_frames of the constant section
+        self._tables: DeviceBuffer | None = None      # its power tables (single-launch path)
         self._params: DeviceBuffer | None = None      # pgx_biquad_var_params (varying path)
         self._state: DeviceBuffer | None = None       # [C][2] or [C][4] float64
         self._state_channels = 0
@@ -159,14 +180,17 @@ class BiquadPE(ProcessingElement):
         sr = float(self.sample_rate)
         if not self._freq_is_pe and not self._q_is_pe:
             if self._coef is None:
-                self._coef = DeviceBuffer.from_host(np.asarray(
-                    rbj_coefficients(self._mode, self._frequency, self._q, self._gain_db, sr),
-                    dtype=np.float64))
-            need = L.pgx_biquad_workspace_bytes(1, duration, ch)
+                coef = rbj_coefficients(self._mode, self._frequency, self._q, self._gain_db, sr)
+                self._coef = DeviceBuffer.from_host(np.asarray(coef, dtype=np.float64))
+                self._settle = settle_frames(coef[3], coef[4])
+                if self._settle:
+                    self._tables = DeviceBuffer((L.pgx_biquad_table_doubles(),), np.float64)
+                    check(L.pgx_biquad_tables(self._tables.ptr, self._coef.ptr, 1), "pgx_biquad_tables")
+            need = L.pgx_biquad_workspace_bytes(1, duration, ch, self._settle)
             if need and (self._workspace is None or self._workspace.nbytes < need):
                 self._workspace = DeviceBuffer((need,), np.uint8)
             check(L.pgx_biquad_const(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, self._coef.ptr,
-                                     self._state.ptr, ptr(self._workspace) if need else None),
+                                     ptr(self._tables), self._settle, self._state.ptr, ptr(self._workspace) if need else None),
                   "pgx_biquad_const")
             return Snippet(start, out)
 

@@ -17,7 +17,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libpygmu_hip.so")
+LIB_PATH = os.environ.get("PGX_LIB_PATH") or os.path.join(PKG_DIR, "libpygmu_hip.so")
 
 SOURCES = [
     "pgx_runtime.hip",

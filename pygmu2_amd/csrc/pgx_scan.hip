@@ -348,10 +348,303 @@ k_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_strid
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Settled single launch.  A stable section forgets: once every entry of A^W is below 2^-90 the state W
+// frames back no longer reaches the float64 arithmetic of the present.  Each workgroup then recovers
+// its carry-in by running the recurrence from zero over the frames that precede its range (outputs
+// discarded) instead of waiting for its predecessors: one launch, no cross-workgroup traffic, every
+// input frame fetched from HBM once (the warm-up frames are L2/MALL hits of a neighbour's fetch).
+// W is evaluated by the host from the coefficients (pgx_biquad_const's settle_frames); slowly decaying
+// sections (W above kSbMaxWarm half-tiles) keep the exact reduce + apply pair.
+//
+// Geometry: 512 threads x 16 frames = one 8192-frame tile, addressed in 4096-frame halves so that the
+// smallest plan (one half of warm-up + one half of output per workgroup) is a single scan step.
+// Workgroup 0 renders the halves [0, head) and the tail [tail_start, halves): it alone reads the
+// carried state (first thing) and writes it (last thing); workgroup g >= 1 renders seg halves from
+// head + (g-1)*seg.  head >= warm, so no other workgroup ever needs the carried state.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSbBlock = 512;
+constexpr int kSbWaves = kSbBlock / 64;
+constexpr int kSbHalf = (kSbBlock / 2) * kBqT;     // 4096 frames
+constexpr int kSbMaxWarm = 16;                     // half-tiles
+
+// DPP moves of a double (two 32-bit halves).  CTRL: 0x110+n = row_shr:n (within 16-lane rows),
+// 0x138 = wave_shr:1, 0x142 = row_bcast:15, 0x143 = row_bcast:31.  Lanes without a source, or outside
+// ROW_MASK, receive 0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ V2 dpp_v2(const V2 &v) {
+    return V2{dpp_f64<CTRL, ROW_MASK>(v.x), dpp_f64<CTRL, ROW_MASK>(v.y)};
+}
+
+struct SbShared {
+    V2 wave_tot[kSbWaves];
+};
+
+// Staging of a wave's 1024 frames through wave-private LDS: HBM is touched with fully coalesced 16-byte
+// accesses (lane l of access i owns frames i*256 + 4l ..), the scan wants 16 consecutive frames per lane.
+// Chunk c (16 frames) lives at word c*20: the 4-word pad makes both access patterns bank-conflict free.
+constexpr int kStageWords = 64 * 20;
+
+__device__ __forceinline__ void stage_fetch(const float *src, int lane, float (&t)[kBqT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + i * 256 + lane * 4);
+        t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
+    }
+}
+__device__ __forceinline__ int stage_slot(int i, int lane) {       // LDS word of frame i*256 + 4*lane
+    const int idx = i * 256 + lane * 4;
+    return (idx >> 4) * 20 + (idx & 15);
+}
+// coalesced order (as fetched) -> 16 consecutive frames per lane
+__device__ __forceinline__ void stage_to_chunks(float *lds, int lane, float (&t)[kBqT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4 *>(lds + stage_slot(i, lane)) = make_float4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(lds + lane * 20 + 4 * i);
+        t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
+    }
+}
+// 16 consecutive frames per lane -> coalesced stores
+__device__ __forceinline__ void stage_store(float *lds, float *dst, int lane, const float (&y)[kBqT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4 *>(lds + lane * 20 + 4 * i) = make_float4(y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4 *>(dst + i * 256 + lane * 4) = *reinterpret_cast<const float4 *>(lds + stage_slot(i, lane));
+}
+
+// Matrix-power tables of one section, computed once per coefficient set (pgx_biquad_tables):
+// A^(16*2^k) for k = 0..5, A^(16*64), then A^(16*j) for j = 0..63.
+constexpr int kBqTableDoubles = 28 + 4 * 64;
+
+__global__ void __launch_bounds__(64)
+k_biquad_tables(double *tables, const double *coef) {
+    __shared__ M2 ps[6];
+    const int lane = threadIdx.x, inst = blockIdx.x;
+    double *tb = tables + (int64_t)inst * kBqTableDoubles;
+    if (lane == 0) {
+        M2 p{-coef[inst * 5 + 3], 1.0, -coef[inst * 5 + 4], 0.0};
+#pragma unroll
+        for (int s = 1; s < kBqT; s <<= 1) p = mm(p, p);
+        for (int k = 0; k < 6; ++k) {
+            ps[k] = p;
+            tb[4 * k] = p.a; tb[4 * k + 1] = p.b; tb[4 * k + 2] = p.c; tb[4 * k + 3] = p.d;
+            p = mm(p, p);
+        }
+        tb[24] = p.a; tb[25] = p.b; tb[26] = p.c; tb[27] = p.d;
+    }
+    __syncthreads();
+    M2 m = m_identity();
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (lane & (1 << k)) m = mm(ps[k], m);
+    double *ml = tb + 28 + 4 * lane;
+    ml[0] = m.a; ml[1] = m.b; ml[2] = m.c; ml[3] = m.d;
+}
+
+__device__ __forceinline__ M2 load_m2(const double *p) { return M2{p[0], p[1], p[2], p[3]}; }
+
+// p*v + q with fused multiply-adds.  Used only where the result feeds a carry (zero-state responses and
+// their scan), never in the output pass, whose operation order is the reference's.
+__device__ __forceinline__ V2 mv_add_fma(const M2 &p, const V2 &v, const V2 &q) {
+    return V2{__builtin_fma(p.a, v.x, __builtin_fma(p.b, v.y, q.x)),
+              __builtin_fma(p.c, v.x, __builtin_fma(p.d, v.y, q.y))};
+}
+
+template <bool MONO, bool STAGED>
+__global__ void __launch_bounds__(kSbBlock, MONO ? 4 : 2)
+k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__restrict__ in, int64_t in_stride,
+                 int64_t n, int channels_arg, const double *__restrict__ coef, const double *__restrict__ tables,
+                 double *state, int seg, int head, int tail, int warm) {
+    __shared__ SbShared sh;
+    __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? kSbWaves * kStageWords : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int channels = MONO ? 1 : channels_arg;
+    const int chain = blockIdx.y;
+    const int inst = chain / channels, ch = MONO ? 0 : chain - inst * channels;
+    const int g = blockIdx.x;
+    const float *ib = in + (int64_t)inst * in_stride;
+    float *ob = out + (int64_t)inst * out_stride;
+    float *wlds = stage_lds + (STAGED ? wave * kStageWords : 0);
+    // STAGED (mono only): a wave whose 1024 frames are all inside the block and 16-byte aligned moves them
+    // with coalesced accesses; any other wave takes the per-lane path.  `xn_staged` says which layout xn has.
+    const bool io_aligned = STAGED && aligned16(ib) && aligned16(ob);
+    bool xn_staged = false;
+    const int64_t halves = (n + kSbHalf - 1) / kSbHalf;
+    int64_t tail_start = halves - tail;
+    if (tail_start < head) tail_start = head;
+
+    // the ranges of this workgroup, in halves: [hb0, he0) and, for workgroup 0 only, [hb1, he1)
+    int64_t hb = g == 0 ? 0 : head + (int64_t)(g - 1) * seg;
+    int64_t he = g == 0 ? (head < halves ? head : halves) : (hb + seg < tail_start ? hb + seg : tail_start);
+    int64_t h = hb == 0 ? 0 : hb - warm;
+    int64_t emit_to = he * kSbHalf < n ? he * kSbHalf : n;
+
+    // first tile's frames are requested before anything else so that their latency covers the table loads
+    float xn[kBqT];
+    auto request = [&](int64_t hh) {
+        const int64_t w0 = hh * kSbHalf + (int64_t)(tid - lane) * kBqT;      // first frame of this wave
+        const int64_t f0 = w0 + lane * kBqT;
+        xn_staged = io_aligned && w0 + 64 * kBqT <= emit_to;
+        if (xn_staged) {
+            stage_fetch(ib + w0, lane, xn);
+        } else if (f0 < emit_to) {
+            load_frames<kBqT>(ib, f0, n, channels, ch, xn);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kBqT; ++j) xn[j] = 0.0f;
+        }
+    };
+    if (hb < he) request(h);
+
+    const double b0 = coef[inst * 5 + 0], b1 = coef[inst * 5 + 1], b2 = coef[inst * 5 + 2];
+    const double a1 = coef[inst * 5 + 3], a2 = coef[inst * 5 + 4];
+    // uniform loads -> scalar registers
+    const double *tb = tables + (int64_t)inst * kBqTableDoubles;
+    M2 pstep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pstep[k] = load_m2(tb + 4 * k);
+    const M2 pwave = load_m2(tb + 24);
+    // per-lane powers: carry-in of the wave -> lane, previous row(s) -> lane
+    const M2 mlane = load_m2(tb + 28 + 4 * lane);
+    const M2 m16 = load_m2(tb + 28 + 4 * ((lane & 15) + 1));
+    const M2 m32 = load_m2(tb + 28 + 4 * ((lane & 31) + 1));
+
+#pragma nounroll
+    for (int range = 0; range < 2; ++range) {
+        if (range == 1) {
+            if (g != 0) break;
+            hb = tail_start;
+            he = halves;
+            if (hb >= he) break;
+            h = hb - warm;
+            emit_to = n;
+            request(h);
+        }
+        if (hb >= he) continue;
+        V2 carry{0.0, 0.0};
+        if (hb == 0) carry = V2{state[chain * 2 + 0], state[chain * 2 + 1]};
+        const int64_t emit_from = hb * kSbHalf;
+
+#pragma nounroll
+        for (; h < he; h += 2) {
+            const int64_t f0 = h * kSbHalf + (int64_t)tid * kBqT;
+            float xf[kBqT];
+#pragma unroll
+            for (int j = 0; j < kBqT; ++j) xf[j] = xn[j];
+            if (STAGED && xn_staged) stage_to_chunks(wlds, lane, xf);
+            if (h + 2 < he) request(h + 2);                    // next tile's frames, in flight during this one
+            // zero-state response of the 16-frame chunk
+            V2 e{0.0, 0.0};
+            const double na1 = -a1, na2 = -a2;
+#pragma unroll
+            for (int j = 0; j < kBqT; ++j) {
+                const double x = (double)xf[j];
+                const double y = __builtin_fma(b0, x, e.x);
+                e.x = __builtin_fma(na1, y, __builtin_fma(b1, x, e.y));
+                e.y = __builtin_fma(na2, y, b2 * x);
+            }
+#pragma unroll
+            for (int j = 0; j < kBqT; ++j) asm volatile("" : "+v"(xf[j]));   // re-convert in pass 2, keep VGPRs low
+            // inclusive scan over the wave: Kogge-Stone inside each 16-lane row (DPP row shifts) ...
+            e = mv_add_fma(pstep[0], dpp_v2<0x111, 0xf>(e), e);
+            e = mv_add_fma(pstep[1], dpp_v2<0x112, 0xf>(e), e);
+            e = mv_add_fma(pstep[2], dpp_v2<0x114, 0xf>(e), e);
+            e = mv_add_fma(pstep[3], dpp_v2<0x118, 0xf>(e), e);
+            // ... then row 0 -> 1, row 2 -> 3 (lane 15 of the previous row), then rows 0-1 -> 2, 3 (lane 31)
+            e = mv_add_fma(m16, dpp_v2<0x142, 0xa>(e), e);
+            e = mv_add_fma(m32, dpp_v2<0x143, 0xc>(e), e);
+            if (lane == 63) sh.wave_tot[wave] = e;
+            __syncthreads();
+            V2 cw = carry, run = carry;
+#pragma unroll
+            for (int w = 0; w < kSbWaves; ++w) {
+                run = mv_add_fma(pwave, run, sh.wave_tot[w]);
+                if (w + 1 == wave) cw = run;                   // wave-uniform pick of this wave's carry-in
+            }
+            __syncthreads();
+            carry = run;
+
+            if (f0 >= emit_from && f0 < emit_to) {
+                const V2 ex = dpp_v2<0x138, 0xf>(e);           // previous lane's inclusive value, 0 for lane 0
+                const V2 zin = mv_add_fma(mlane, cw, ex);
+                V2 z = zin;
+                float yf[kBqT];
+                // scipy lfilter DF-II-T operation order from the scanned carry-in
+#pragma unroll
+                for (int j = 0; j < kBqT; ++j) {
+                    double x = (double)xf[j];
+                    double y = z.x + b0 * x;
+                    double z0 = (z.y + b1 * x) - a1 * y;
+                    z.y = b2 * x - a2 * y;
+                    z.x = z0;
+                    yf[j] = (float)y;
+                }
+                const int64_t w0 = f0 - lane * kBqT;
+                if (STAGED && io_aligned && w0 >= emit_from && w0 + 64 * kBqT <= emit_to)
+                    stage_store(wlds, ob + w0, lane, yf);
+                else
+                    store_frames<kBqT>(ob, f0, n, channels, ch, yf);
+                if (n - 1 - f0 < kBqT) {                         // the chunk holding the last frame: new state
+                    z = zin;
+                    for (int j = 0; j <= (int)(n - 1 - f0); ++j) {
+                        double x = (double)xf[j];
+                        double y = z.x + b0 * x;
+                        double z0 = (z.y + b1 * x) - a1 * y;
+                        z.y = b2 * x - a2 * y;
+                        z.x = z0;
+                    }
+                    state[chain * 2 + 0] = z.x;
+                    state[chain * 2 + 1] = z.y;
+                }
+            }
+        }
+    }
+}
+
 struct BqPlan {
     int seg_tiles;
     int nseg;
 };
+
+struct BqSettledPlan {
+    bool ok;
+    int seg, head, tail, warm, groups;        // in 4096-frame halves
+};
+
+BqSettledPlan biquad_settled_plan(int batch, int64_t n, int channels, int64_t settle_frames, bool have_tables) {
+    BqSettledPlan p{};
+    if (settle_frames <= 0 || !have_tables) return p;
+    const int64_t halves = pgx::ceil_div(n, kSbHalf);
+    const int64_t warm = pgx::ceil_div(settle_frames, kSbHalf);
+    if (warm > kSbMaxWarm) return p;
+    const int64_t chains = (int64_t)batch * channels;
+    int64_t want = 512 / chains;                               // two resident workgroups per CU, one round
+    if (want < 1) want = 1;
+    int64_t seg = pgx::ceil_div(halves, want);
+    if (seg < warm) seg = warm;                                // warm-up never exceeds the rendered part
+    const int64_t head = seg / 2 > warm ? seg / 2 : warm;      // workgroup 0: head + tail ~ one segment
+    const int64_t tail = seg - head > 1 ? seg - head : 1;
+    if (halves <= head + tail) return p;                       // short chain: the plain path is one workgroup
+    p.ok = true;
+    p.seg = (int)seg;
+    p.head = (int)head;
+    p.tail = (int)tail;
+    p.warm = (int)warm;
+    p.groups = 1 + (int)pgx::ceil_div(halves - head - tail, seg);
+    return p;
+}
+
 
 BqPlan biquad_plan(int batch, int64_t n, int channels) {
     int64_t tiles = pgx::ceil_div(n, kBqTile);
@@ -1045,24 +1338,50 @@ k_transform(float *out, const float *in, int64_t n_elems, const pgx_transform_op
 // ================================================================================================ C ABI
 extern "C" {
 
-size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels) {
+size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames) {
     if (batch <= 0 || n <= 0 || channels <= 0) return 0;
+    if (biquad_settled_plan(batch, n, channels, settle_frames, true).ok) return 0;
     BqPlan p = biquad_plan(batch, n, channels);
     if (p.nseg <= 1) return 0;
     size_t chains = (size_t)batch * channels;
     return (chains * 2 + chains * (size_t)p.nseg * 2) * sizeof(double);
 }
 
+size_t pgx_biquad_table_doubles(void) { return kBqTableDoubles; }
+
+int pgx_biquad_tables(double *tables, const double *coef, int batch) {
+    PGX_REQUIRE_INIT();
+    if (batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(tables && coef, "pgx_biquad_tables: bad argument");
+    hipLaunchKernelGGL(k_biquad_tables, dim3(batch), dim3(64), 0, pgx::stream(), tables, coef);
+    PGX_LAUNCH_CHECK("k_biquad_tables");
+    return PGX_OK;
+}
+
 int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
-                     int channels, const double *coef, double *state, void *workspace) {
+                     int channels, const double *coef, const double *tables, int64_t settle_frames, double *state,
+                     void *workspace) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && coef && state && channels >= 1, "pgx_biquad_const: bad argument");
     PGX_CHECK_ARG(batch == 1 || (out_stride >= n * channels && in_stride >= n * channels),
                   "pgx_biquad_const: instance stride too small");
     PGX_CHECK_ARG((int64_t)batch * channels <= 65535, "pgx_biquad_const: too many chains");
-    BqPlan p = biquad_plan(batch, n, channels);
     int chains = batch * channels;
+    const BqSettledPlan sp = biquad_settled_plan(batch, n, channels, settle_frames, tables != nullptr);
+    if (sp.ok) {
+        if (channels == 1)
+            hipLaunchKernelGGL((k_biquad_settled<true, true>), dim3(sp.groups, chains), dim3(kSbBlock), 0,
+                               pgx::stream(), out, out_stride, in, in_stride, n, channels, coef, tables, state,
+                               sp.seg, sp.head, sp.tail, sp.warm);
+        else
+            hipLaunchKernelGGL((k_biquad_settled<false, false>), dim3(sp.groups, chains), dim3(kSbBlock), 0,
+                               pgx::stream(), out, out_stride, in, in_stride, n, channels, coef, tables, state,
+                               sp.seg, sp.head, sp.tail, sp.warm);
+        PGX_LAUNCH_CHECK("k_biquad_settled");
+        return PGX_OK;
+    }
+    BqPlan p = biquad_plan(batch, n, channels);
     dim3 grid(p.nseg, chains);
     if (p.nseg > 1) {
         PGX_CHECK_ARG(workspace != nullptr, "pgx_biquad_const: workspace required for this size");

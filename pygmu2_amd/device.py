@@ -15,7 +15,8 @@ import threading
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libpygmu_hip.so")
+# PGX_LIB_PATH: load another build of the same library (kernel experiments under experiments/)
+LIB_PATH = os.environ.get("PGX_LIB_PATH") or os.path.join(_PKG_DIR, "libpygmu_hip.so")
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -67,8 +68,10 @@ _SIGNATURES = [
     ("pgx_mix_n", _I, [_P, C.POINTER(_P), _I, _L]),
     ("pgx_mix_batch", _I, [_P, _P, _L, _I, _L]),
     ("pgx_gain_mix_batch", _I, [_P, _P, _L, _P, _L, _I, _L, _I, _I]),
-    ("pgx_biquad_workspace_bytes", _Z, [_I, _L, _I]),
-    ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _P]),
+    ("pgx_biquad_workspace_bytes", _Z, [_I, _L, _I, _L]),
+    ("pgx_biquad_table_doubles", _Z, []),
+    ("pgx_biquad_tables", _I, [_P, _P, _I]),
+    ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _L, _P, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
     ("pgx_svf", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _P, _P]),
     ("pgx_envelope", _I, [_P, _P, _L, _I, _D, _D, _I, _I, _P, _P]),

@@ -165,11 +165,11 @@ class _BiquadNode(_Node):
         ch = x.shape[2]
         if self.state is None:
             self.state = DeviceBuffer((self.k, ch, 2), np.float64, zero=True)
-        need = L.pgx_biquad_workspace_bytes(self.k, n, ch)
+        need = L.pgx_biquad_workspace_bytes(self.k, n, ch, 0)
         if need and (self.ws is None or self.ws.nbytes < need):
             self.ws = DeviceBuffer((need,), np.uint8)
         out = DeviceBuffer((self.k, n, ch), np.float32)
-        check(L.pgx_biquad_const(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.coef.ptr,
+        check(L.pgx_biquad_const(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.coef.ptr, None, 0,
                                  self.state.ptr, ptr(self.ws) if need else None), "pgx_biquad_const")
         return out
 

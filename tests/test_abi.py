@@ -59,6 +59,8 @@ def test_no_cpu_fallback_without_gpu(lib):
     assert lib.pgx_fill(None, 16, 0.0) == -3
     assert b"pgx_init" in lib.pgx_last_error()
     # pure planning helpers work without a device
-    assert lib.pgx_biquad_workspace_bytes(1, 1_000_000, 1) > 0
-    assert lib.pgx_biquad_workspace_bytes(512, 48_000, 1) == 0
+    assert lib.pgx_biquad_workspace_bytes(1, 1_000_000, 1, 0) > 0
+    assert lib.pgx_biquad_workspace_bytes(512, 48_000, 1, 0) == 0
+    assert lib.pgx_biquad_workspace_bytes(1, 1_000_000, 1, 512) == 0      # settled single launch
+    assert lib.pgx_biquad_workspace_bytes(1, 1_000_000, 1, 1 << 20) > 0    # too slow a decay: exact pair
     assert lib.pgx_convolve_workspace_bytes(96_000, 65_536, 2) > 0
