@@ -465,14 +465,20 @@ template <bool MONO, bool STAGED>
 __global__ void __launch_bounds__(kSbBlock, MONO ? 4 : 2)
 k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__restrict__ in, int64_t in_stride,
                  int64_t n, int channels_arg, const double *__restrict__ coef, const double *__restrict__ tables,
-                 double *state, int seg, int head, int tail, int warm) {
+                 double *state, int seg, int head, int tail, int warm, int groups) {
     __shared__ SbShared sh;
     __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? kSbWaves * kStageWords : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int channels = MONO ? 1 : channels_arg;
     const int chain = blockIdx.y;
     const int inst = chain / channels, ch = MONO ? 0 : chain - inst * channels;
-    const int g = blockIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2.  While the warm-up is
+    // a sizeable part of a segment, give every XCD one contiguous run of segments, so that a segment's
+    // warm-up frames are its left neighbour's L2 lines (measured: 1M frames fetch 4.3 MB instead of 8.2 MB).
+    // Long segments keep the round-robin order (the re-read is ~3% there and it streams ~10% faster).
+    const int per_xcd = gridDim.x >> 3;                        // gridDim.x is a multiple of 8
+    const int g = seg <= 8 ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (g >= groups) return;
     const float *ib = in + (int64_t)inst * in_stride;
     float *ob = out + (int64_t)inst * out_stride;
     float *wlds = stage_lds + (STAGED ? wave * kStageWords : 0);
@@ -1370,14 +1376,15 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
     int chains = batch * channels;
     const BqSettledPlan sp = biquad_settled_plan(batch, n, channels, settle_frames, tables != nullptr);
     if (sp.ok) {
+        const dim3 grid((sp.groups + 7) / 8 * 8, chains);
         if (channels == 1)
-            hipLaunchKernelGGL((k_biquad_settled<true, true>), dim3(sp.groups, chains), dim3(kSbBlock), 0,
-                               pgx::stream(), out, out_stride, in, in_stride, n, channels, coef, tables, state,
-                               sp.seg, sp.head, sp.tail, sp.warm);
+            hipLaunchKernelGGL((k_biquad_settled<true, true>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
+                               out_stride, in, in_stride, n, channels, coef, tables, state, sp.seg, sp.head,
+                               sp.tail, sp.warm, sp.groups);
         else
-            hipLaunchKernelGGL((k_biquad_settled<false, false>), dim3(sp.groups, chains), dim3(kSbBlock), 0,
-                               pgx::stream(), out, out_stride, in, in_stride, n, channels, coef, tables, state,
-                               sp.seg, sp.head, sp.tail, sp.warm);
+            hipLaunchKernelGGL((k_biquad_settled<false, false>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
+                               out_stride, in, in_stride, n, channels, coef, tables, state, sp.seg, sp.head,
+                               sp.tail, sp.warm, sp.groups);
         PGX_LAUNCH_CHECK("k_biquad_settled");
         return PGX_OK;
     }
