@@ -2,7 +2,7 @@
 """
 bench.py -- throughput of the MI355X render path on the BASELINE.json configurations.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4|c5]
 
 Prints ONE JSON line (rank 0).  Metric: Msamples/s = output frames rendered per wall second
 x 1e-6, the metric of the reference's benchmarks/benchmark_pes.py:62-66.
@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle timings")
     ap.add_argument("--no-extras", action="store_true", help="primary workload only")
     return ap.parse_args()
@@ -321,6 +321,10 @@ def main():
         dt, frames = bench_c3(pg, dist, args.steps, args.warmup)
         name = "C3: ConvolvePE stereo x 65536-tap FIR, 48 kHz, 96 000 frames per step"
         units = frames * args.steps * n_gpus
+    elif args.workload == "c4":
+        from pygmu2_amd.sharding import bench_voice_mix
+        dt, frames, name = bench_voice_mix(pg, dist, args.steps, args.warmup, voices=64, config="c4")
+        units = frames * args.steps
     else:
         from pygmu2_amd.sharding import bench_voice_mix
         dt, frames, name = bench_voice_mix(pg, dist, args.steps, args.warmup)
@@ -331,15 +335,15 @@ def main():
         "metric": "Msamples/s rendered (benchmark_pes.py metric: output frames / wall second)",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True,
-        "scaling": "strong" if args.workload == "c5" else "weak", "vs_baseline": None, "dtype": "f64",
+        "scaling": "strong" if args.workload in ("c4", "c5") else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": name, "frames_per_step": frames,
                    "parallelism": ("voices sharded over ranks, RCCL all-reduce of the partial mixes"
-                                   if args.workload == "c5" else
+                                   if args.workload in ("c4", "c5") else
                                    ("single chain" if n_gpus == 1 else f"{n_gpus} independent replicas (replicas only)"))},
     })
 
-    if args.workload != "c5" and not args.no_extras:
+    if args.workload not in ("c4", "c5") and not args.no_extras:
         # collective: every rank takes part.  512-voice mix sharded over the ranks (strong scaling).
         from pygmu2_amd.sharding import bench_voice_mix
         vdt, vframes, vname = bench_voice_mix(pg, dist, 10, 2)

@@ -69,6 +69,8 @@ int pgx_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises 
 /* Diagnostics: evaluate the library's float64 sine / cosine (the routine every oscillator and
  * coefficient kernel uses in place of np.sin / np.cos) on n device doubles. */
 int pgx_selftest_sincos(double *out_sin, double *out_cos, const double *x, int64_t n);
+/* the library's own float64 tanh (LadderPE's feedback nonlinearity), for the accuracy test */
+int pgx_selftest_tanh(double *out, const double *x, int64_t n);
 
 /* ------------------------------------------------------------------ sources / copies
  * ConstantPE._render (constant_pe.py:51-63), IdentityPE._render (identity_pe.py:43-60),
@@ -239,8 +241,15 @@ int pgx_supersaw_sum(float *out, int64_t out_stride, int batch, int nvoices, int
                      const float *amp, int64_t amp_stride);
 
 /* ------------------------------------------------------------------ LadderPE
- * _ladder_process_numba (ladder_pe.py:31-203).  One lane per (instance, channel) chain.
- * state[instance][channel] = {z0[4], z1[4], old_input}. */
+ * _ladder_process_numba (ladder_pe.py:31-203), the reference's float64 operation order.
+ * state[instance][channel] = {z0[4], z1[4], old_input}.
+ * settle_frames = 0: one lane per (instance, channel) chain, strictly sequential.
+ * settle_frames = W > 0 (host estimate of how many samples the filter needs to forget its state;
+ * only meaningful below self-oscillation): the block is cut into segments that each start W samples
+ * early from a zero state; the library verifies every segment against its left neighbour's final
+ * state (1e-8 relative) and re-renders a chain sequentially when the check fails, so W affects
+ * speed, never results beyond that bound.  workspace: pgx_ladder_workspace_bytes(...) bytes
+ * (NULL when 0); the int32 at byte offset (size - 16) counts chains that fell back (zero it to count). */
 typedef struct {
     double freq;
     double resonance;
@@ -253,7 +262,8 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
                int batch, int64_t n, int channels, double sample_rate,
                const pgx_ladder_params *params,
                const float *freq, const float *resonance, const float *drive, /* batch==1 only */
-               double *state /* [batch][channels][9] */);
+               double *state /* [batch][channels][9] */, int64_t settle_frames, void *workspace);
+size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames);
 
 /* ------------------------------------------------------------------ CombPE
  * _comb_process_numba (comb_pe.py:26-113).  state = {write_pos, smoothed_freq(-1 = unset)};

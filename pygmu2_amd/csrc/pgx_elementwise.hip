@@ -51,6 +51,11 @@ __global__ void __launch_bounds__(kBlock) k_selftest_sincos(double *os, double *
     }
 }
 
+__global__ void __launch_bounds__(kBlock) k_selftest_tanh(double *out, const double *x, int64_t n) {
+    int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = pgx::pgx_tanh(x[i]);
+}
+
 // ------------------------------------------------------------------------------ fill / ramp / dirac
 __global__ void __launch_bounds__(kBlock) k_fill(float *out, int64_t n_elems, float value, bool aligned) {
     int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
@@ -339,6 +344,15 @@ int pgx_selftest_sincos(double *out_sin, double *out_cos, const double *x, int64
     hipLaunchKernelGGL(k_selftest_sincos, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out_sin,
                        out_cos, x, n);
     PGX_LAUNCH_CHECK("k_selftest_sincos");
+    return PGX_OK;
+}
+
+int pgx_selftest_tanh(double *out, const double *x, int64_t n) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && x, "pgx_selftest_tanh: null pointer");
+    hipLaunchKernelGGL(k_selftest_tanh, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out, x, n);
+    PGX_LAUNCH_CHECK("k_selftest_tanh");
     return PGX_OK;
 }
 

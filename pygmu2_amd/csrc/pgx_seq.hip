@@ -9,8 +9,183 @@
 namespace {
 
 // ================================================================================================
-// LadderPE (ladder_pe.py:31-203).  One lane per (instance, channel) chain.
+// LadderPE (ladder_pe.py:31-203).
+//
+// The recurrence is nonlinear (tanh inside the feedback loop), so a chain advances one sample at a
+// time in the reference's exact float64 operation order: ladder_advance().
+//   * k_ladder: one lane per (instance, channel) chain over the whole block -- exact, but the whole
+//     GPU then runs `chains` lanes.
+//   * k_ladder_segments + k_ladder_finish: time-parallel.  Below self-oscillation the ladder is a
+//     contraction: two trajectories driven by the same input converge geometrically whatever their
+//     starting states.  The block is cut into segments; every segment but those reaching the block
+//     start begins `settle` samples early from a zero state and discards that warm-up output.  The
+//     state each segment reached at its first output sample is then compared with the state its left
+//     neighbour ended in (k_ladder_finish, one wave per chain); on any disagreement beyond 1e-8
+//     relative the chain is simply re-rendered sequentially from the carried state, so the result
+//     never depends on the convergence assumption, only the speed does.
 // ================================================================================================
+struct LadderConsts {
+    double sr, pbg, oversample_recip, max_cutoff;
+    int oversample, mode, channels, ch;
+    const float *x, *freq, *resonance, *drive;
+    float *o;
+    double p_freq, p_res, p_drive;
+};
+
+struct LadderState {
+    double z0[4], z1[4], old_input;
+};
+
+__device__ __forceinline__ double ladder_drive_scale(double drv, double pbg) {
+    if (drv < 0.0) drv = 0.0;
+    if (drv > 1.0) {
+        if (drv > 4.0) drv = 4.0;
+        return 1.0 + (drv - 1.0) * (1.0 - pbg);
+    }
+    return drv;
+}
+
+__device__ __forceinline__ LadderConsts ladder_consts(const pgx_ladder_params &p, double sr, int channels, int ch,
+                                                      const float *x, float *o, const float *freq,
+                                                      const float *resonance, const float *drive) {
+    LadderConsts c;
+    c.sr = sr;
+    c.pbg = p.passband_gain;
+    c.oversample = p.oversample;
+    c.oversample_recip = 1.0 / (double)p.oversample;
+    const double nyquist = sr / 2.0;
+    c.max_cutoff = nyquist * 0.85;
+    if (c.max_cutoff > nyquist - 1.0) c.max_cutoff = nyquist - 1.0;
+    c.mode = p.mode;
+    c.channels = channels;
+    c.ch = ch;
+    c.x = x; c.o = o; c.freq = freq; c.resonance = resonance; c.drive = drive;
+    c.p_freq = p.freq; c.p_res = p.resonance; c.p_drive = p.drive;
+    return c;
+}
+
+__device__ __forceinline__ void ladder_store(double *st, const LadderState &s);
+
+constexpr int kLadderChunk = 8;
+
+__device__ __forceinline__ void ladder_fetch(const LadderConsts &c, int64_t i, int64_t i1, float (&x)[kLadderChunk]) {
+#pragma unroll
+    for (int j = 0; j < kLadderChunk; ++j) x[j] = (i + j < i1) ? c.x[(i + j) * c.channels + c.ch] : 0.0f;
+}
+
+// Samples [i0, i1); output is written from `emit_from` on; when `snap` is given the state on entering
+// sample `emit_from` is stored there (i0 <= emit_from <= i1, and emit_from - i0 is a multiple of the
+// chunk or emit_from == i0... the test is per sample, so any value works).
+// Input is fetched a chunk ahead and output stored a chunk at a time: the recurrence is latency
+// bound, one memory round trip per sample would double its run time.
+__device__ __forceinline__ void ladder_advance(const LadderConsts &c, LadderState &s, int64_t i0, int64_t emit_from,
+                                               int64_t i1, double *snap = nullptr) {
+    const double state_decay = 0.95, input_threshold = 1e-5, resonance_multiplier = 1.8;
+    const double two_pi = 2.0 * 3.141592653589793;
+    const double min_cutoff = 5.0;
+    float xn[kLadderChunk];
+    if (i0 < i1) ladder_fetch(c, i0, i1, xn);
+    for (int64_t base = i0; base < i1; base += kLadderChunk) {
+        float xc[kLadderChunk], yc[kLadderChunk];
+#pragma unroll
+        for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
+        if (base + kLadderChunk < i1) ladder_fetch(c, base + kLadderChunk, i1, xn);
+#pragma unroll
+        for (int j = 0; j < kLadderChunk; ++j) {
+            const int64_t i = base + j;
+            yc[j] = 0.0f;
+            if (i >= i1) continue;
+            if (snap && i == emit_from) ladder_store(snap, s);
+
+            double cutoff = c.freq ? (double)c.freq[i] : c.p_freq;
+            if (cutoff < min_cutoff) cutoff = min_cutoff;
+            if (cutoff > c.max_cutoff) cutoff = c.max_cutoff;
+            const double wc = cutoff * two_pi / (c.sr * (double)c.oversample);
+            const double wc2 = wc * wc;
+            const double wc3 = wc2 * wc;
+            const double wc4 = wc3 * wc;
+            const double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
+            const double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
+
+            double res = c.resonance ? (double)c.resonance[i] : c.p_res;
+            if (res < 0.0) res = 0.0;
+            if (res > 1.0) res = 1.0;
+            const double k = 4.0 * res * resonance_multiplier;
+            const double drive_scaled = ladder_drive_scale(c.drive ? (double)c.drive[i] : c.p_drive, c.pbg);
+
+            const double input_sample = (double)xc[j] * drive_scaled;
+            const double input_abs = input_sample >= 0.0 ? input_sample : -input_sample;
+            if (input_abs < input_threshold) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s.z0[q] *= state_decay;
+                    s.z1[q] *= state_decay;
+                }
+                s.old_input *= state_decay;
+            }
+            double total = 0.0, interp = 0.0;
+            for (int os = 0; os < c.oversample; ++os) {
+                const double in_interp = interp * s.old_input + (1.0 - interp) * input_sample;
+                const double u = pgx::pgx_tanh(in_interp - (s.z1[3] - c.pbg * in_interp) * k * q_adjust);
+                double ft, stage1, stage2, stage3, stage4, weighted;
+
+                ft = u * 0.76923077 + 0.23076923 * s.z0[0] - s.z1[0];
+                ft = ft * alpha + s.z1[0];
+                s.z1[0] = ft; s.z0[0] = u; stage1 = ft;
+
+                ft = stage1 * 0.76923077 + 0.23076923 * s.z0[1] - s.z1[1];
+                ft = ft * alpha + s.z1[1];
+                s.z1[1] = ft; s.z0[1] = stage1; stage2 = ft;
+
+                ft = stage2 * 0.76923077 + 0.23076923 * s.z0[2] - s.z1[2];
+                ft = ft * alpha + s.z1[2];
+                s.z1[2] = ft; s.z0[2] = stage2; stage3 = ft;
+
+                ft = stage3 * 0.76923077 + 0.23076923 * s.z0[3] - s.z1[3];
+                ft = ft * alpha + s.z1[3];
+                s.z1[3] = ft; s.z0[3] = stage3; stage4 = ft;
+
+                if (c.mode == 0) weighted = stage4;
+                else if (c.mode == 1) weighted = stage2;
+                else if (c.mode == 2) weighted = (stage2 + stage4) * 4.0 - stage3 * 8.0;
+                else if (c.mode == 3) weighted = (stage1 - stage2) * 2.0;
+                else if (c.mode == 4) weighted = u + stage4 - (stage1 + stage3) * 4.0 + stage2 * 6.0;
+                else weighted = u + stage2 - stage1 * 2.0;
+
+                total += weighted * c.oversample_recip;
+                interp += c.oversample_recip;
+            }
+            s.old_input = input_sample;
+            yc[j] = (float)total;
+        }
+#pragma unroll
+        for (int j = 0; j < kLadderChunk; ++j) {
+            const int64_t i = base + j;
+            if (i >= emit_from && i < i1) c.o[i * c.channels + c.ch] = yc[j];
+        }
+    }
+    if (snap && emit_from == i1) ladder_store(snap, s);
+}
+
+__device__ __forceinline__ LadderState ladder_load(const double *st) {
+    LadderState s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s.z0[j] = st[j];
+        s.z1[j] = st[4 + j];
+    }
+    s.old_input = st[8];
+    return s;
+}
+__device__ __forceinline__ void ladder_store(double *st, const LadderState &s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st[j] = s.z0[j];
+        st[4 + j] = s.z1[j];
+    }
+    st[8] = s.old_input;
+}
+
 __global__ void __launch_bounds__(64)
 k_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n, int channels,
          double sr, const pgx_ladder_params *params, const float *freq, const float *resonance,
@@ -18,102 +193,83 @@ k_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int
     const int chain = blockIdx.x * 64 + threadIdx.x;
     if (chain >= batch * channels) return;
     const int inst = chain / channels, ch = chain - inst * channels;
-    const pgx_ladder_params p = params[inst];
-    const float *x = in + (int64_t)inst * in_stride;
-    float *o = out + (int64_t)inst * out_stride;
+    const LadderConsts c = ladder_consts(params[inst], sr, channels, ch, in + (int64_t)inst * in_stride,
+                                         out + (int64_t)inst * out_stride, freq, resonance, drive);
     double *st = state + (int64_t)chain * 9;
-    double z0[4] = {st[0], st[1], st[2], st[3]};
-    double z1[4] = {st[4], st[5], st[6], st[7]};
-    double old_input = st[8];
+    LadderState s = ladder_load(st);
+    ladder_advance(c, s, 0, 0, n);
+    ladder_store(st, s);
+}
 
-    const int oversample = p.oversample;
-    const double oversample_recip = 1.0 / (double)oversample;
-    const double state_decay = 0.95, input_threshold = 1e-5, resonance_multiplier = 1.8;
-    const double two_pi = 2.0 * 3.141592653589793;
-    const double min_cutoff = 5.0;
-    const double nyquist = sr / 2.0;
-    double max_cutoff = nyquist * 0.85;
-    if (max_cutoff > nyquist - 1.0) max_cutoff = nyquist - 1.0;
-    const double pbg = p.passband_gain;
-    const int mode = p.mode;
-
-    for (int64_t i = 0; i < n; ++i) {
-        double cutoff = freq ? (double)freq[i] : p.freq;
-        if (cutoff < min_cutoff) cutoff = min_cutoff;
-        if (cutoff > max_cutoff) cutoff = max_cutoff;
-        const double wc = cutoff * two_pi / (sr * (double)oversample);
-        const double wc2 = wc * wc;
-        const double wc3 = wc2 * wc;
-        const double wc4 = wc3 * wc;
-        const double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
-        const double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
-
-        double res = resonance ? (double)resonance[i] : p.resonance;
-        if (res < 0.0) res = 0.0;
-        if (res > 1.0) res = 1.0;
-        const double k = 4.0 * res * resonance_multiplier;
-
-        double drv = drive ? (double)drive[i] : p.drive;
-        double drive_scaled;
-        if (drv < 0.0) drv = 0.0;
-        if (drv > 1.0) {
-            if (drv > 4.0) drv = 4.0;
-            drive_scaled = 1.0 + (drv - 1.0) * (1.0 - pbg);
-        } else {
-            drive_scaled = drv;
-        }
-
-        const double input_sample = (double)x[i * channels + ch] * drive_scaled;
-        const double input_abs = input_sample >= 0.0 ? input_sample : -input_sample;
-        if (input_abs < input_threshold) {
+// One lane per (chain, segment).  warm[chain][seg] = state on entering the segment's first output
+// sample, ends[chain][seg] = state after its last one.
+__global__ void __launch_bounds__(64)
+k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
+                  int channels, double sr, const pgx_ladder_params *params, const float *freq,
+                  const float *resonance, const float *drive, const double *state, int64_t settle,
+                  int64_t seg_len, int nseg, double *warm, double *ends) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t chains = (int64_t)batch * channels;
+    if (t >= chains * nseg) return;
+    const int chain = (int)(t / nseg), seg = (int)(t - (int64_t)chain * nseg);
+    const int inst = chain / channels, ch = chain - inst * channels;
+    const pgx_ladder_params p = params[inst];
+    const LadderConsts c = ladder_consts(p, sr, channels, ch, in + (int64_t)inst * in_stride,
+                                         out + (int64_t)inst * out_stride, freq, resonance, drive);
+    const int64_t sb = (int64_t)seg * seg_len;
+    int64_t se = sb + seg_len;
+    if (se > n) se = n;
+    const int64_t ws = sb - settle;
+    LadderState s;
+    int64_t i0 = 0;
+    if (ws <= 0) {
+        s = ladder_load(state + (int64_t)chain * 9);             // reaches the block start: exact
+    } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                z0[s] *= state_decay;
-                z1[s] *= state_decay;
-            }
-            old_input *= state_decay;
-        }
-        double total = 0.0, interp = 0.0;
-        for (int os = 0; os < oversample; ++os) {
-            const double in_interp = interp * old_input + (1.0 - interp) * input_sample;
-            const double u = tanh(in_interp - (z1[3] - pbg * in_interp) * k * q_adjust);
-            double ft, stage1, stage2, stage3, stage4, weighted;
-
-            ft = u * 0.76923077 + 0.23076923 * z0[0] - z1[0];
-            ft = ft * alpha + z1[0];
-            z1[0] = ft; z0[0] = u; stage1 = ft;
-
-            ft = stage1 * 0.76923077 + 0.23076923 * z0[1] - z1[1];
-            ft = ft * alpha + z1[1];
-            z1[1] = ft; z0[1] = stage1; stage2 = ft;
-
-            ft = stage2 * 0.76923077 + 0.23076923 * z0[2] - z1[2];
-            ft = ft * alpha + z1[2];
-            z1[2] = ft; z0[2] = stage2; stage3 = ft;
-
-            ft = stage3 * 0.76923077 + 0.23076923 * z0[3] - z1[3];
-            ft = ft * alpha + z1[3];
-            z1[3] = ft; z0[3] = stage3; stage4 = ft;
-
-            if (mode == 0) weighted = stage4;
-            else if (mode == 1) weighted = stage2;
-            else if (mode == 2) weighted = (stage2 + stage4) * 4.0 - stage3 * 8.0;
-            else if (mode == 3) weighted = (stage1 - stage2) * 2.0;
-            else if (mode == 4) weighted = u + stage4 - (stage1 + stage3) * 4.0 + stage2 * 6.0;
-            else weighted = u + stage2 - stage1 * 2.0;
-
-            total += weighted * oversample_recip;
-            interp += oversample_recip;
-        }
-        old_input = input_sample;
-        o[i * channels + ch] = (float)total;
+        for (int j = 0; j < 4; ++j) s.z0[j] = s.z1[j] = 0.0;
+        s.old_input = (double)c.x[(ws - 1) * channels + ch] *
+                      ladder_drive_scale(drive ? (double)drive[ws - 1] : p.drive, c.pbg);
+        i0 = ws;
     }
+    ladder_advance(c, s, i0, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
+    ladder_store(ends + ((int64_t)chain * nseg + seg) * 9, s);
+}
+
+// One wave per chain: check every warm-started segment against its left neighbour; commit the new
+// state, or re-render the chain sequentially from the carried state.
+__global__ void __launch_bounds__(64)
+k_ladder_finish(float *out, int64_t out_stride, const float *in, int64_t in_stride, int64_t n, int channels,
+                double sr, const pgx_ladder_params *params, const float *freq, const float *resonance,
+                const float *drive, double *state, int64_t settle, int64_t seg_len, int nseg,
+                const double *warm, const double *ends, int *fallbacks) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    bool bad = false;
+    for (int seg = 1 + lane; seg < nseg; seg += 64) {
+        if ((int64_t)seg * seg_len - settle <= 0) continue;      // exact continuation, nothing assumed
+        const double *a = warm + ((int64_t)chain * nseg + seg) * 9;
+        const double *b = ends + ((int64_t)chain * nseg + seg - 1) * 9;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        st[s] = z0[s];
-        st[4 + s] = z1[s];
+        for (int j = 0; j < 9; ++j) {
+            const double d = fabs(a[j] - b[j]);
+            const double m = fmax(fabs(a[j]), fabs(b[j]));
+            if (!(d <= 1e-10 + 1e-8 * m)) bad = true;            // also catches NaN
+        }
     }
-    st[8] = old_input;
+    bad = __any(bad);
+    double *st = state + (int64_t)chain * 9;
+    if (!bad) {
+        if (lane < 9) st[lane] = ends[((int64_t)chain * nseg + nseg - 1) * 9 + lane];
+        return;
+    }
+    if (lane == 0) {
+        const int inst = chain / channels, ch = chain - inst * channels;
+        const LadderConsts c = ladder_consts(params[inst], sr, channels, ch, in + (int64_t)inst * in_stride,
+                                             out + (int64_t)inst * out_stride, freq, resonance, drive);
+        LadderState s = ladder_load(st);
+        ladder_advance(c, s, 0, 0, n);
+        ladder_store(st, s);
+        if (fallbacks) atomicAdd(fallbacks, 1);
+    }
 }
 
 // ================================================================================================
@@ -228,9 +384,40 @@ k_comb_apply(float *out, const float *in, int64_t n, int channels, double *ring,
 // ================================================================================================ C ABI
 extern "C" {
 
+namespace {
+struct LadderPlan {
+    bool segmented;
+    int64_t seg_len;
+    int nseg;
+};
+
+LadderPlan ladder_plan(int batch, int64_t n, int channels, int64_t settle) {
+    LadderPlan p{false, n, 1};
+    if (settle <= 0) return p;
+    const int64_t chains = (int64_t)batch * channels;
+    int64_t seg_len = settle / 8 > 64 ? settle / 8 : 64;          // run time ~ settle + seg_len
+    const int64_t lane_budget = 1 << 18;                          // ~4 waves on every SIMD
+    const int64_t floor_len = pgx::ceil_div(n * chains, lane_budget);
+    if (seg_len < floor_len) seg_len = floor_len;
+    if (n < 2 * (settle + seg_len)) return p;                     // nothing to win
+    p.segmented = true;
+    p.seg_len = seg_len;
+    p.nseg = (int)pgx::ceil_div(n, seg_len);
+    return p;
+}
+}  // namespace
+
+size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames) {
+    if (batch <= 0 || n <= 0 || channels <= 0) return 0;
+    const LadderPlan p = ladder_plan(batch, n, channels, settle_frames);
+    if (!p.segmented) return 0;
+    return ((size_t)batch * channels * p.nseg * 18 + 2) * sizeof(double);
+}
+
 int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
                int channels, double sample_rate, const pgx_ladder_params *params, const float *freq,
-               const float *resonance, const float *drive, double *state) {
+               const float *resonance, const float *drive, double *state, int64_t settle_frames,
+               void *workspace) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && params && state && channels >= 1 && sample_rate > 0, "pgx_ladder: bad argument");
@@ -238,10 +425,27 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
                   "pgx_ladder: instance stride too small");
     PGX_CHECK_ARG(batch == 1 || (!freq && !resonance && !drive),
                   "pgx_ladder: per-sample control streams require batch == 1");
-    int chains = batch * channels;
-    hipLaunchKernelGGL(k_ladder, dim3((chains + 63) / 64), dim3(64), 0, pgx::stream(), out, out_stride, in,
-                       in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive, state);
-    PGX_LAUNCH_CHECK("k_ladder");
+    const int chains = batch * channels;
+    const LadderPlan p = ladder_plan(batch, n, channels, settle_frames);
+    if (!p.segmented) {
+        hipLaunchKernelGGL(k_ladder, dim3((chains + 63) / 64), dim3(64), 0, pgx::stream(), out, out_stride, in,
+                           in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive, state);
+        PGX_LAUNCH_CHECK("k_ladder");
+        return PGX_OK;
+    }
+    PGX_CHECK_ARG(workspace != nullptr, "pgx_ladder: workspace required for the segmented path");
+    double *warm = (double *)workspace;
+    double *ends = warm + (size_t)chains * p.nseg * 9;
+    int *fallbacks = (int *)(ends + (size_t)chains * p.nseg * 9);
+    const int64_t lanes = (int64_t)chains * p.nseg;
+    hipLaunchKernelGGL(k_ladder_segments, dim3((unsigned)pgx::ceil_div(lanes, 64)), dim3(64), 0, pgx::stream(), out,
+                       out_stride, in, in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
+                       (const double *)state, settle_frames, p.seg_len, p.nseg, warm, ends);
+    PGX_LAUNCH_CHECK("k_ladder_segments");
+    hipLaunchKernelGGL(k_ladder_finish, dim3(chains), dim3(64), 0, pgx::stream(), out, out_stride, in, in_stride, n,
+                       channels, sample_rate, params, freq, resonance, drive, state, settle_frames, p.seg_len,
+                       p.nseg, (const double *)warm, (const double *)ends, fallbacks);
+    PGX_LAUNCH_CHECK("k_ladder_finish");
     return PGX_OK;
 }
 

@@ -55,6 +55,7 @@ _SIGNATURES = [
     ("pgx_event_record", _I, [_P]),
     ("pgx_event_elapsed_ms", _I, [_P, _P, C.POINTER(_F)]),
     ("pgx_selftest_sincos", _I, [_P, _P, _P, _L]),
+    ("pgx_selftest_tanh", _I, [_P, _P, _L]),
     ("pgx_fill", _I, [_P, _L, _F]),
     ("pgx_ramp", _I, [_P, _F, _F, _L, _I]),
     ("pgx_dirac", _I, [_P, _L, _L, _I]),
@@ -78,7 +79,8 @@ _SIGNATURES = [
     ("pgx_transform", _I, [_P, _P, _L, _P, _I]),
     ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P]),
     ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
-    ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P]),
+    ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P, _L, _P]),
+    ("pgx_ladder_workspace_bytes", _Z, [_I, _L, _I, _L]),
     ("pgx_comb", _I, [_P, _P, _L, _I, _D, _D, _D, _P, _P, _D, _L, _P, _L, _P, _P, _P]),
     ("pgx_periodic_gate", _I, [_P, _L, _I, _L, _L, _P]),
     ("pgx_periodic_trigger", _I, [_P, _L, _L, _L, _L, _F]),

@@ -1,8 +1,11 @@
 """
 LadderPE: Moog-style 4-pole ladder with tanh feedback, oversampling and six responses
-(ladder_pe.py:210-625).  The recurrence is nonlinear, so each (instance, channel) chain
-runs sequentially on one lane in the reference's exact float64 operation order
-(pgx_ladder); independent chains (voices, channels) fill the lanes of a wave.
+(ladder_pe.py:210-625).  The recurrence is nonlinear, so a chain advances sample by sample
+in the reference's exact float64 operation order (pgx_ladder).  Independent chains (voices,
+channels) fill the lanes of a wave; with scalar cutoff and resonance below self-oscillation
+the block is additionally cut into time segments that warm up over `ladder_settle_frames`
+samples -- verified on the device against the neighbouring segment, with a sequential
+re-render of the chain if the check fails.
 """
 
 from __future__ import annotations
@@ -30,6 +33,29 @@ class LadderMode(Enum):
 _MODE_INDEX = {m: i for i, m in enumerate(LadderMode)}
 
 
+def ladder_settle_frames(cutoff: float, resonance: float, sample_rate: float, oversample: int,
+                         limit: int = 16384) -> int:
+    """
+    Samples after which the ladder has forgotten its state to ~1e-12, from the small-signal
+    loop: four one-poles (pole 1 - alpha per sub-step, ladder_pe.py:103-113) closed with gain
+    k*q_adjust; the slowest closed-loop pole decays at alpha*(1 - k_fb^(1/4)/sqrt(2)) per
+    sub-step.  0 = do not segment (close to or above self-oscillation, or too slow a decay).
+    The device checks the outcome, so this only has to be a good guess.
+    """
+    nyquist = sample_rate / 2.0
+    fc = min(max(float(cutoff), 5.0), min(nyquist * 0.85, nyquist - 1.0))
+    wc = fc * 2.0 * np.pi / (sample_rate * oversample)
+    alpha = 0.9892 * wc - 0.4324 * wc ** 2 + 0.1381 * wc ** 3 - 0.0202 * wc ** 4
+    q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc ** 2 - 0.05 * wc ** 4
+    k_fb = 4.0 * min(max(float(resonance), 0.0), 1.0) * 1.8 * q_adjust
+    if k_fb >= 3.0 or alpha <= 0.0:
+        return 0
+    rate = alpha * (1.0 - k_fb ** 0.25 / np.sqrt(2.0))
+    frames = int(np.ceil(1.5 * 27.6 / rate / oversample))
+    frames = (frames + 63) // 64 * 64
+    return frames if frames <= limit else 0
+
+
 class LadderPE(ProcessingElement):
     _DEFAULT_OVERSAMPLE = 2
     _RESONANCE_MULTIPLIER = 1.8
@@ -53,6 +79,7 @@ class LadderPE(ProcessingElement):
         self._params: DeviceBuffer | None = None
         self._state: DeviceBuffer | None = None      # [C][9]: z0[4], z1[4], old_input
         self._state_channels = 0
+        self._workspace: DeviceBuffer | None = None
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -112,10 +139,20 @@ class LadderPE(ProcessingElement):
         _, r_buf = self._control_stream(self._resonance, start, duration)
         _, d_buf = self._control_stream(self._drive, start, duration)
         out = new_output(duration, ch)
-        check(lib().pgx_ladder(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate),
-                               self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr),
-              "pgx_ladder")
+        settle = self._settle_frames()
+        L = lib()
+        need = L.pgx_ladder_workspace_bytes(1, duration, ch, settle)
+        if need and (self._workspace is None or self._workspace.nbytes < need):
+            self._workspace = DeviceBuffer((need,), np.uint8, zero=True)
+        check(L.pgx_ladder(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate),
+                           self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr, settle,
+                           ptr(self._workspace) if need else None), "pgx_ladder")
         return Snippet(start, out)
+
+    def _settle_frames(self) -> int:
+        if self._freq_is_pe or self._res_is_pe:
+            return 0
+        return ladder_settle_frames(self._frequency, self._resonance, self.sample_rate, self._oversample)
 
     def __repr__(self) -> str:
         def s(is_pe, p):

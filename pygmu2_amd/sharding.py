@@ -143,9 +143,16 @@ def c5_voice(pg, i: int):
         gain=pg.AdsrGatedPE(pg.PeriodicGate(2.0 + 0.01 * i, 0.5), 0.01, 0.1, 0.7, 0.2))
 
 
-def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000):
-    """512-voice polyphonic graph, voices i = rank (mod world) on each GPU, one RCCL
-    all-reduce of the (block, 1) partial mix per rendered block.  Strong scaling."""
+def c4_voice(pg, i: int):
+    """BASELINE config 4 instance i: 7-voice SuperSaw -> 24 dB ladder low-pass."""
+    return pg.LadderPE(pg.SuperSawPE(55.0 * 2 ** (i / 12.0), voices=7, detune_cents=20.0, seed=i),
+                       frequency=1200.0, resonance=0.3, mode=pg.LadderMode.LP24, drive=1.0, oversample=2)
+
+
+def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c5"):
+    """Sharded MixPE of BASELINE config 5 (512 voices) or 4 (64 SuperSaw->Ladder instances):
+    inputs i = rank (mod world) on each GPU, one RCCL all-reduce of the (block, 1) partial mix
+    per rendered block.  Strong scaling."""
     import time
 
     from . import device
@@ -153,7 +160,8 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000):
     pg.set_sample_rate(48000)
     world = dist.world if dist.enabled else 1
     rank = dist.rank if dist.enabled else 0
-    root = ShardedMixPE([c5_voice(pg, i) for i in range(voices)], rank, world)
+    make = c5_voice if config == "c5" else c4_voice
+    root = ShardedMixPE([make(pg, i) for i in range(voices)], rank, world)
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
     r.start()
@@ -169,6 +177,10 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000):
     dist.barrier()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
     r.stop()
-    name = (f"C5: {voices}-voice polyphonic graph (BlitSawPE->BiquadPE->xAdsrGatedPE per voice)->MixPE, "
-            f"48 kHz mono, {block}-frame blocks, voices sharded i mod {world}")
+    if config == "c5":
+        name = (f"C5: {voices}-voice polyphonic graph (BlitSawPE->BiquadPE->xAdsrGatedPE per voice)->MixPE, "
+                f"48 kHz mono, {block}-frame blocks, voices sharded i mod {world}")
+    else:
+        name = (f"C4: {voices} x LadderPE(SuperSawPE 7 voices)->MixPE, 48 kHz mono, {block}-frame blocks, "
+                f"instances sharded i mod {world}")
     return dt, block, name

@@ -183,6 +183,9 @@ class _LadderNode(_Node):
                 rec[i][key] = v
         self.params = _dev.upload_structs(rec)
         self.state = None
+        self.ws = None
+        settles = [pe._settle_frames() for pe in pes]
+        self.settle = 0 if min(settles) == 0 else max(settles)     # one warm-up length for the batch
 
     def reset(self):
         super().reset()
@@ -198,8 +201,13 @@ class _LadderNode(_Node):
         if self.state is None:
             self.state = DeviceBuffer((self.k, ch, 9), np.float64, zero=True)
         out = DeviceBuffer((self.k, n, ch), np.float32)
-        check(lib().pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
-                               None, None, None, self.state.ptr), "pgx_ladder")
+        L = lib()
+        need = L.pgx_ladder_workspace_bytes(self.k, n, ch, self.settle)
+        if need and (self.ws is None or self.ws.nbytes < need):
+            self.ws = DeviceBuffer((need,), np.uint8, zero=True)
+        check(L.pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
+                           None, None, None, self.state.ptr, self.settle, ptr(self.ws) if need else None),
+              "pgx_ladder")
         return out
 
 

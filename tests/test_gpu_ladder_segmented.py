@@ -1,0 +1,103 @@
+"""
+GPU: the time-segmented LadderPE path (pgx_ladder with settle_frames > 0) against the
+sequential kernel and the oracle (orc_ladder, the restated numba kernel of ladder_pe.py:31-203).
+
+The segmented path is only a speed device: the library checks every warm-started segment and
+re-renders the chain sequentially when the check fails.  Both outcomes are exercised here.
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def env():
+    import pygmu2_amd as pg
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+
+    class Env:
+        pass
+
+    e = Env()
+    e.pg, e.device, e.lib = pg, device, lib
+    return e
+
+
+def _ladder(e, x, settle, *, freq=1200.0, res=0.3, drive=1.0, mode=0, oversample=2, sr=48000.0, state0=None):
+    device, lib = e.device, e.lib
+    n, ch = x.shape
+    xin = device.DeviceBuffer.from_host(x)
+    out = device.DeviceBuffer((n, ch), np.float32)
+    params = device.upload_struct(device.LADDER_PARAMS, freq=freq, resonance=res, drive=drive, passband_gain=0.5,
+                                  oversample=oversample, mode=mode)
+    st = device.DeviceBuffer.from_host(np.zeros((ch, 9)) if state0 is None else np.asarray(state0, dtype=np.float64))
+    need = lib.pgx_ladder_workspace_bytes(1, n, ch, settle)
+    ws = device.DeviceBuffer((max(need, 8),), np.uint8, zero=True)
+    device.check(lib.pgx_ladder(out.ptr, 0, xin.ptr, 0, 1, n, ch, sr, params.ptr, None, None, None, st.ptr,
+                                settle, ws.ptr if need else None))
+    fallbacks = int(ws.to_host()[need - 16:need - 12].view(np.int32)[0]) if need else -1
+    return out.to_host(), st.to_host(), fallbacks, need
+
+
+def _signal(n, ch, seed, silence=False):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)[:, None] / 48000.0
+    x = 0.6 * np.sin(2 * np.pi * 110.0 * t * (1 + np.arange(ch))) + 0.2 * rng.standard_normal((n, ch))
+    if silence:
+        x[n // 3: n // 3 + 5000] = 0.0                       # exercises the |in| < 1e-5 state-decay rule
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 4])
+@pytest.mark.parametrize("res,freq", [(0.0, 1200.0), (0.3, 1200.0), (0.4, 3000.0)])
+def test_segmented_matches_sequential(env, mode, res, freq):
+    from pygmu2_amd.ladder_pe import ladder_settle_frames
+    n = 48_000
+    x = _signal(n, 2, 3, silence=True)
+    settle = ladder_settle_frames(freq, res, 48000.0, 2)
+    assert settle > 0
+    s0 = np.random.default_rng(1).standard_normal((2, 9)) * 0.05
+    y_seq, st_seq, _, need0 = _ladder(env, x, 0, freq=freq, res=res, mode=mode, state0=s0)
+    y_seg, st_seg, fallbacks, need = _ladder(env, x, settle, freq=freq, res=res, mode=mode, state0=s0)
+    assert need0 == 0 and need > 0
+    assert fallbacks == 0, "the host's settle estimate should hold for this (stable) setting"
+    peak = float(np.max(np.abs(y_seq)))
+    assert float(np.max(np.abs(y_seg.astype(np.float64) - y_seq))) <= 1e-6 * peak
+    assert np.allclose(st_seg, st_seq, rtol=1e-6, atol=1e-9)
+
+
+def test_failed_check_rerenders_sequentially(env):
+    """A hopeless warm-up length (self-oscillating filter, 64 samples) must fall back and still be exact."""
+    n = 20_000
+    x = _signal(n, 1, 4)
+    y_seq, st_seq, _, _ = _ladder(env, x, 0, res=0.95, freq=2000.0)
+    y_seg, st_seg, fallbacks, need = _ladder(env, x, 64, res=0.95, freq=2000.0)
+    assert need > 0 and fallbacks == 1
+    assert np.array_equal(y_seg, y_seq)
+    assert np.array_equal(st_seg, st_seq)
+
+
+def test_segmented_matches_oracle_and_streams_state(env):
+    """LadderPE over 3 x 48000-frame blocks (segmented each) == one oracle pass."""
+    from oracle import pe_oracle as O
+    pg = env.pg
+    pg.set_sample_rate(48000)
+    x = _signal(144_000, 1, 5)
+    pe = pg.LadderPE(pg.ArrayPE(x), frequency=1200.0, resonance=0.3, mode=pg.LadderMode.LP24, oversample=2)
+    assert pe._settle_frames() > 0
+    r = pg.NullRenderer(sample_rate=48000)
+    r.set_source(pe)
+    r.start()
+    got = np.concatenate([pe.render(i * 48_000, 48_000).data for i in range(3)])
+    r.stop()
+    st = O.ladder_state(1)
+    want = O.ladder(st, x, 1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2, sr=48000)
+    peak = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= REL_TOL * peak

@@ -38,3 +38,29 @@ def test_sincos_accuracy_over_oscillator_ranges():
     assert np.max(np.abs(s - ws)[big] / ulp[big]) <= 4.0
     assert np.max(np.abs(s - ws)) <= 4e-16
     assert np.max(np.abs(c - wc)) <= 4e-16
+
+
+def test_tanh_accuracy_over_ladder_feedback_range():
+    """pgx_tanh (the ladder's feedback nonlinearity): <= 4 ulp for |x| >= 0.25, absolute <= 2.5e-16 below."""
+    lib = device.ensure_init()
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        rng.uniform(-0.25, 0.25, 200_000), rng.uniform(-4.0, 4.0, 200_000), rng.uniform(-45.0, 45.0, 100_000),
+        10.0 ** rng.uniform(-12, -1, 50_000) * rng.choice([-1.0, 1.0], 50_000),
+        np.array([0.0, -0.0, 1e-300, -1e-300, 0.25, -0.25, 19.0, 40.0, 1e300, -1e300, np.inf, -np.inf]),
+    ])
+    xd = device.DeviceBuffer.from_host(x)
+    out = device.DeviceBuffer(x.shape, np.float64)
+    device.check(lib.pgx_selftest_tanh(out.ptr, xd.ptr, x.size))
+    got, want = out.to_host(), np.tanh(x)
+    assert np.all(np.isfinite(got))
+    assert np.array_equal(np.signbit(got), np.signbit(want))
+    err = np.abs(got - want)
+    big = np.abs(x) >= 0.25
+    assert np.max(err[big] / np.spacing(np.abs(want[big]))) <= 4.0
+    assert np.max(err[~big]) <= 2.5e-16
+    assert np.all(np.abs(got) <= 1.0)
+    nan_in = device.DeviceBuffer.from_host(np.array([np.nan]))
+    nan_out = device.DeviceBuffer((1,), np.float64)
+    device.check(lib.pgx_selftest_tanh(nan_out.ptr, nan_in.ptr, 1))
+    assert np.isnan(nan_out.to_host()[0])
