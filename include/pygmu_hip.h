@@ -213,6 +213,28 @@ typedef struct {
 } pgx_transform_op;
 int pgx_transform(float *out, const float *in, int64_t n_elems, const pgx_transform_op *ops, int nops);
 
+/* ------------------------------------------------------------------ DelayPE / PiecewisePE / WAV formats
+ * (the callers and data formats either side of the path)
+ * DelayPE's float / PE delay: interpolated_lookup (interpolated_lookup.py:28-130) over the rendered
+ * source window [window_start, window_start + window_len): index = float64(start + i) - delay,
+ * linear or Catmull-Rom ("cubic"), neighbours clipped to the window; with bounded != 0 indices
+ * outside [extent_start, extent_end) give 0 (delay_pe.py:199-205).  delay: NULL -> delay_scalar. */
+int pgx_interp_lookup(float *out, const float *window, int64_t window_start, int64_t window_len,
+                      int channels, int64_t start, int64_t n, double delay_scalar, const float *delay,
+                      int cubic, int bounded, double extent_start, double extent_end);
+/* result_dev[0..1] = min, max of float64(start + i) - delay[i]  (np.min / np.max of the indices,
+ * interpolated_lookup.py:111-112): the host sizes the source window from them. */
+int pgx_index_range(double *result_dev, const float *delay, int64_t start, int64_t n);
+/* PiecewisePE._render (piecewise_pe.py:164-229); times sorted int64, values float64 (device).
+ * transition: 0 step, 1 linear, 2 exponential, 3 sigmoid, 4 constant_power. */
+int pgx_piecewise(float *out, int64_t start, int64_t n, int channels, const int64_t *times,
+                  const double *values, int count, int transition, int hold_first, int hold_last);
+/* WavWriterPE / WavReaderPE sample conversion on the device (half the PCIe bytes of float32):
+ * libsndfile's PCM_16 rules (the reference's default subtype, wav_writer_pe.py:67):
+ * s = lrintf(x * 32767) wrapped to 16 bits; x = s / 32768. */
+int pgx_f32_to_pcm16(int16_t *out, const float *in, int64_t n_elems);
+int pgx_pcm16_to_f32(float *out, const int16_t *in, int64_t n_elems);
+
 /* ------------------------------------------------------------------ BlitSawPE / SuperSawPE
  * BlitSawPE._render (blit_saw_pe.py:150-264): phase cumsum -> mod 1 -> Dirichlet kernel
  * -> leaky integrator -> *2 *amp -> float32.  state[instance] = {phase, integrator}.

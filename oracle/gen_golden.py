@@ -58,7 +58,8 @@ def load_reference():
                  "dirac_pe", "array_pe", "crop_pe", "sine_pe", "gain_pe", "mix_pe", "biquad_pe",
                  "blit_saw_pe", "super_saw_pe", "ladder_pe", "comb_pe", "adsr_pe",
                  "periodic_gate", "periodic_trigger", "convolve_pe", "svfilter_pe", "envelope_pe",
-                 "transform_pe"):
+                 "transform_pe", "wavetable_pe", "delay_pe", "piecewise_pe", "trigger_restart_pe", "cache_pe",
+                 "reverb_pe"):
         mods[name] = importlib.import_module(f"pygmu2.{name}")
     return mods
 
@@ -129,6 +130,17 @@ def build(spec, M):
         if "mode" in kw:
             kw["mode"] = M["envelope_pe"].DetectionMode(kw["mode"])
         return M["envelope_pe"].EnvelopePE(**kw)
+    if kind == "DelayPE":
+        if "interpolation" in kw:
+            kw["interpolation"] = M["wavetable_pe"].InterpolationMode(kw["interpolation"])
+        return M["delay_pe"].DelayPE(**kw)
+    if kind == "PiecewisePE":
+        kw["points"] = [(int(t), float(v)) for t, v in kw["points"]]
+        return M["piecewise_pe"].PiecewisePE(**kw)
+    if kind == "TriggerRestartPE":
+        return M["trigger_restart_pe"].TriggerRestartPE(kw["trigger"], kw["src"])
+    if kind == "ReverbPE":
+        return M["reverb_pe"].ReverbPE(kw.pop("source"), kw.pop("ir"), kw.pop("mix", 0.5), **kw)
     if kind == "TransformPE":
         return M["transform_pe"].TransformPE(kw["source"], func=numpy_func(kw["ops"]), name="ops")
     raise KeyError(kind)
@@ -181,7 +193,7 @@ def main():
         # A reference ConvolvePE cannot be start()ed (its _reset_state drops the tail
         # that _ensure_filter_prepared never re-creates); the
         # reference's own tests render it un-started, so do the same.
-        if not has_kind(case["graph"], "ConvolvePE"):
+        if not (has_kind(case["graph"], "ConvolvePE") or has_kind(case["graph"], "ReverbPE")):
             r.start()
         for i, (s, n) in enumerate(case["blocks"]):
             data = pe.render(int(s), int(n)).data

@@ -360,6 +360,51 @@ def cases():
     add("autowah_biquad", 44100, autowah("BiquadPE"), blocks_contig(0, [1024] * 8))
     add("autowah_svf", 44100, autowah("SVFilterPE"), blocks_contig(0, [1024] * 8))
 
+    # ---------------------------------------------------------------- Delay / Piecewise / TriggerRestart / Reverb
+    tone = {"rng": 40, "n": 3000, "ch": 2, "scale": 0.5}
+    add("delay_int", 44100, S("DelayPE", source=S("ArrayPE", data=tone), delay=100),
+        [[-50, 200], [150, 1000], [2900, 400]])
+    add("delay_int_negative", 44100, S("DelayPE", source=S("ArrayPE", data=tone), delay=-37),
+        [[-100, 300], [2800, 300]])
+    add("delay_float_linear", 44100, S("DelayPE", source=S("ArrayPE", data=tone), delay=10.5, interpolation="linear"),
+        [[-20, 100], [80, 1024], [2990, 60]])
+    add("delay_float_cubic", 44100, S("DelayPE", source=S("ArrayPE", data=tone), delay=3.25, interpolation="cubic"),
+        [[-20, 100], [80, 1024], [2990, 60]])
+    vib = S("MixPE", inputs=[S("ConstantPE", value=100.0), S("SinePE", frequency=5.0, amplitude=50.0)])
+    add("delay_pe_vibrato_linear", 44100, S("DelayPE", source=S("SinePE", frequency=440.0), delay=vib),
+        blocks_contig(0, [4096, 1024, 17]))
+    add("delay_pe_vibrato_cubic", 44100,
+        S("DelayPE", source=S("ArrayPE", data={"rng": 41, "n": 6000, "ch": 1, "scale": 0.5}), delay=vib,
+          interpolation="cubic"), blocks_contig(0, [4096, 2048, 500]))
+    pts = [[0, 0.0], [100, 1.0], [400, 0.25], [401, 0.9], [1000, 0.5]]
+    for tt in ("step", "linear", "exponential", "sigmoid", "constant_power"):
+        add(f"piecewise_{tt}", 44100, S("PiecewisePE", points=pts, transition_type=tt, extend_mode="zero"),
+            [[-50, 200], [150, 1000]])
+    add("piecewise_hold_both_stereo", 44100,
+        S("PiecewisePE", points=[[10, 2.0], [500, -1.0], [200, 0.0]], transition_type="exponential",
+          extend_mode="hold_both", channels=2), [[-100, 300], [200, 500], [700, 100]])
+    add("piecewise_single_point", 44100,
+        S("PiecewisePE", points=[[5, 0.75]], extend_mode="hold_last"), [[0, 20], [20, 10]])
+    add("piecewise_single_point_zero", 44100, S("PiecewisePE", points=[[5, 0.75]]), [[0, 20]])
+    add("trigger_restart_sine", 44100,
+        S("TriggerRestartPE", trigger=S("PeriodicTrigger", hz=30.0, phase=0.25), src=S("SinePE", frequency=700.0)),
+        blocks_contig(0, [1024, 1024, 17, 3000]))
+    add("trigger_restart_blitsaw", 48000,
+        S("TriggerRestartPE", trigger=S("PeriodicTrigger", hz=20.0),
+          src=S("BlitSawPE", frequency=330.0)), blocks_contig(0, [4096, 100, 4000]))
+    room = {"rng": 42, "n": 300, "ch": 1, "scale": 0.2, "decay": 60.0}
+    add("reverb_mix_03", 10000,
+        S("ReverbPE", source=S("ArrayPE", data={"rng": 43, "n": 2000, "ch": 2, "scale": 0.5}),
+          ir=S("ArrayPE", data=room), mix=0.3, fft_size=1024), blocks_contig(0, [700, 700, 700, 400]))
+    add("reverb_unnormalised", 10000,
+        S("ReverbPE", source=S("ArrayPE", data={"rng": 43, "n": 2000, "ch": 2, "scale": 0.5}),
+          ir=S("ArrayPE", data=room), mix=1.0, normalize_ir=False, fft_size=1024), blocks_contig(0, [1000, 1400]))
+    add("reverb_mix_pe", 10000,
+        S("ReverbPE", source=S("ArrayPE", data={"rng": 43, "n": 2000, "ch": 1, "scale": 0.5}),
+          ir=S("ArrayPE", data=room), mix=S("MixPE", inputs=[S("ConstantPE", value=0.5),
+                                                              S("SinePE", frequency=3.0, amplitude=0.4)]),
+          fft_size=1024), blocks_contig(0, [1000, 1400]))
+
     # ---------------------------------------------------------------- Convolve
     add("conv_kat", 10000,
         S("ConvolvePE", src=S("ArrayPE", data={"values": [1.0, 2.0, 3.0, 4.0]}),

@@ -74,7 +74,9 @@ class Node:
         self.reset()
 
     # ------------------------------------------------------------------ state
-    def reset(self):
+    def reset(self, recursive=True):
+        """recursive=True: graph start (every node's on_start); False: ProcessingElement.reset_state(),
+        which resets this node only (processing_element.py:277-294)."""
         k, kw = self.kind, self.kw
         self.state = None
         if k == "SinePE":
@@ -95,8 +97,12 @@ class Node:
             self.state = O.envelope_state()
         elif k in ("AdsrGatedPE", "AdsrTriggeredPE"):
             self.state = O.adsr_state()
-        elif k == "ConvolvePE":
+        elif k in ("ConvolvePE", "ReverbPE"):
             self.state = O.convolve_state()
+        elif k == "TriggerRestartPE":
+            self.state = {"t0": None}
+        if not recursive:
+            return
         for s in self.sub.values():
             for n in (s if isinstance(s, list) else [s]):
                 n.reset()
@@ -112,6 +118,10 @@ class Node:
             return 1
         if k == "MixPE":
             return self.sub["inputs"][0].channels()
+        if k == "PiecewisePE":
+            return int(kw.get("channels", 1))
+        if k == "TriggerRestartPE":
+            return self.sub["src"].channels()
         if k == "ConvolvePE":
             sc, fc = self.sub["src"].channels(), self.sub["fir"].channels()
             return sc if fc == 1 else (fc if sc == 1 else sc)
@@ -156,6 +166,27 @@ class Node:
             se = self.sub["src"].extent()
             L = self.sub["fir"].extent()[1]
             return (se[0], None if se[1] is None else se[1] + L - 1)
+        if k == "DelayPE":
+            se = self.sub["source"].extent()
+            if "delay" in self.sub:
+                return _isect(se, self.sub["delay"].extent())
+            d = kw["delay"]
+            if float(d).is_integer():
+                d = int(d)
+                return (None if se[0] is None else se[0] + d, None if se[1] is None else se[1] + d)
+            return (None if se[0] is None else int(np.floor(se[0] + d)),
+                    None if se[1] is None else int(np.ceil(se[1] + d)))
+        if k == "PiecewisePE":
+            if kw.get("extend_mode", "zero") != "zero":
+                return INF
+            times, _ = O.piecewise_points(kw["points"])
+            return (int(times[0]), int(times[0]) + 1) if len(times) == 1 else (int(times[0]), int(times[-1]))
+        if k == "TriggerRestartPE":
+            return self.sub["trigger"].extent()
+        if k == "ReverbPE":
+            se = self.sub["source"].extent()
+            L = self.sub["ir"].extent()[1]
+            return _union(se, (se[0], None if se[1] is None else se[1] + L - 1))
         if k in ("SinePE", "BlitSawPE", "SuperSawPE", "PeriodicGate"):
             ext = INF
             for name in ("frequency", "amplitude", "phase", "m", "duty_cycle"):
@@ -266,6 +297,16 @@ class Node:
             return O.adsr_triggered(self.state, t, start, kw.get("attack_time", 0.1),
                                     kw.get("decay_time", 0.1), kw.get("sustain_time", 0.5),
                                     kw.get("sustain_level", 0.5), kw.get("release_time", 0.1), sr)
+        if k == "DelayPE":
+            return self._delay(start, n)
+        if k == "PiecewisePE":
+            times, values = O.piecewise_points(kw["points"])
+            return O.piecewise(times, values, kw.get("transition_type", "linear"), kw.get("extend_mode", "zero"),
+                               int(kw.get("channels", 1)), start, n)
+        if k == "TriggerRestartPE":
+            return self._trigger_restart(start, n)
+        if k == "ReverbPE":
+            return self._reverb(start, n)
         if k == "ConvolvePE":
             if "h" not in self.state:
                 L = self.sub["fir"].extent()[1]
@@ -273,6 +314,70 @@ class Node:
             x = self.sub["src"].render(start, n)
             return O.convolve(self.state, start, x, self.state["h"], kw.get("fft_size"))
         raise KeyError(f"oracle graph_eval: unknown PE kind {k}")
+
+    def _delay(self, start, n):
+        """delay_pe.py:135-216."""
+        kw, src = self.kw, self.sub["source"]
+        if "delay" not in self.sub and float(kw["delay"]).is_integer():
+            return src.render(start - int(kw["delay"]), n)
+        t = np.arange(start, start + n, dtype=np.float64)
+        if "delay" in self.sub:
+            indices = t - self.sub["delay"].render(start, n)[:, 0].astype(np.float64)
+        else:
+            indices = t - kw["delay"]
+        cubic = kw.get("interpolation", "linear") == "cubic"
+        se = src.extent()
+        oob = None
+        if se[0] is not None and se[1] is not None:
+            oob = (indices < se[0]) | (indices >= se[1])
+        lo, cnt = O.interp_window(indices, cubic)
+        return O.interp_lookup(src.render(lo, cnt), lo, indices, cubic, oob)
+
+    def _trigger_restart(self, start, n):
+        """trigger_restart_pe.py:72-98."""
+        src = self.sub["src"]
+        out = np.zeros((n, src.channels()), dtype=np.float32)
+        trig = self.sub["trigger"].render(start, n)[:, 0]
+        events = np.nonzero(trig > 0)[0]
+        prefix_end = int(events[0]) if events.size else n
+        if prefix_end > 0 and self.state["t0"] is not None:
+            out[:prefix_end, :] = src.render(start - self.state["t0"], prefix_end)
+        for i, k in enumerate(events.tolist()):
+            k_end = int(events[i + 1]) if i + 1 < events.size else n
+            if k_end <= k:
+                continue
+            src.reset(recursive=False)
+            self.state["t0"] = start + k
+            out[k:k_end, :] = src.render(0, k_end - k)
+        return out
+
+    def _reverb(self, start, n):
+        """reverb_pe.py:27-129: MixPE(GainPE(src, 1-mix), GainPE(ConvolvePE(src, ir), mix / ir_energy))."""
+        kw, src = self.kw, self.sub["source"]
+        if "h" not in self.state:
+            self.state["h"] = self.sub["ir"].render(0, self.sub["ir"].extent()[1])
+        h = self.state["h"]
+        energy = O.ir_energy_norm(h) if kw.get("normalize_ir", True) else 1.0
+        x = src.render(start, n)                      # CachePE: one pull feeds both paths
+        wet = O.convolve(self.state, start, x, h, kw.get("fft_size"))
+        if "mix" in self.sub:
+            m = self.sub["mix"].render(start, n)
+            dry_gain = O.mix([O.constant(n, 1.0, 1), O.gain_const(m, -1.0)])
+            wet_gain = O.gain_const(m, 1.0 / energy) if kw.get("normalize_ir", True) else m
+            dry, wetg = O.gain_vec(x, dry_gain), O.gain_vec(wet, wet_gain)
+        else:
+            mixv = float(kw.get("mix", 0.5))
+            wg = mixv / energy if kw.get("normalize_ir", True) else mixv
+            dry, wetg = O.gain_const(x, 1.0 - mixv), O.gain_const(wet, wg)
+        req = (start, start + n)
+        se = src.extent()
+        L = h.shape[0]
+        parts = []
+        if _intersects(se, req):
+            parts.append(dry)
+        if _intersects((se[0], None if se[1] is None else se[1] + L - 1), req):
+            parts.append(wetg)
+        return O.mix(parts) if parts else np.zeros((n, x.shape[1]), dtype=np.float32)
 
     def _crop(self, start, n):
         """extent_window_pe.py:88-157 (CropPE)."""

@@ -5,7 +5,8 @@ Same public names as the reference package for the accelerated hot path:
 ProcessingElement / SourcePE / Snippet / Extent / Renderer / NullRenderer and the PEs
 SinePE, BlitSawPE, SuperSawPE, BiquadPE, LadderPE, CombPE, MixPE, GainPE, ConvolvePE,
 AdsrGatedPE, AdsrTriggeredPE, PeriodicGate, PeriodicTrigger, ConstantPE, ArrayPE,
-DiracPE, IdentityPE, CachePE, CropPE, SVFilterPE, EnvelopePE, TransformPE.  Snippet payloads live in HBM; all DSP runs in
+DiracPE, IdentityPE, CachePE, CropPE, SVFilterPE, EnvelopePE, TransformPE, DelayPE, PiecewisePE,
+TriggerRestartPE, ReverbPE, WavWriterPE, WavReaderPE (+ render_to_file).  Snippet payloads live in HBM; all DSP runs in
 hand-written HIP kernels for gfx950 behind the C ABI of include/pygmu_hip.h.
 """
 
@@ -41,6 +42,13 @@ from .svfilter_pe import SVFilterPE
 from .envelope_pe import DetectionMode, EnvelopePE
 from .transform_pe import TransformPE
 from . import transforms
+from .delay_pe import DelayPE, InterpolationMode
+from .piecewise_pe import PiecewisePE, TransitionType
+from .trigger_restart_pe import TriggerRestartPE
+from .reverb_pe import ReverbPE
+from .wav_writer_pe import WavWriterPE
+from .wav_reader_pe import WavReaderPE
+from .utils import render_to_file
 from . import device, diagnostics
 
 __all__ = [
@@ -50,5 +58,6 @@ __all__ = [
     "ArrayPE", "CachePE", "CropPE", "SinePE", "GainPE", "MixPE", "BiquadMode", "BiquadPE", "BlitSawPE",
     "SuperSawPE", "LadderMode", "LadderPE", "CombPE", "PeriodicGate", "PeriodicTrigger", "AdsrGatedPE",
     "AdsrTriggeredPE", "ConvolvePE", "SVFilterPE", "DetectionMode", "EnvelopePE", "TransformPE",
-    "transforms", "device", "diagnostics",
+    "transforms", "DelayPE", "InterpolationMode", "PiecewisePE", "TransitionType", "TriggerRestartPE",
+    "ReverbPE", "WavWriterPE", "WavReaderPE", "render_to_file", "device", "diagnostics",
 ]

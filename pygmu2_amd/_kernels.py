@@ -20,8 +20,8 @@ def lib():
     return _LIB
 
 
-def new_output(frames: int, channels: int) -> DeviceBuffer:
-    return DeviceBuffer((int(frames), int(channels)), np.float32)
+def new_output(frames: int, channels: int, *, zero: bool = False) -> DeviceBuffer:
+    return DeviceBuffer((int(frames), int(channels)), np.float32, zero=zero)
 
 
 def ptr(buf) -> int | None:

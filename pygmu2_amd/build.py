@@ -26,6 +26,7 @@ SOURCES = [
     "pgx_seq.hip",
     "pgx_adsr.hip",
     "pgx_convolve.hip",
+    "pgx_lookup.hip",
 ]
 
 # -ffp-contract=off: the parity contract is "same float64 operation order as the reference's

@@ -74,6 +74,11 @@ _SIGNATURES = [
     ("pgx_biquad_tables", _I, [_P, _P, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _L, _P, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
+    ("pgx_interp_lookup", _I, [_P, _P, _L, _L, _I, _L, _L, _D, _P, _I, _I, _D, _D]),
+    ("pgx_index_range", _I, [_P, _P, _L, _L]),
+    ("pgx_piecewise", _I, [_P, _L, _L, _I, _P, _P, _I, _I, _I, _I]),
+    ("pgx_f32_to_pcm16", _I, [_P, _P, _L]),
+    ("pgx_pcm16_to_f32", _I, [_P, _P, _L]),
     ("pgx_svf", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _P, _P]),
     ("pgx_envelope", _I, [_P, _P, _L, _I, _D, _D, _I, _I, _P, _P]),
     ("pgx_transform", _I, [_P, _P, _L, _P, _I]),

@@ -51,6 +51,17 @@ def build(spec):
         return pg.EnvelopePE(**kw)
     if kind == "TransformPE":
         return pg.TransformPE(kw["source"], func=pg.transforms.from_spec(kw["ops"]), name="ops")
+    if kind == "DelayPE":
+        if "interpolation" in kw:
+            kw["interpolation"] = pg.InterpolationMode(kw["interpolation"])
+        return pg.DelayPE(**kw)
+    if kind == "PiecewisePE":
+        kw["points"] = [(int(t), float(v)) for t, v in kw["points"]]
+        return pg.PiecewisePE(**kw)
+    if kind == "TriggerRestartPE":
+        return pg.TriggerRestartPE(kw["trigger"], kw["src"])
+    if kind == "ReverbPE":
+        return pg.ReverbPE(kw.pop("source"), kw.pop("ir"), kw.pop("mix", 0.5), **kw)
     if kind == "ConvolvePE":
         return pg.ConvolvePE(kw.pop("src"), kw.pop("fir"), **kw)
     raise KeyError(kind)
