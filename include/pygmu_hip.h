@@ -52,6 +52,15 @@ int pgx_shutdown(void);                   /* sync, release pool, destroy stream 
 int pgx_device_name(char *buf, size_t len);
 void *pgx_stream_handle(void);            /* hipStream_t of the library stream               */
 int pgx_stream_sync(void);
+/* Two independent sub-graphs of one block may overlap on the device:
+ *   pgx_stream_fork()      a side stream starts behind everything enqueued so far; calls go to it
+ *   pgx_stream_select(s)   while forked: s != 0 -> side stream, 0 -> main stream
+ *   pgx_stream_join()      main stream waits for the side stream; calls go to the main stream again
+ * Between fork and join pgx_free() parks blocks (they are re-pooled at the join): "freed = reusable"
+ * is only true in single-stream order.  The caller keeps the two call sequences data-independent. */
+int pgx_stream_fork(void);
+int pgx_stream_select(int side);
+int pgx_stream_join(void);
 
 int pgx_malloc(void **dptr, size_t bytes);      /* pooled (size-class free lists)           */
 int pgx_free(void *dptr);                       /* returns the block to the pool            */
@@ -325,10 +334,14 @@ size_t pgx_adsr_workspace_bytes(int batch, int64_t n);
 int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t gate_stride,
                    int batch, int64_t n, const pgx_adsr_params *params, double *state, void *workspace);
 /* AdsrGatedPE(PeriodicGate(scalar params)): the gate of pgx_periodic_gate is evaluated inside the
- * envelope kernels, sample for sample the same values, without materialising the gate buffer. */
+ * envelope kernels, sample for sample the same values, without materialising the gate buffer.
+ * detach_walk != 0: after the (parallel) edge search the library forks (pgx_stream_fork), enqueues the
+ * envelope walk -- one latency-bound wave per envelope -- on the side stream and selects the main
+ * stream again; the caller enqueues independent work and must call pgx_stream_join() before any call
+ * that reads `out` or touches `state`.  Not allowed while already forked. */
 int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                             const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
-                            void *workspace);
+                            void *workspace, int detach_walk);
 int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride,
                        int batch, int64_t start, int64_t n, const pgx_adsr_params *params,
                        double *state, void *workspace);

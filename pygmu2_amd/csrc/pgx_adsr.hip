@@ -50,43 +50,76 @@ __device__ __forceinline__ float adsr_control(const float *g, const pgx_gate_par
     return g[idx];
 }
 
+constexpr int kEdgeRun = 24;          // consecutive chunks of one voice per wave
+
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_adsr_edges(unsigned long long *masks, unsigned long long *group_bits, float *last_gate, const float *ctl,
              int64_t ctl_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
              const pgx_gate_params *gates, const double *state) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wave >= (int64_t)batch * nchunks) return;
-    const int inst = (int)(wave / nchunks);
-    const int64_t chunk = wave - (int64_t)inst * nchunks;
+    // one wave = kEdgeRun consecutive chunks of one voice: the voice's parameters are loaded once and
+    // the gate value at the end of a chunk is the "previous sample" of the next one
+    const int64_t runs_per_voice = (nchunks + kEdgeRun - 1) / kEdgeRun;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)batch * runs_per_voice) return;
+    const int inst = (int)(w / runs_per_voice);
+    const int64_t c0 = (w - (int64_t)inst * runs_per_voice) * kEdgeRun;
+    const int64_t c1 = (c0 + kEdgeRun < nchunks) ? c0 + kEdgeRun : nchunks;
     const float *g = (MODE == 2) ? nullptr : ctl + (int64_t)inst * ctl_stride;
     pgx_gate_params gp{0.0, 0.0, 0.0};
     if (MODE == 2) gp = gates[inst];
-    const int64_t idx = chunk * 64 + lane;
-    const bool valid = idx < n;
-    const float cur = valid ? adsr_control<MODE>(g, gp, start, idx) : 0.0f;
-    unsigned long long am, rm = 0ull;
-    if (MODE == 1) {
-        am = __ballot(valid && cur > 0.0f);                        // adsr_pe.py:297: trigger > 0
-    } else {
-        // previous sample: lane 0 evaluates / loads it (or takes the carried gate), the other lanes get
-        // their left neighbour through a whole-wave DPP shift (wave_shr:1)
-        float p0 = 0.0f;
-        if (lane == 0) p0 = (idx == 0) ? (float)state[(int64_t)inst * 3 + 2]
-                                       : (valid ? adsr_control<MODE>(g, gp, start, idx - 1) : 0.0f);
-        const float pv = __int_as_float(__builtin_amdgcn_update_dpp(
-            __float_as_int(p0), __float_as_int(cur), 0x138, 0xf, 0xf, false));
-        am = __ballot(valid && pv == 0.0f && cur == 1.0f);         // adsr_pe.py:146-147
-        rm = __ballot(valid && pv == 1.0f && cur == 0.0f);
-        if (idx == n - 1) last_gate[inst] = cur;
+    // A periodic gate whose high and low phases both last 65 samples or more changes at most once inside
+    // a 64-sample chunk, so "value before the chunk == value at its last sample" means the chunk has no
+    // edge: one evaluation per chunk instead of 64 (the common case by a wide margin).
+    const double narrow = gp.duty < 1.0 - gp.duty ? gp.duty : 1.0 - gp.duty;
+    const bool sparse = (MODE == 2) && gp.dt > 0.0 && narrow >= 65.0 * gp.dt;
+
+    // gate value just before the run (wave-uniform)
+    float before = 0.0f;
+    if (MODE != 1) {
+        before = (c0 == 0) ? (float)state[(int64_t)inst * 3 + 2]
+                           : ((MODE == 2) ? adsr_control<MODE>(g, gp, start, c0 * 64 - 1) : g[c0 * 64 - 1]);
     }
-    if (lane == 0) {
-        masks[wave * 2 + 0] = am;
-        masks[wave * 2 + 1] = rm;
-        if (am | rm) {                                             // rare: mark the 512-sample group
-            const int64_t grp = chunk / kGroupChunks;
-            atomicOr(&group_bits[(int64_t)inst * gwords + (grp >> 6)], 1ull << (grp & 63));
+    for (int64_t chunk = c0; chunk < c1; ++chunk) {
+        const int64_t wave = (int64_t)inst * nchunks + chunk;
+        const int64_t i_first = chunk * 64;
+        const int64_t i_last = (i_first + 63 < n - 1) ? i_first + 63 : n - 1;
+        if (sparse) {
+            const float v_last = adsr_control<MODE>(g, gp, start, i_last);
+            if (before == v_last) {
+                if (lane == 0) {
+                    masks[wave * 2 + 0] = 0ull;
+                    masks[wave * 2 + 1] = 0ull;
+                    if (i_last == n - 1) last_gate[inst] = v_last;
+                }
+                continue;
+            }
+        }
+        const int64_t idx = i_first + lane;
+        const bool valid = idx < n;
+        const float cur = valid ? adsr_control<MODE>(g, gp, start, idx) : 0.0f;
+        unsigned long long am, rm = 0ull;
+        if (MODE == 1) {
+            am = __ballot(valid && cur > 0.0f);                        // adsr_pe.py:297: trigger > 0
+        } else {
+            // previous sample: lane 0 takes the value carried along the run, the other lanes their left
+            // neighbour through a whole-wave DPP shift (wave_shr:1)
+            const float pv = __int_as_float(__builtin_amdgcn_update_dpp(
+                __float_as_int(before), __float_as_int(cur), 0x138, 0xf, 0xf, false));
+            am = __ballot(valid && pv == 0.0f && cur == 1.0f);         // adsr_pe.py:146-147
+            rm = __ballot(valid && pv == 1.0f && cur == 0.0f);
+            if (idx == n - 1) last_gate[inst] = cur;
+            // the chunk's last valid sample becomes `before` of the next chunk
+            before = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), (int)(i_last - i_first)));
+        }
+        if (lane == 0) {
+            masks[wave * 2 + 0] = am;
+            masks[wave * 2 + 1] = rm;
+            if (am | rm) {                                             // rare: mark the 512-sample group
+                const int64_t grp = chunk / kGroupChunks;
+                atomicOr(&group_bits[(int64_t)inst * gwords + (grp >> 6)], 1ull << (grp & 63));
+            }
         }
     }
 }
@@ -234,6 +267,10 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
             const pgx_adsr_params *params, const unsigned long long *masks, const unsigned long long *group_bits,
             const float *last_gate, double *state) {
     const int lane = threadIdx.x & 63;
+    // A dependent chain on one wave: when it shares a SIMD with throughput kernels of a forked block
+    // (pgx_adsr_gated_periodic's detach_walk) it must win instruction arbitration, or it is the
+    // block's critical path at a third of its speed.
+    __builtin_amdgcn_s_setprio(3);
     // one wave per envelope; readfirstlane makes the index provably wave-uniform (scalar loads)
     const int inst = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (inst >= batch) return;
@@ -303,6 +340,21 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                 rmk = (k == j) ? rm[j] : rmk;
             }
             const int64_t i0 = (ch + k) * 64;
+            if ((amk | rmk) == 0ull) {
+                // no edge in this chunk: the group was slow because a run ends somewhere in it -- most of
+                // its chunks still are plain 64-sample pieces of a run
+                if (!c.have) c.have = adsr_derive(c, p, TRIG, (long long)(start + i0));
+                if (c.have) {
+                    const double vlast = c.env + 63.0 * c.dq;
+                    bool ok = (c.dir > 0) ? (vlast <= c.lim) : ((c.dir < 0) ? (vlast >= c.lim) : true);
+                    if (TRIG && c.s == kSustain) ok = ((long long)(start + i0) + 63 < c.ends_at);
+                    if (ok) {
+                        o[i0 + lane] = (float)(c.env + (double)lane * c.dq);       // exact
+                        c.env = c.env + 64.0 * c.dq;
+                        continue;
+                    }
+                }
+            }
             const double mine = adsr_chunk<TRIG>(c, p, amk, amk | rmk, 64, (long long)(start + i0), lane);
             o[i0 + lane] = (float)mine;
         }
@@ -344,18 +396,26 @@ AdsrWs adsr_ws(void *workspace, int batch, int64_t n) {
 template <int MODE>
 int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_stride, int batch, int64_t start,
                 int64_t n, const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
-                void *workspace) {
+                void *workspace, bool detach_walk = false) {
     AdsrWs w = adsr_ws(workspace, batch, n);
     const int64_t waves = (int64_t)batch * w.nchunks;
     PGX_HIP(hipMemsetAsync(w.group_bits, 0, w.bits_bytes, pgx::stream()));
-    hipLaunchKernelGGL(k_adsr_edges<MODE>, dim3((unsigned)pgx::ceil_div(waves, 4)), dim3(256), 0, pgx::stream(),
+    const int64_t edge_waves = (int64_t)batch * pgx::ceil_div(w.nchunks, kEdgeRun);
+    hipLaunchKernelGGL(k_adsr_edges<MODE>, dim3((unsigned)pgx::ceil_div(edge_waves, 4)), dim3(256), 0, pgx::stream(),
                        w.masks, w.group_bits, w.last_gate, ctl, ctl_stride, batch, start, n, w.nchunks, w.gwords,
                        gates, (const double *)state);
     PGX_LAUNCH_CHECK("k_adsr_edges");
+    if (detach_walk) {
+        // the walk is one latency-bound wave per envelope: it runs behind the edges on the side stream
+        // and leaves the main stream (and nearly all of the machine) to the caller until pgx_stream_join()
+        int rc = pgx_stream_fork();
+        if (rc != PGX_OK) return rc;
+    }
     hipLaunchKernelGGL(k_adsr_walk<MODE == 1>, dim3((batch + 3) / 4), dim3(256), 0, pgx::stream(), out, out_stride,
                        batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
                        (const unsigned long long *)w.group_bits, (const float *)w.last_gate, state);
     PGX_LAUNCH_CHECK("k_adsr_walk");
+    if (detach_walk) return pgx_stream_select(0);
     return PGX_OK;
 }
 
@@ -381,12 +441,13 @@ int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t ga
 
 int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                             const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
-                            void *workspace) {
+                            void *workspace, int detach_walk) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && gates && params && state && workspace, "pgx_adsr_gated_periodic: null pointer");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_adsr_gated_periodic: stride too small");
-    return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, state, workspace);
+    return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, state, workspace,
+                          detach_walk != 0);
 }
 
 int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride, int batch,

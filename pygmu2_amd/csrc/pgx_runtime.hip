@@ -3,6 +3,12 @@
 // Host-side plumbing for the C ABI in include/pygmu_hip.h.  The pool keeps freed blocks in
 // power-of-two size classes; because every kernel and copy is ordered on the one library
 // stream, a block may be handed out again as soon as it is freed.
+//
+// Fork / join: two independent sub-graphs of one block (a voice bank's envelopes and its
+// oscillator -> filter chain) may run concurrently.  pgx_stream_fork() starts a side stream behind
+// everything enqueued so far; between fork and join the caller picks the stream each call goes
+// to; pgx_stream_join() orders the main stream after the side stream.  While forked, freed blocks
+// are parked instead of re-pooled, because "freed = reusable" only holds in single-stream order.
 
 #include <map>
 #include <mutex>
@@ -18,7 +24,12 @@ thread_local std::string g_last_error;
 struct Runtime {
     bool ready = false;
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // main stream
+    hipStream_t side = nullptr;            // second stream, used between fork and join
+    hipStream_t current = nullptr;         // where the next call is enqueued
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false;
+    std::vector<void *> parked;            // blocks freed while forked (re-pooled at join)
     std::mutex mu;
     std::map<size_t, std::vector<void *>> free_lists;   // size class -> blocks
     std::unordered_map<void *, size_t> live;             // ptr -> size class
@@ -47,7 +58,7 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
-hipStream_t stream() { return rt().stream; }
+hipStream_t stream() { return rt().current; }
 bool initialised() { return rt().ready; }
 
 }  // namespace pgx
@@ -85,6 +96,17 @@ int pgx_init(int device) {
     PGX_CHECK_ARG(device >= 0 && device < n, "pgx_init: device index out of range");
     PGX_HIP(hipSetDevice(device));
     PGX_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    {
+        // the side stream carries the latency-bound branch of a fork: give it queue priority so that its
+        // short throughput phases are not stretched by the main stream's VALU-bound kernels
+        int least = 0, greatest = 0;
+        PGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        PGX_HIP(hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, greatest));
+    }
+    PGX_HIP(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
+    PGX_HIP(hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming));
+    r.current = r.stream;
+    r.forked = false;
     r.device = device;
     r.ready = true;
     return PGX_OK;
@@ -95,6 +117,7 @@ int pgx_pool_trim(void) {
     std::lock_guard<std::mutex> lock(r.mu);
     if (!r.ready) return PGX_OK;
     (void)hipStreamSynchronize(r.stream);
+    (void)hipStreamSynchronize(r.side);
     for (auto &kv : r.free_lists)
         for (void *p : kv.second) (void)hipFree(p);
     r.free_lists.clear();
@@ -109,8 +132,14 @@ int pgx_shutdown(void) {
     std::lock_guard<std::mutex> lock(r.mu);
     for (auto &kv : r.live) (void)hipFree(kv.first);
     r.live.clear();
+    for (void *p : r.parked) (void)hipFree(p);
+    r.parked.clear();
     (void)hipStreamDestroy(r.stream);
-    r.stream = nullptr;
+    (void)hipStreamDestroy(r.side);
+    (void)hipEventDestroy(r.ev_fork);
+    (void)hipEventDestroy(r.ev_join);
+    r.stream = r.side = r.current = nullptr;
+    r.forked = false;
     r.ready = false;
     r.device = -1;
     return PGX_OK;
@@ -130,6 +159,47 @@ void *pgx_stream_handle(void) { return (void *)rt().stream; }
 int pgx_stream_sync(void) {
     PGX_REQUIRE_INIT();
     PGX_HIP(hipStreamSynchronize(rt().stream));
+    if (rt().forked) PGX_HIP(hipStreamSynchronize(rt().side));
+    return PGX_OK;
+}
+
+int pgx_stream_fork(void) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(!r.forked, "pgx_stream_fork: already forked");
+    PGX_HIP(hipEventRecord(r.ev_fork, r.stream));
+    PGX_HIP(hipStreamWaitEvent(r.side, r.ev_fork, 0));
+    r.forked = true;
+    r.current = r.side;
+    return PGX_OK;
+}
+
+int pgx_stream_select(int side) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(r.forked, "pgx_stream_select: not forked");
+    r.current = side ? r.side : r.stream;
+    return PGX_OK;
+}
+
+int pgx_stream_join(void) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(r.forked, "pgx_stream_join: not forked");
+    PGX_HIP(hipEventRecord(r.ev_join, r.side));
+    PGX_HIP(hipStreamWaitEvent(r.stream, r.ev_join, 0));
+    r.forked = false;
+    r.current = r.stream;
+    std::lock_guard<std::mutex> lock(r.mu);
+    for (void *p : r.parked) {                      // single-stream order holds again from here on
+        auto it = r.live.find(p);
+        if (it == r.live.end()) continue;
+        const size_t cls = it->second;
+        r.live.erase(it);
+        r.free_lists[cls].push_back(p);
+        r.bytes_cached += cls;
+    }
+    r.parked.clear();
     return PGX_OK;
 }
 
@@ -174,6 +244,10 @@ int pgx_free(void *dptr) {
     std::lock_guard<std::mutex> lock(r.mu);
     auto it = r.live.find(dptr);
     if (it == r.live.end()) return pgx::fail(PGX_ERR_INVALID, "pgx_free: unknown pointer");
+    if (r.forked) {                                  // two streams in flight: park until the join
+        r.parked.push_back(dptr);
+        return PGX_OK;
+    }
     size_t cls = it->second;
     r.live.erase(it);
     r.free_lists[cls].push_back(dptr);
@@ -185,7 +259,7 @@ int pgx_memset(void *dptr, int byte_value, size_t bytes) {
     PGX_REQUIRE_INIT();
     if (bytes == 0) return PGX_OK;
     PGX_CHECK_ARG(dptr != nullptr, "pgx_memset: null pointer");
-    PGX_HIP(hipMemsetAsync(dptr, byte_value, bytes, rt().stream));
+    PGX_HIP(hipMemsetAsync(dptr, byte_value, bytes, rt().current));
     return PGX_OK;
 }
 
@@ -193,8 +267,8 @@ int pgx_memcpy_h2d(void *dst, const void *src_host, size_t bytes) {
     PGX_REQUIRE_INIT();
     if (bytes == 0) return PGX_OK;
     PGX_CHECK_ARG(dst != nullptr && src_host != nullptr, "pgx_memcpy_h2d: null pointer");
-    PGX_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, rt().stream));
-    PGX_HIP(hipStreamSynchronize(rt().stream));
+    PGX_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, rt().current));
+    PGX_HIP(hipStreamSynchronize(rt().current));
     return PGX_OK;
 }
 
@@ -202,8 +276,8 @@ int pgx_memcpy_d2h(void *dst_host, const void *src, size_t bytes) {
     PGX_REQUIRE_INIT();
     if (bytes == 0) return PGX_OK;
     PGX_CHECK_ARG(dst_host != nullptr && src != nullptr, "pgx_memcpy_d2h: null pointer");
-    PGX_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, rt().stream));
-    PGX_HIP(hipStreamSynchronize(rt().stream));
+    PGX_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, rt().current));
+    PGX_HIP(hipStreamSynchronize(rt().current));
     return PGX_OK;
 }
 
@@ -211,7 +285,7 @@ int pgx_memcpy_d2d(void *dst, const void *src, size_t bytes) {
     PGX_REQUIRE_INIT();
     if (bytes == 0) return PGX_OK;
     PGX_CHECK_ARG(dst != nullptr && src != nullptr, "pgx_memcpy_d2d: null pointer");
-    PGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().stream));
+    PGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().current));
     return PGX_OK;
 }
 

@@ -630,27 +630,40 @@ struct BqSettledPlan {
 
 BqSettledPlan biquad_settled_plan(int batch, int64_t n, int channels, int64_t settle_frames, bool have_tables) {
     BqSettledPlan p{};
-    if (settle_frames <= 0 || !have_tables) return p;
+    if (!have_tables) return p;
     const int64_t halves = pgx::ceil_div(n, kSbHalf);
-    const int64_t warm = pgx::ceil_div(settle_frames, kSbHalf);
-    if (warm > kSbMaxWarm) return p;
     const int64_t chains = (int64_t)batch * channels;
-    int64_t want = 512 / chains;                               // two resident workgroups per CU, one round
-    if (want < 1) want = 1;
-    int64_t seg = pgx::ceil_div(halves, want);
-    if (seg < warm) seg = warm;                                // warm-up never exceeds the rendered part
-    const int64_t head = seg / 2 > warm ? seg / 2 : warm;      // workgroup 0: head + tail ~ one segment
-    const int64_t tail = seg - head > 1 ? seg - head : 1;
-    if (halves <= head + tail) return p;                       // short chain: the plain path is one workgroup
-    p.ok = true;
-    p.seg = (int)seg;
-    p.head = (int)head;
-    p.tail = (int)tail;
-    p.warm = (int)warm;
-    p.groups = 1 + (int)pgx::ceil_div(halves - head - tail, seg);
+    const int64_t warm = pgx::ceil_div(settle_frames, kSbHalf);
+    if (settle_frames > 0 && warm <= kSbMaxWarm) {
+        int64_t want = 512 / chains;                           // two resident workgroups per CU, one round
+        if (want < 1) want = 1;
+        int64_t seg = pgx::ceil_div(halves, want);
+        if (seg < warm) seg = warm;                            // warm-up never exceeds the rendered part
+        const int64_t head = seg / 2 > warm ? seg / 2 : warm;  // workgroup 0: head + tail ~ one segment
+        const int64_t tail = seg - head > 1 ? seg - head : 1;
+        if (halves > head + tail) {
+            p.ok = true;
+            p.seg = (int)seg;
+            p.head = (int)head;
+            p.tail = (int)tail;
+            p.warm = (int)warm;
+            p.groups = 1 + (int)pgx::ceil_div(halves - head - tail, seg);
+            return p;
+        }
+    }
+    // One workgroup per chain over the whole block: nothing is assumed (the carried state is read, no
+    // warm-up), this is just the faster tile engine.  Worth it when the chains alone fill the machine
+    // (voice banks) or the block is a tile or two; long lone chains keep the segment-parallel exact pair.
+    if (chains >= 64 || halves <= 2) {
+        p.ok = true;
+        p.seg = (int)halves;
+        p.head = (int)halves;
+        p.tail = 0;
+        p.warm = 0;
+        p.groups = 1;
+    }
     return p;
 }
-
 
 BqPlan biquad_plan(int batch, int64_t n, int channels) {
     int64_t tiles = pgx::ceil_div(n, kBqTile);
@@ -1346,7 +1359,8 @@ extern "C" {
 
 size_t pgx_biquad_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames) {
     if (batch <= 0 || n <= 0 || channels <= 0) return 0;
-    if (biquad_settled_plan(batch, n, channels, settle_frames, true).ok) return 0;
+    // a caller that passes settle_frames > 0 also passes tables; without them the exact pair may run
+    if (settle_frames > 0 && biquad_settled_plan(batch, n, channels, settle_frames, true).ok) return 0;
     BqPlan p = biquad_plan(batch, n, channels);
     if (p.nseg <= 1) return 0;
     size_t chains = (size_t)batch * channels;
@@ -1376,7 +1390,7 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
     int chains = batch * channels;
     const BqSettledPlan sp = biquad_settled_plan(batch, n, channels, settle_frames, tables != nullptr);
     if (sp.ok) {
-        const dim3 grid((sp.groups + 7) / 8 * 8, chains);
+        const dim3 grid(sp.groups == 1 ? 1 : (sp.groups + 7) / 8 * 8, chains);
         if (channels == 1)
             hipLaunchKernelGGL((k_biquad_settled<true, true>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
                                out_stride, in, in_stride, n, channels, coef, tables, state, sp.seg, sp.head,

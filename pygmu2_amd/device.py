@@ -43,6 +43,9 @@ _SIGNATURES = [
     ("pgx_device_name", _I, [C.c_char_p, _Z]),
     ("pgx_stream_handle", _P, []),
     ("pgx_stream_sync", _I, []),
+    ("pgx_stream_fork", _I, []),
+    ("pgx_stream_select", _I, [_I]),
+    ("pgx_stream_join", _I, []),
     ("pgx_malloc", _I, [C.POINTER(_P), _Z]),
     ("pgx_free", _I, [_P]),
     ("pgx_pool_trim", _I, []),
@@ -91,7 +94,7 @@ _SIGNATURES = [
     ("pgx_periodic_trigger", _I, [_P, _L, _L, _L, _L, _F]),
     ("pgx_adsr_workspace_bytes", _Z, [_I, _L]),
     ("pgx_adsr_gated", _I, [_P, _L, _P, _L, _I, _L, _P, _P, _P]),
-    ("pgx_adsr_gated_periodic", _I, [_P, _L, _I, _L, _L, _P, _P, _P, _P]),
+    ("pgx_adsr_gated_periodic", _I, [_P, _L, _I, _L, _L, _P, _P, _P, _P, _I]),
     ("pgx_adsr_triggered", _I, [_P, _L, _P, _L, _I, _L, _L, _P, _P, _P]),
     ("pgx_convolve_workspace_bytes", _Z, [_L, _L, _I]),
     ("pgx_convolve", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P]),

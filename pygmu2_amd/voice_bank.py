@@ -148,6 +148,7 @@ class _BiquadNode(_Node):
         coef = np.array([rbj_coefficients(pe._mode, pe._frequency, pe._q, pe._gain_db, self.sr)
                          for pe in pes], dtype=np.float64)
         self.coef = DeviceBuffer.from_host(coef)
+        self.tables = None           # per-voice powers of A (pgx_biquad_tables), made on first render
         self.state = None
         self.ws = None
 
@@ -165,12 +166,17 @@ class _BiquadNode(_Node):
         ch = x.shape[2]
         if self.state is None:
             self.state = DeviceBuffer((self.k, ch, 2), np.float64, zero=True)
+        if self.tables is None:
+            self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
+            check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
+        # settle_frames = 0: a bank has a workgroup per voice, nothing is gained by cutting voices in time
         need = L.pgx_biquad_workspace_bytes(self.k, n, ch, 0)
         if need and (self.ws is None or self.ws.nbytes < need):
             self.ws = DeviceBuffer((need,), np.uint8)
         out = DeviceBuffer((self.k, n, ch), np.float32)
-        check(L.pgx_biquad_const(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.coef.ptr, None, 0,
-                                 self.state.ptr, ptr(self.ws) if need else None), "pgx_biquad_const")
+        check(L.pgx_biquad_const(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.coef.ptr,
+                                 self.tables.ptr, 0, self.state.ptr, ptr(self.ws) if need else None),
+              "pgx_biquad_const")
         return out
 
 
@@ -253,14 +259,19 @@ class _AdsrGatedNode(_Node):
     def channels(self):
         return 1
 
-    def render(self, start, n):
+    def fused_gate(self) -> bool:
+        return isinstance(self.children["gate"], _GateNode)
+
+    def render(self, start, n, detach=False):
+        """detach=True (fused gate only): the envelope walk is left running on the side stream;
+        the caller joins (pgx_stream_join) before using the result."""
         out = DeviceBuffer((self.k, n, 1), np.float32)
         gate_node = self.children["gate"]
         if isinstance(gate_node, _GateNode):
             # PeriodicGate feeding the envelope: evaluate the gate inside the envelope kernel
             check(lib().pgx_adsr_gated_periodic(out.ptr, n, self.k, start, n, gate_node.params.ptr,
-                                                self.params.ptr, self.state.ptr, self._scratch(n).ptr),
-                  "pgx_adsr_gated_periodic")
+                                                self.params.ptr, self.state.ptr, self._scratch(n).ptr,
+                                                1 if detach else 0), "pgx_adsr_gated_periodic")
             return out
         gate = gate_node.render(start, n)
         check(lib().pgx_adsr_gated(out.ptr, n, gate.ptr, n, self.k, n, self.params.ptr, self.state.ptr,
@@ -381,9 +392,26 @@ class VoiceBank:
     def render_mix(self, start: int, duration: int) -> Snippet:
         root = self.root
         if isinstance(root, _GainNode) and root.gains is None:
-            # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix
-            x = root.children["source"].render(start, duration)
-            g = root.children["gain"].render(start, duration)
+            # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix.  The gain
+            # sub-graph (envelopes: few, latency-bound waves) and the signal sub-graph (oscillators and
+            # filters: VALU-bound) share nothing, so they are enqueued on two streams and overlap.
+            L = lib()
+            gain = root.children["gain"]
+            if isinstance(gain, _AdsrGatedNode) and gain.fused_gate():
+                # edge search first (parallel, short), then the walk detached on the side stream
+                g = gain.render(start, duration, detach=True)
+                try:
+                    x = root.children["source"].render(start, duration)
+                finally:
+                    check(L.pgx_stream_join(), "pgx_stream_join")
+            else:
+                check(L.pgx_stream_fork(), "pgx_stream_fork")
+                try:
+                    g = gain.render(start, duration)
+                    check(L.pgx_stream_select(0), "pgx_stream_select")
+                    x = root.children["source"].render(start, duration)
+                finally:
+                    check(L.pgx_stream_join(), "pgx_stream_join")
             ch, gch = x.shape[2], g.shape[2]
             out = DeviceBuffer((duration, ch), np.float32)
             check(lib().pgx_gain_mix_batch(out.ptr, x.ptr, duration * ch, g.ptr, duration * gch, self.k,

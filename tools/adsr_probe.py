@@ -23,7 +23,7 @@ def run(name, gate=None, gates=None, reps=20):
         if gate is not None:
             device.check(lib.pgx_adsr_gated(out.ptr, n, g.ptr, n, K, n, params.ptr, state.ptr, ws.ptr))
         else:
-            device.check(lib.pgx_adsr_gated_periodic(out.ptr, n, K, i * n, n, gates.ptr, params.ptr, state.ptr, ws.ptr))
+            device.check(lib.pgx_adsr_gated_periodic(out.ptr, n, K, i * n, n, gates.ptr, params.ptr, state.ptr, ws.ptr, 0))
     for i in range(3):
         launch(i)
     e0, e1 = device.Event(), device.Event()
