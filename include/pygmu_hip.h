@@ -361,6 +361,22 @@ int pgx_convolve(float *out, const float *x, int64_t n, int src_channels,
                  const float *h, int64_t fir_len, int fir_channels, int out_channels,
                  float *hist, void *workspace);
 
+/* Long filters: the same convolution by float64 FFT overlap-save, hand-written (four-step N1 x N2
+ * decomposition, Stockham radix-4 FFTs of 4096 points per workgroup in LDS, spectrum kept in the
+ * order the forward pass produces it, two real blocks packed per complex transform).
+ *   fft_size = pgx_convolve_fft_size(L): power of two >= 2L in [4096, 262144], 0 if L is too long
+ *   spectrum: pgx_convolve_fft_spectrum_bytes(...) bytes, filled once per filter by _prepare
+ *   workspace >= pgx_convolve_fft_workspace_bytes(n, L, out_ch, fft_size)
+ * x, hist, out as for pgx_convolve; hist is updated in place. */
+int64_t pgx_convolve_fft_size(int64_t fir_len);
+size_t pgx_convolve_fft_spectrum_bytes(int64_t fft_size, int fir_channels);
+size_t pgx_convolve_fft_workspace_bytes(int64_t n, int64_t fir_len, int out_channels, int64_t fft_size);
+int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, int fir_channels,
+                             int64_t fft_size);
+int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, const void *spectrum,
+                     int64_t fir_len, int fir_channels, int out_channels, int64_t fft_size,
+                     float *hist, void *workspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ SOURCES = [
     "pgx_adsr.hip",
     "pgx_convolve.hip",
     "pgx_lookup.hip",
+    "pgx_fftconv.hip",
 ]
 
 # -ffp-contract=off: the parity contract is "same float64 operation order as the reference's

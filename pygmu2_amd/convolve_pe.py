@@ -3,12 +3,14 @@ ConvolvePE: streaming convolution y = src * fir with a finite FIR PE
 (convolve_pe.py:40-349).
 
 The reference computes the linear convolution by float64 FFT overlap-save with an
-(L-1)-sample input history; this PE computes the identical sum as a dense
-Toeplitz x Hankel product on the MI355X f32 matrix cores with float64 accumulation
-across 1024-tap slabs (pgx_convolve), keeping the same history semantics: the history
-is cleared when a render is not contiguous with the previous one.  `fft_size` is kept
-for API compatibility and validated like the reference does, but does not influence
-the result (overlap-save output is independent of the FFT size).
+(L-1)-sample input history.  Two device evaluations of the identical sum, same history
+semantics (cleared when a render is not contiguous with the previous one):
+  * filters shorter than FFT_MIN_TAPS: a dense Toeplitz x Hankel product on the MI355X f32
+    matrix cores with float64 accumulation across 1024-tap slabs (pgx_convolve);
+  * longer filters (up to 131 072 taps): hand-written float64 FFT overlap-save
+    (pgx_convolve_fft), like the reference but resident in HBM.
+`fft_size` is kept for API compatibility and validated like the reference does, but does
+not influence the result (overlap-save output is independent of the FFT size).
 
 Channel rules (convolve_pe.py:114-144,207-223): mono FIR -> applied to every source
 channel; FIR channels == source channels -> per-channel; mono source + N-channel FIR ->
@@ -25,6 +27,11 @@ from ._kernels import DeviceBuffer, check, lib, new_output
 from .extent import Extent
 from .processing_element import ProcessingElement
 from .snippet import Snippet
+
+
+# Crossover between the direct MFMA form (time ~ L) and the FFT form (time ~ flat), measured on MI355X
+# for stereo 96 000-frame blocks: see DESIGN.md section 7.
+FFT_MIN_TAPS = 8192
 
 
 def _next_pow2(n: int) -> int:
@@ -45,6 +52,8 @@ class ConvolvePE(ProcessingElement):
         self._out_ch = 0
         self._hist: DeviceBuffer | None = None       # (L-1, out_ch) float32
         self._workspace: DeviceBuffer | None = None
+        self._device_fft = 0                         # transform size of the FFT path, 0 = direct MFMA form
+        self._spectrum: DeviceBuffer | None = None   # filter spectrum of the FFT path
         self._last_render_end: int | None = None
 
     src = property(lambda self: self._src)
@@ -132,6 +141,17 @@ class ConvolvePE(ProcessingElement):
         self._fir_len, self._fir_ch, self._out_ch = length, fir_ch, out_ch
         self._h = h.dev
         self._hist = DeviceBuffer((max(length - 1, 1), out_ch), np.float32, zero=True)
+        # Long filters: float64 FFT overlap-save on the device (the direct MFMA form costs 2*L flops per
+        # sample; the FFT form a few hundred).  The library picks its own transform size; the reference's
+        # fft_size only shapes ITS block loop and does not change the result.
+        self._device_fft = 0
+        if length >= FFT_MIN_TAPS:
+            self._device_fft = int(lib().pgx_convolve_fft_size(length))
+        if self._device_fft:
+            L = lib()
+            self._spectrum = DeviceBuffer((L.pgx_convolve_fft_spectrum_bytes(self._device_fft, fir_ch),), np.uint8)
+            check(L.pgx_convolve_fft_prepare(self._spectrum.ptr, self._h.ptr, length, fir_ch, self._device_fft),
+                  "pgx_convolve_fft_prepare")
 
     def _render(self, start: int, duration: int) -> Snippet:
         self._prepare()
@@ -149,13 +169,21 @@ class ConvolvePE(ProcessingElement):
         if src_ch != 1 and src_ch != out_ch:
             raise ValueError(f"ConvolvePE src channels ({src_ch}) incompatible with output channels ({out_ch})")
         L = lib()
-        need = L.pgx_convolve_workspace_bytes(duration, length, out_ch)
+        if self._device_fft:
+            need = L.pgx_convolve_fft_workspace_bytes(duration, length, out_ch, self._device_fft)
+        else:
+            need = L.pgx_convolve_workspace_bytes(duration, length, out_ch)
         if self._workspace is None or self._workspace.nbytes < need:
             self._workspace = None
             self._workspace = DeviceBuffer((need,), np.uint8)
         out = new_output(duration, out_ch)
-        check(L.pgx_convolve(out.ptr, x.dev.ptr, duration, src_ch, self._h.ptr, length, self._fir_ch,
-                             out_ch, self._hist.ptr, self._workspace.ptr), "pgx_convolve")
+        if self._device_fft:
+            check(L.pgx_convolve_fft(out.ptr, x.dev.ptr, duration, src_ch, self._spectrum.ptr, length,
+                                     self._fir_ch, out_ch, self._device_fft, self._hist.ptr,
+                                     self._workspace.ptr), "pgx_convolve_fft")
+        else:
+            check(L.pgx_convolve(out.ptr, x.dev.ptr, duration, src_ch, self._h.ptr, length, self._fir_ch,
+                                 out_ch, self._hist.ptr, self._workspace.ptr), "pgx_convolve")
         self._last_render_end = start + duration
         return Snippet(start, out)
 

@@ -787,7 +787,9 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             const double m_theta = kc[j].m * theta;
             const double sin_num = pgx::pgx_sin(m_theta);
             const double sin_den = pgx::pgx_sin(theta);
-            const double blit = (fabs(sin_den) < 1e-9) ? (kc[j].m / kc[j].P) : (sin_num / (kc[j].P * sin_den));
+            // |P*sin_den| >= 1e-9: a Newton-refined reciprocal (<= 1 ulp) replaces the IEEE division sequence
+            const double blit = (fabs(sin_den) < 1e-9) ? (kc[j].m / kc[j].P)
+                                                       : pgx::pgx_div_fast(sin_num, kc[j].P * sin_den);
             xb[j] = (f0 + j < n) ? (blit - kc[j].invP) : 0.0;
             if (f0 + j == n - 1) {
                 final_phase = ph;

@@ -77,6 +77,11 @@ _SIGNATURES = [
     ("pgx_biquad_tables", _I, [_P, _P, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _L, _P, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
+    ("pgx_convolve_fft_size", _L, [_L]),
+    ("pgx_convolve_fft_spectrum_bytes", _Z, [_L, _I]),
+    ("pgx_convolve_fft_workspace_bytes", _Z, [_L, _L, _I, _L]),
+    ("pgx_convolve_fft_prepare", _I, [_P, _P, _L, _I, _L]),
+    ("pgx_convolve_fft", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _L, _P, _P]),
     ("pgx_interp_lookup", _I, [_P, _P, _L, _L, _I, _L, _L, _D, _P, _I, _I, _D, _D]),
     ("pgx_index_range", _I, [_P, _P, _L, _L]),
     ("pgx_piecewise", _I, [_P, _L, _L, _I, _P, _P, _I, _I, _I, _I]),

@@ -1,0 +1,117 @@
+"""
+GPU: the FFT overlap-save path of ConvolvePE (pgx_convolve_fft) against numpy's float64
+convolution and against the direct MFMA path, over geometries that exercise every branch:
+square and non-square N1 x N2, odd and even numbers of overlap-save blocks (packed pairs),
+blocks shorter than the filter, carried history, every channel rule.
+"""
+
+import numpy as np
+import pytest
+from scipy.signal import fftconvolve
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from pygmu2_amd import device
+    device.ensure_init()
+    return device
+
+
+def _fft_conv(dev, x, h, hist, fft_size):
+    lib = dev.ensure_init()
+    n, src_ch = x.shape
+    L, fir_ch = h.shape
+    out_ch = max(src_ch, fir_ch)
+    hd = dev.DeviceBuffer.from_host(h)
+    spec = dev.DeviceBuffer((lib.pgx_convolve_fft_spectrum_bytes(fft_size, fir_ch),), np.uint8)
+    dev.check(lib.pgx_convolve_fft_prepare(spec.ptr, hd.ptr, L, fir_ch, fft_size))
+    xd = dev.DeviceBuffer.from_host(x)
+    histd = dev.DeviceBuffer.from_host(hist)
+    ws = dev.DeviceBuffer((lib.pgx_convolve_fft_workspace_bytes(n, L, out_ch, fft_size),), np.uint8)
+    out = dev.DeviceBuffer((n, out_ch), np.float32)
+    dev.check(lib.pgx_convolve_fft(out.ptr, xd.ptr, n, src_ch, spec.ptr, L, fir_ch, out_ch, fft_size, histd.ptr,
+                                   ws.ptr))
+    return out.to_host(), histd.to_host()
+
+
+def _numpy_conv(x, h, hist):
+    n, src_ch = x.shape
+    L, fir_ch = h.shape
+    out_ch = max(src_ch, fir_ch)
+    y = np.zeros((n, out_ch))
+    new_hist = np.zeros_like(hist)
+    for c in range(out_ch):
+        xc = x[:, 0 if src_ch == 1 else c].astype(np.float64)
+        hc = h[:, 0 if fir_ch == 1 else c].astype(np.float64)
+        ext = np.concatenate([hist[:, c].astype(np.float64), xc])
+        y[:, c] = fftconvolve(ext, hc)[L - 1:L - 1 + n]          # float64, ~1e-13: a reference, not the oracle
+        new_hist[:, c] = ext[n:n + L - 1]
+    return y, new_hist
+
+
+@pytest.mark.parametrize("L,n,fft_size", [
+    (300, 2500, 4096),          # N1 = N2 = 64, one block
+    (2000, 9000, 4096),         # 5 blocks: odd count -> last pair half empty
+    (3000, 1000, 8192),         # block shorter than the filter, N1 = 64, N2 = 128
+    (5000, 40000, 16384),       # 128 x 128
+    (20000, 70000, 65536),      # 256 x 256, two blocks
+    (65536, 96000, 131072),     # C3: 256 x 512
+    (100000, 30000, 262144),    # 512 x 512
+])
+@pytest.mark.parametrize("src_ch,fir_ch", [(1, 1), (2, 1), (2, 2), (1, 2)])
+def test_fft_conv_matches_numpy(dev, L, n, fft_size, src_ch, fir_ch):
+    if L >= 65536 and (src_ch, fir_ch) not in ((2, 1), (2, 2)):
+        pytest.skip("big cases: two channel layouts are enough")
+    rng = np.random.default_rng(L + n)
+    out_ch = max(src_ch, fir_ch)
+    x = (rng.standard_normal((n, src_ch)) * 0.1).astype(np.float32)
+    h = (rng.standard_normal((L, fir_ch)) * np.exp(-np.arange(L) / (L / 8.0))[:, None]).astype(np.float32)
+    hist = (rng.standard_normal((L - 1, out_ch)) * 0.1).astype(np.float32)
+    got, got_hist = _fft_conv(dev, x, h, hist, fft_size)
+    want, want_hist = _numpy_conv(x, h, hist)
+    peak = float(np.max(np.abs(want)))
+    err = float(np.max(np.abs(got.astype(np.float64) - want)))
+    assert err <= 1e-6 * peak, (err, peak)              # float64 transforms: float32 rounding only
+    assert np.array_equal(got_hist, want_hist.astype(np.float32))
+
+
+def test_fft_size_rule_and_argument_checks(dev):
+    lib = dev.ensure_init()
+    assert lib.pgx_convolve_fft_size(1) == 4096
+    assert lib.pgx_convolve_fft_size(2049) == 8192
+    assert lib.pgx_convolve_fft_size(65536) == 131072
+    assert lib.pgx_convolve_fft_size(131072) == 262144
+    assert lib.pgx_convolve_fft_size(131073) == 0                      # too long: the caller stays on pgx_convolve
+    assert lib.pgx_convolve_fft_workspace_bytes(1000, 300, 2, 3000) == 0     # not a power of two
+    assert lib.pgx_convolve_fft_workspace_bytes(1000, 5000, 2, 4096) == 0    # hop would be < 1
+
+
+def test_convolve_pe_streams_through_the_fft_path(dev):
+    """ConvolvePE with a 20 000-tap filter in uneven blocks == one numpy convolution."""
+    import pygmu2_amd as pg
+    from pygmu2_amd import convolve_pe
+    pg.set_sample_rate(48000)
+    rng = np.random.default_rng(8)
+    L, T = 20000, 150_000
+    assert L >= convolve_pe.FFT_MIN_TAPS
+    x = (rng.standard_normal((T, 2)) * 0.1).astype(np.float32)
+    h = (rng.standard_normal(L) * np.exp(-np.arange(L) / 3000.0)).astype(np.float32)
+    pe = pg.ConvolvePE(pg.ArrayPE(x), pg.ArrayPE(h))
+    r = pg.NullRenderer(sample_rate=48000)
+    r.set_source(pe)
+    r.start()
+    sizes = [48000, 17, 30000, 1, 71982]
+    pos, parts = 0, []
+    for n in sizes:
+        parts.append(pe.render(pos, n).data)
+        pos += n
+    r.stop()
+    assert pe._device_fft == 65536
+    got = np.concatenate(parts)
+    want = np.stack([fftconvolve(x[:, c].astype(np.float64), h.astype(np.float64))[:T] for c in range(2)], axis=1)
+    peak = float(np.max(np.abs(want)))
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= REL_TOL * peak
