@@ -284,6 +284,44 @@ def conv_kernel_roofline(pg, frames, launches):
             "frames_per_launch": frames, "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(ms, 6)}
 
 
+def conv_fft_roofline(pg, frames, launches):
+    """HIP-event timing of pgx_convolve_fft (the path ConvolvePE takes for the 65 536-tap C3 filter)."""
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+    x, h = c3_inputs(frames)
+    L = 65536
+    nfft = lib.pgx_convolve_fft_size(L)
+    xd, hd = device.DeviceBuffer.from_host(x), device.DeviceBuffer.from_host(h.reshape(-1, 1))
+    spec = device.DeviceBuffer((lib.pgx_convolve_fft_spectrum_bytes(nfft, 1),), np.uint8)
+    device.check(lib.pgx_convolve_fft_prepare(spec.ptr, hd.ptr, L, 1, nfft))
+    out = device.DeviceBuffer((frames, 2), np.float32)
+    hist = device.DeviceBuffer((L - 1, 2), np.float32, zero=True)
+    ws = device.DeviceBuffer((lib.pgx_convolve_fft_workspace_bytes(frames, L, 2, nfft),), np.uint8)
+
+    def launch():
+        device.check(lib.pgx_convolve_fft(out.ptr, xd.ptr, frames, 2, spec.ptr, L, 1, 2, nfft, hist.ptr, ws.ptr))
+
+    for _ in range(2):
+        launch()
+    e0, e1 = device.Event(), device.Event()
+    e0.record()
+    for _ in range(launches):
+        launch()
+    e1.record()
+    ms = e1.elapsed_ms_since(e0) / launches
+    algo_bytes = 4.0 * (2 + 2) * frames              # 4(C_in + C_out) per frame (SURVEY 8d); taps are read once
+    hop = nfft - (L - 1)
+    pairs = 2 * ((-(-frames // hop) + 1) // 2)
+    moved = 3.0 * 32.0 * nfft * pairs                # three passes, 16 B read + 16 B written per complex point
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "work_buffer_bytes_per_launch": moved,
+            "kernel": "k_fft_cols<fwd> + k_fft_rows + k_fft_cols<inv> + k_fft_hist (pgx_convolve_fft, "
+                      f"N={nfft}, float64)",
+            "frames_per_launch": frames, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms, 6)}
+
+
 def cpu_c3(frames=96_000, budget_s=6.0):
     from oracle import pe_oracle as O
     x, h = c3_inputs(frames)
@@ -362,7 +400,11 @@ def main():
             cases["c1_sine_gain_1024_blocks"] = {"value": round(f1 * 5 / dt1 / 1e6, 3), "unit": "Msamples/s"}
             dt3, f3 = bench_c3(pg, Dist(1), 10, 2)
             cases["c3_convolve_64k_taps"] = {"value": round(f3 * 10 / dt3 / 1e6, 3), "unit": "Msamples/s",
-                                             "roofline": conv_kernel_roofline(pg, 96_000, 10)}
+                                             "path": "float64 FFT overlap-save (pgx_convolve_fft)",
+                                             "roofline": conv_fft_roofline(pg, 96_000, 20),
+                                             # the dense FIR x block product on the matrix cores, same filter:
+                                             # what ConvolvePE uses below convolve_pe.FFT_MIN_TAPS taps
+                                             "direct_form_mfma": conv_kernel_roofline(pg, 96_000, 10)}
         if not args.no_cpu and n_gpus == 1:
             result["cpu_baseline"] = cpu_c2(1_000_000)
             if "c1_sine_gain_1024_blocks" in cases:

@@ -29,9 +29,10 @@ from .processing_element import ProcessingElement
 from .snippet import Snippet
 
 
-# Crossover between the direct MFMA form (time ~ L) and the FFT form (time ~ flat), measured on MI355X
-# for stereo 96 000-frame blocks: see DESIGN.md section 7.
-FFT_MIN_TAPS = 8192
+# Crossover between the direct MFMA form (time ~ L) and the FFT form (time ~ flat at 31-36 us up to
+# 65 536 taps), measured on MI355X for stereo 96 000-frame blocks (tools/conv_crossover.py): the direct
+# form is level with the FFT form up to 1024 taps (36 us) and 3x behind from 2048 on.
+FFT_MIN_TAPS = 2048
 
 
 def _next_pow2(n: int) -> int:
