@@ -1313,18 +1313,50 @@ k_env_onepole(float *out, const double *det, int64_t n, int channels, double coe
     if (have_final) state[ch] = final_y;
 }
 
-// attack != release (envelope_pe.py:259-271): data-dependent switch -> one lane per channel.
+// attack != release (envelope_pe.py:259-271): data-dependent switch -> one lane per channel, strictly
+// sequential (bit-exact).  The recurrence itself is four dependent float64 operations per sample; the
+// detector values are fetched 16 samples ahead and the outputs stored 16 at a time so that no memory
+// round trip sits on that chain (one per sample made it 10x slower than a CPU core).
+constexpr int kEnvChunk = 16;
+
 __global__ void __launch_bounds__(64)
 k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_coeff, double release_coeff,
          double *state) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= channels) return;
     double e = state[ch];
-    for (int64_t i = 0; i < n; ++i) {
-        const double target = det[i * channels + ch];
-        if (target > e) e = e + attack_coeff * (target - e);
-        else e = e + release_coeff * (target - e);
-        out[i * channels + ch] = (float)e;
+    const int64_t full = n / kEnvChunk * kEnvChunk;
+    const double *d = det + ch;
+    float *o = out + ch;
+    double next[kEnvChunk];
+    if (full > 0) {
+#pragma unroll
+        for (int j = 0; j < kEnvChunk; ++j) next[j] = d[(int64_t)j * channels];
+    }
+    for (int64_t base = 0; base < full; base += kEnvChunk) {
+        double cur[kEnvChunk];
+        float y[kEnvChunk];
+#pragma unroll
+        for (int j = 0; j < kEnvChunk; ++j) cur[j] = next[j];
+        // next chunk (the last iteration re-reads its own chunk: in bounds, unused)
+        const int64_t nb = (base + kEnvChunk < full) ? base + kEnvChunk : base;
+#pragma unroll
+        for (int j = 0; j < kEnvChunk; ++j) next[j] = d[(nb + j) * channels];
+#pragma unroll
+        for (int j = 0; j < kEnvChunk; ++j) {
+            // branch-free: pick the coefficient, then the reference's e + c*(target - e)
+            const double c = cur[j] > e ? attack_coeff : release_coeff;
+            e = e + c * (cur[j] - e);
+            y[j] = (float)e;
+        }
+#pragma unroll
+        for (int j = 0; j < kEnvChunk; ++j) o[(base + j) * channels] = y[j];
+    }
+    for (int64_t i = full; i < n; ++i) {
+        const double target = d[i * channels];
+        const double c = target > e ? attack_coeff : release_coeff;
+        e = e + c * (target - e);
+        o[i * channels] = (float)e;
     }
     state[ch] = e;
 }
