@@ -34,13 +34,15 @@ _MODE_INDEX = {m: i for i, m in enumerate(LadderMode)}
 
 
 def ladder_settle_frames(cutoff: float, resonance: float, sample_rate: float, oversample: int,
-                         limit: int = 16384) -> int:
+                         limit: int = 16384, target: float = 1e-11) -> int:
     """
-    Samples after which the ladder has forgotten its state to ~1e-12, from the small-signal
-    loop: four one-poles (pole 1 - alpha per sub-step, ladder_pe.py:103-113) closed with gain
-    k*q_adjust; the slowest closed-loop pole decays at alpha*(1 - k_fb^(1/4)/sqrt(2)) per
-    sub-step.  0 = do not segment (close to or above self-oscillation, or too slow a decay).
-    The device checks the outcome, so this only has to be a good guess.
+    Samples after which the ladder has forgotten its state to `target`: the smallest W for which
+    every entry of M^(W*oversample) is below it, M being the small-signal (tanh' = 1) transition
+    matrix of one sub-step over the states (z0[4], z1[4]) of ladder_pe.py:139-181 -- saturation only
+    lowers the loop gain, so the small-signal loop is the slowest to forget.  0 = do not segment
+    (at or above self-oscillation, or too slow a decay).  The device checks every segment to 1e-8 and
+    re-renders on failure, so this only has to be a good estimate; a block's run time is proportional
+    to it.
     """
     nyquist = sample_rate / 2.0
     fc = min(max(float(cutoff), 5.0), min(nyquist * 0.85, nyquist - 1.0))
@@ -48,11 +50,33 @@ def ladder_settle_frames(cutoff: float, resonance: float, sample_rate: float, ov
     alpha = 0.9892 * wc - 0.4324 * wc ** 2 + 0.1381 * wc ** 3 - 0.0202 * wc ** 4
     q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc ** 2 - 0.05 * wc ** 4
     k_fb = 4.0 * min(max(float(resonance), 0.0), 1.0) * 1.8 * q_adjust
-    if k_fb >= 3.0 or alpha <= 0.0:
-        return 0
-    rate = alpha * (1.0 - k_fb ** 0.25 / np.sqrt(2.0))
-    frames = int(np.ceil(1.5 * 27.6 / rate / oversample))
-    frames = (frames + 63) // 64 * 64
+    c0, c1 = 0.76923077, 0.23076923
+    # rows: new z0[0..3], new z1[0..3]; columns: old z0[0..3], old z1[0..3]
+    m = np.zeros((8, 8))
+    u = np.zeros(8)
+    u[7] = -k_fb                                   # stage input of stage 0: -(k*q_adjust) * z1[3]
+    stage_in = u
+    for j in range(4):
+        ft = alpha * c0 * stage_in
+        ft[j] += alpha * c1
+        ft[4 + j] += 1.0 - alpha
+        m[j] = stage_in                             # z0[j]' = this stage's input
+        m[4 + j] = ft                               # z1[j]' = its output
+        stage_in = ft.copy()
+    powers = [m]                                    # M^(2^k)
+    with np.errstate(over="ignore", invalid="ignore"):
+        while np.max(np.abs(powers[-1])) >= target:
+            if len(powers) > 18 or not np.all(np.isfinite(powers[-1])):
+                return 0
+            powers.append(powers[-1] @ powers[-1])
+        # smallest exponent: greedy over the bits below the first power that is already small enough
+        acc, steps = np.eye(8), 0
+        for k in range(len(powers) - 2, -1, -1):
+            trial = acc @ powers[k]
+            if np.max(np.abs(trial)) >= target:
+                acc, steps = trial, steps + (1 << k)
+        steps += 1
+    frames = (-(-steps // oversample) + 31) // 32 * 32
     return frames if frames <= limit else 0
 
 

@@ -324,3 +324,28 @@ def test_transform_descriptors_are_numpy_callables():
     pe = pg.TransformPE(pg.ConstantPE(1.0), func=tf.Affine(2.0, 1.0))
     assert pe.is_pure() and pe.name == "affine" and "func=affine" in repr(pe)
     assert pg.TransformPE(pg.ConstantPE(1.0), func=np.tanh, name="soft").name == "soft"
+
+
+def test_ladder_settle_estimate_follows_the_small_signal_loop():
+    from pygmu2_amd.ladder_pe import ladder_settle_frames as settle
+    base = settle(1200.0, 0.3, 48000, 2)
+    assert 500 < base < 3000 and base % 32 == 0
+    assert settle(1200.0, 0.0, 48000, 2) < base < settle(1200.0, 0.5, 48000, 2)   # resonance slows forgetting
+    assert settle(200.0, 0.3, 48000, 2) > base > settle(6000.0, 0.3, 48000, 2)    # so does a low cutoff
+    assert settle(1200.0, 0.6, 48000, 2) == 0          # k*q_adjust > 4: the linear loop oscillates
+    assert settle(2000.0, 1.0, 48000, 2) == 0
+    assert settle(20.0, 0.3, 48000, 2) == 0            # forgets too slowly to be worth segmenting
+    pe = pg.LadderPE(pg.ConstantPE(0.1), frequency=pg.SinePE(frequency=1.0, amplitude=100.0), resonance=0.3)
+    assert pe._settle_frames() == 0                    # PE-driven cutoff: always the sequential kernel
+
+
+def test_biquad_settle_frames_bounds_the_state_matrix():
+    from pygmu2_amd.biquad_pe import rbj_coefficients, settle_frames
+    c = rbj_coefficients(pg.BiquadMode.LOWPASS, 1000.0, 0.707, 0.0, 44100.0)
+    w = settle_frames(c[3], c[4])
+    assert w == 1024
+    a = np.array([[-c[3], 1.0], [-c[4], 0.0]])
+    assert np.max(np.abs(np.linalg.matrix_power(a, w))) < 2.0 ** -90
+    assert np.max(np.abs(np.linalg.matrix_power(a, w // 2))) >= 2.0 ** -90
+    assert settle_frames(-1.999, 0.9991) == 0          # poles at radius ~0.9995: no usable horizon
+    assert settle_frames(-2.1, 1.2) == 0               # unstable

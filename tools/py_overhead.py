@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
-"""Where does the host time of a small-block render go?  (GPU box; cProfile over the C1 loop.)"""
+"""Where does the host time of a small-block render go?  (GPU box; cProfile over a 1024-frame block loop.)
+argv[1]: c1 (GainPE(SinePE), pure) | c2 (BiquadPE(SinePE), stateful; default)"""
 import cProfile, pstats, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pygmu2_amd as pg
 from pygmu2_amd import device
 pg.set_sample_rate(44100)
-pe = pg.GainPE(pg.SinePE(440.0, 1.0, 0.0, channels=2), gain=0.5)
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+if which == "c1":
+    pe = pg.GainPE(pg.SinePE(440.0, 1.0, 0.0, channels=2), gain=0.5)
+else:
+    pe = pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707)
 r = pg.NullRenderer(44100); r.set_source(pe); r.start()
-def loop(nblk):
+def loop(nblk, base=0):
     keep = None
     for i in range(nblk):
-        keep = pe.render(i * 1024, 1024)
+        keep = pe.render((base + i) * 1024, 1024)
     device.synchronize()
-loop(500)
-t0 = time.perf_counter(); loop(4000); dt = time.perf_counter() - t0
-print(f"{dt / 4000 * 1e6:.2f} us per block (2 PE calls)")
-pr = cProfile.Profile(); pr.enable(); loop(4000); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+    return base + nblk
+pos = loop(500)
+t0 = time.perf_counter(); pos = loop(4000, pos); dt = time.perf_counter() - t0
+print(f"{which}: {dt / 4000 * 1e6:.2f} us per 1024-frame block = {1024 * 4000 / dt / 1e6:.1f} Msamples/s")
+pr = cProfile.Profile(); pr.enable(); pos = loop(4000, pos); pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
