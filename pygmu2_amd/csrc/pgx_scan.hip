@@ -1313,53 +1313,88 @@ k_env_onepole(float *out, const double *det, int64_t n, int channels, double coe
     if (have_final) state[ch] = final_y;
 }
 
-// attack != release (envelope_pe.py:259-271): data-dependent switch -> one lane per channel, strictly
-// sequential (bit-exact).  The recurrence itself is four dependent float64 operations per sample; the
-// detector values are fetched 16 samples ahead and the outputs stored 16 at a time so that no memory
-// round trip sits on that chain (one per sample made it 10x slower than a CPU core).
-constexpr int kEnvChunk = 16;
+// attack != release (envelope_pe.py:259-271):  e += (target > e ? attack : release) * (target - e).
+// The coefficient depends on the state, so this is not a linear scan -- but between two switches it
+// is one (e' = (1-c) e + c t with a constant c), and envelopes switch rarely: a few times per period of
+// the input.  One wave per channel walks 64-sample chunks: it takes the regime of the first open
+// sample (known from the carried level), scans the chunk as if that regime held to the end
+// (Kogge-Stone over affine maps, DPP), and accepts the samples up to the first one whose comparison
+// target > previous level contradicts the regime; the walk continues from there with the other
+// coefficient.  A chunk that needs more than kEnvMaxPasses passes (noise-like input) is finished one
+// sample at a time.  Levels come out of a scan instead of the literal sum: ~1e-16 relative, and a
+// comparison that flips at a near-tie picks between two branches that agree there.
+constexpr int kEnvMaxPasses = 10;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_keep(double old, double v) {     // lanes without a source keep `old`
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// (m, p) <- (m, p) o (pm, pp): apply the earlier map first
+#define ENV_COMPOSE(CTRL, MASK)                                        \
+    {                                                                  \
+        const double pm = dpp_f64_keep<CTRL, MASK>(1.0, m);            \
+        const double pp = dpp_f64_keep<CTRL, MASK>(0.0, p);            \
+        p = __builtin_fma(m, pp, p);                                   \
+        m = m * pm;                                                    \
+    }
 
 __global__ void __launch_bounds__(64)
 k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_coeff, double release_coeff,
          double *state) {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= channels) return;
-    double e = state[ch];
-    const int64_t full = n / kEnvChunk * kEnvChunk;
+    const int ch = blockIdx.x, lane = threadIdx.x;
     const double *d = det + ch;
     float *o = out + ch;
-    double next[kEnvChunk];
-    if (full > 0) {
-#pragma unroll
-        for (int j = 0; j < kEnvChunk; ++j) next[j] = d[(int64_t)j * channels];
-    }
-    for (int64_t base = 0; base < full; base += kEnvChunk) {
-        double cur[kEnvChunk];
-        float y[kEnvChunk];
-#pragma unroll
-        for (int j = 0; j < kEnvChunk; ++j) cur[j] = next[j];
-        // next chunk (the last iteration re-reads its own chunk: in bounds, unused)
-        const int64_t nb = (base + kEnvChunk < full) ? base + kEnvChunk : base;
-#pragma unroll
-        for (int j = 0; j < kEnvChunk; ++j) next[j] = d[(nb + j) * channels];
-#pragma unroll
-        for (int j = 0; j < kEnvChunk; ++j) {
-            // branch-free: pick the coefficient, then the reference's e + c*(target - e)
-            const double c = cur[j] > e ? attack_coeff : release_coeff;
-            e = e + c * (cur[j] - e);
-            y[j] = (float)e;
+    double e_in = state[ch];
+    double t_next = (lane < n) ? d[(int64_t)lane * channels] : 0.0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int nv = (n - base < 64) ? (int)(n - base) : 64;
+        const double t = t_next;
+        if (base + 64 + lane < n) t_next = d[(base + 64 + lane) * channels];      // next chunk, in flight
+        double mine = 0.0;
+        int f = 0, passes = 0;
+        while (f < nv && passes < kEnvMaxPasses) {
+            ++passes;
+            const double t_f = readlane_f64(t, f);
+            const bool attack = t_f > e_in;
+            const double c = attack ? attack_coeff : release_coeff;
+            // affine maps e -> m*e + p of the open lanes, identity on the closed ones; inclusive scan
+            double m = (lane >= f) ? 1.0 - c : 1.0;
+            double p = (lane >= f) ? c * t : 0.0;
+            ENV_COMPOSE(0x111, 0xf)
+            ENV_COMPOSE(0x112, 0xf)
+            ENV_COMPOSE(0x114, 0xf)
+            ENV_COMPOSE(0x118, 0xf)
+            ENV_COMPOSE(0x142, 0xa)
+            ENV_COMPOSE(0x143, 0xc)
+            const double e = __builtin_fma(m, e_in, p);
+            double prev = dpp_f64_keep<0x138, 0xf>(e_in, e);                       // wave_shr:1
+            if (lane == f) prev = e_in;
+            const bool consistent = (t > prev) == attack;
+            const unsigned long long bad = __ballot(lane >= f && lane < nv && !consistent);
+            const int v = bad ? (__ffsll((long long)bad) - 1) : nv;               // v > f: lane f is consistent
+            if (lane >= f && lane < v) mine = e;
+            e_in = readlane_f64(e, v - 1);
+            f = v;
         }
-#pragma unroll
-        for (int j = 0; j < kEnvChunk; ++j) o[(base + j) * channels] = y[j];
+        for (; f < nv; ++f) {                                                      // pathological chunk: literal steps
+            const double t_f = readlane_f64(t, f);
+            const double c = t_f > e_in ? attack_coeff : release_coeff;
+            e_in = e_in + c * (t_f - e_in);
+            if (lane == f) mine = e_in;
+        }
+        if (lane < nv) o[(base + lane) * channels] = (float)mine;
     }
-    for (int64_t i = full; i < n; ++i) {
-        const double target = d[i * channels];
-        const double c = target > e ? attack_coeff : release_coeff;
-        e = e + c * (target - e);
-        o[i * channels] = (float)e;
-    }
-    state[ch] = e;
+    if (lane == 0) state[ch] = e_in;
 }
+#undef ENV_COMPOSE
 
 // ================================================================================================
 // TransformPE: chains of named element-wise float64 operations (pygmu2_amd/transforms.py)
@@ -1529,7 +1564,7 @@ int pgx_envelope(float *out, const float *in, int64_t n, int channels, double at
                            (const double *)scratch, n, channels, attack_coeff, state);
         PGX_LAUNCH_CHECK("k_env_onepole");
     } else {
-        hipLaunchKernelGGL(k_env_ar, dim3((channels + 63) / 64), dim3(64), 0, pgx::stream(), out,
+        hipLaunchKernelGGL(k_env_ar, dim3(channels), dim3(64), 0, pgx::stream(), out,
                            (const double *)scratch, n, channels, attack_coeff, release_coeff, state);
         PGX_LAUNCH_CHECK("k_env_ar");
     }

@@ -1,0 +1,54 @@
+"""
+GPU: EnvelopePE's attack/release follower (pgx_envelope, wave-cooperative regime walk) against the
+oracle's literal loop (orc_envelope_ar, envelope_pe.py:259-271) on inputs that exercise every path:
+long regimes (periodic input), regime flips every few samples (noise -> literal fallback inside a chunk),
+instant attack, silence, odd block lengths, stereo, state carried across blocks.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+def _signals(n):
+    rng = np.random.default_rng(12)
+    t = np.arange(n) / 44100.0
+    burst = np.sin(2 * np.pi * 220.0 * t) * np.exp(-((t % 0.5) * 6.0))
+    return {
+        "sine": 0.8 * np.sin(2 * np.pi * 220.0 * t),
+        "noise": rng.standard_normal(n) * 0.3,
+        "bursts": burst,
+        "silence_then_step": np.concatenate([np.zeros(n // 3), np.full(n - n // 3, 0.5)]),
+        "slow_am": np.sin(2 * np.pi * 3000.0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 2.0 * t)),
+    }
+
+
+@pytest.mark.parametrize("name", ["sine", "noise", "bursts", "silence_then_step", "slow_am"])
+@pytest.mark.parametrize("attack,release", [(0.005, 0.05), (0.0, 0.03), (0.05, 0.001)])
+def test_attack_release_follower_matches_oracle(name, attack, release):
+    from oracle import pe_oracle as O
+    import pygmu2_amd as pg
+    pg.set_sample_rate(44100)
+    n = 50_000
+    mono = _signals(n)[name]
+    x = np.stack([mono, np.roll(mono, 777) * 0.5], axis=1).astype(np.float32)
+    pe = pg.EnvelopePE(pg.ArrayPE(x), attack=attack, release=release)
+    r = pg.NullRenderer(sample_rate=44100)
+    r.set_source(pe)
+    r.start()
+    sizes = [1024, 63, 64, 65, 1, 20000, 28783]
+    pos, got = 0, []
+    for s in sizes:
+        got.append(pe.render(pos, s).data)
+        pos += s
+    r.stop()
+    got = np.concatenate(got)
+    st = O.envelope_state()
+    want = O.envelope(st, x, attack=attack, release=release, mode="peak", sr=44100)
+    peak = float(np.max(np.abs(want))) or 1.0
+    err = float(np.max(np.abs(got.astype(np.float64) - want)))
+    assert err <= REL_TOL * peak + 1e-7, (name, attack, release, err, peak)
+    assert np.all(got >= 0.0)

@@ -34,7 +34,7 @@ BIT_EXACT = {
     "adsr_full_cycle", "adsr_early_release_chunked", "adsr_bad_gate_values", "adsr_periodic_gate",
     "adsr_sustain_edges", "adsr_triggered", "adsr_triggered_retrigger",
     "comb_kat", "comb_high_freq", "comb_step",
-    "envelope_peak", "envelope_instant_attack", "transform_chain",
+    "transform_chain",
     "delay_int", "delay_int_negative", "delay_float_linear", "delay_float_cubic",
     "piecewise_step", "piecewise_linear", "piecewise_single_point", "piecewise_single_point_zero",
 }
