@@ -187,10 +187,16 @@ typedef struct {
     int32_t pad;
 } pgx_biquad_var_params;
 /* gain_a = 10^(gain_db/40) and gain_sqrt_a = sqrt(gain_a), computed by the host exactly as the
- * reference does (biquad_pe.py:250,290). */
+ * reference does (biquad_pe.py:250,290).
+ * workspace: pgx_scan2_workspace_bytes(n, channels) bytes, or NULL.  With a workspace a long block is cut
+ * into segments: a reduce launch composes each segment's affine state map, the apply launch folds the
+ * earlier maps onto the carried state and renders (2 launches x up to 128 workgroups per channel);
+ * without one (or for blocks of one or two tiles) a single workgroup walks the block. */
+size_t pgx_scan2_workspace_bytes(int64_t n, int channels);
 int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, double sample_rate,
                        const pgx_biquad_var_params *params, const float *freq, const float *q,
-                       double gain_a, double gain_sqrt_a, double *state /* [channels][4] */);
+                       double gain_a, double gain_sqrt_a, double *state /* [channels][4] */,
+                       void *workspace);
 
 /* ------------------------------------------------------------------ SVFilterPE / EnvelopePE / TransformPE
  * (the PEs of benchmarks/profile_biquad_vs_svfilter.py)
@@ -201,7 +207,7 @@ int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_
             const pgx_biquad_var_params *params, const float *freq, const float *q, double gain_a,
             const double *coef /* NULL, or {a00,a01,a10,a11,b0,b1,c0,c1,c2} evaluated by the host
                                   (constant frequency and q; freq and q must then be NULL) */,
-            double *state /* [channels][2] */);
+            double *state /* [channels][2] */, void *workspace /* as for pgx_biquad_varying */);
 
 /* EnvelopePE._render (envelope_pe.py:128-206) on the (already look-ahead shifted) source block.
  * one_pole != 0: attack == release, scipy lfilter one-pole as a scan; else the attack/release

@@ -201,9 +201,13 @@ class BiquadPE(ProcessingElement):
                 _dev.BIQUAD_VAR_PARAMS, freq=0.0 if f_s is None else f_s, q=0.0 if q_s is None else q_s,
                 gain_db=float(self._gain_db), mode=_MODE_INDEX[self._mode])
         gain_a = 10.0 ** (self._gain_db / 40.0)
+        need = L.pgx_scan2_workspace_bytes(duration, ch)
+        if need and (self._workspace is None or self._workspace.nbytes < need):
+            self._workspace = DeviceBuffer((need,), np.uint8)
         check(L.pgx_biquad_varying(out.ptr, src.dev.ptr, duration, ch, sr, self._params.ptr,
                                    ptr(f_buf), ptr(q_buf), gain_a, float(np.sqrt(gain_a)),
-                                   self._state.ptr), "pgx_biquad_varying")
+                                   self._state.ptr, ptr(self._workspace) if need else None),
+              "pgx_biquad_varying")
         return Snippet(start, out)
 
     def __repr__(self) -> str:

@@ -892,6 +892,87 @@ struct BvShared {
     V2 wv[kWaves];
 };
 
+// Time-varying 2x2 recurrences (varying biquad, SVF): s' = A_n s + b_n.  Three ways to run a chain:
+//   MODE 2  one workgroup walks the whole block (short blocks: one launch)
+//   MODE 0  reduce: each workgroup composes the affine map (M, v) of its segment of tiles -> agg
+//   MODE 1  apply: each workgroup folds the maps of the segments before it onto the carried state and
+//           renders its segment
+// so a 44 100-frame block is 2 launches of 44 workgroups instead of 1 workgroup doing 44 tiles in a row.
+constexpr int kS2MaxSeg = 128;
+
+struct Scan2Plan {
+    int seg_tiles, nseg;
+};
+inline Scan2Plan scan2_plan(int64_t n, int tile) {
+    const int64_t tiles = pgx::ceil_div(n, tile);
+    Scan2Plan p{(int)tiles, 1};
+    if (tiles <= 2) return p;
+    int64_t nseg = tiles < kS2MaxSeg ? tiles : kS2MaxSeg;
+    p.seg_tiles = (int)pgx::ceil_div(tiles, nseg);
+    p.nseg = (int)pgx::ceil_div(tiles, p.seg_tiles);
+    return p;
+}
+
+// Per tile: every thread holds the composed map (cm, cv) of its T frames.  Inclusive Kogge-Stone over the
+// wave, exchange through LDS.  MODE 0 folds the tile into the segment map (acc_m, acc_v); the other modes
+// return the state on entering this thread's frames (from the carried state vector) and advance the carry.
+template <int MODE>
+__device__ __forceinline__ V2 scan2_tile(BvShared &sh, const M2 &cm, const V2 &cv, V2 &carry, M2 &acc_m, V2 &acc_v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    M2 im = cm;
+    V2 iv = cv;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        M2 om = shfl_up_m2(im, 1 << k);
+        V2 ov = shfl_up_v2(iv, 1 << k);
+        if (lane >= (1 << k)) {
+            iv = vadd(mv(im, ov), iv);
+            im = mm(im, om);
+        }
+    }
+    if (lane == 63) {
+        sh.wm[wave] = im;
+        sh.wv[wave] = iv;
+    }
+    __syncthreads();
+    V2 s{0.0, 0.0};
+    if (MODE == 0) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const M2 tm = sh.wm[w];
+            acc_v = vadd(mv(tm, acc_v), sh.wv[w]);
+            acc_m = mm(tm, acc_m);
+        }
+    } else {
+        V2 cw = carry, cn = carry;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const M2 tm = sh.wm[w];
+            const V2 tv = sh.wv[w];
+            if (w < wave) cw = vadd(mv(tm, cw), tv);
+            cn = vadd(mv(tm, cn), tv);
+        }
+        carry = cn;
+        // exclusive prefix within the wave applied to the wave carry-in
+        const M2 em = shfl_up_m2(im, 1);
+        const V2 ev = shfl_up_v2(iv, 1);
+        s = cw;
+        if (lane > 0) s = vadd(mv(em, cw), ev);
+    }
+    __syncthreads();
+    return s;
+}
+
+// carried state on entering segment `seg`: the maps of the earlier segments applied in order
+__device__ __forceinline__ V2 scan2_fold(const double *agg, int seg, V2 s) {
+    for (int j = 0; j < seg; ++j) {
+        const double *a = agg + (int64_t)j * 6;
+        const M2 m{a[0], a[1], a[2], a[3]};
+        s = vadd(mv(m, s), V2{a[4], a[5]});
+    }
+    return s;
+}
+
 // RBJ cookbook coefficients for one sample (biquad_pe.py:217-335), normalised by a0.
 __device__ __forceinline__ void rbj(int mode, double f, double q, double A, double sqrtA, double sr, double &b0,
                                     double &b1, double &b2, double &a1, double &a2) {
@@ -948,23 +1029,34 @@ __device__ __forceinline__ void rbj(int mode, double f, double q, double A, doub
     b0 = b0 / a0; b1 = b1 / a0; b2 = b2 / a0; a1 = a1 / a0; a2 = a2 / a0;
 }
 
-// One workgroup per channel chain.  State map per sample: (y1,y2) -> (y0,y1) with
+// State map per sample: (y1,y2) -> (y0,y1) with
 // y0 = ((ff - a1*y1) - a2*y2), ff = (b0*x + b1*x1) + b2*x2  (biquad_pe.py:53-55 grouping).
+// state[channel] = {x1, x2, y1, y2}; snapshot = its copy taken by the reduce launch; agg[channel][seg] = map.
+template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr,
                  const pgx_biquad_var_params *params, const float *freq, const float *qs, double A,
-                 double sqrtA, double *state) {
+                 double sqrtA, double *state, double *snapshot, double *agg, int seg_tiles, int nseg) {
     __shared__ BvShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x, ch = blockIdx.y;
     const pgx_biquad_var_params p = params[0];
     double *st = state + ch * 4;                    // x1,x2,y1,y2
-    const double sx1 = st[0], sx2 = st[1];
-    V2 carry{st[2], st[3]};                         // (y1, y2)
+    const double *init = (MODE == 1) ? snapshot + ch * 4 : st;
+    const double sx1 = init[0], sx2 = init[1];
+    double *ag = agg + ((int64_t)ch * nseg) * 6;
+    V2 carry{init[2], init[3]};                     // (y1, y2)
+    if (MODE == 1) carry = scan2_fold(ag, seg, carry);
+    if (MODE == 0 && seg == 0 && tid < 4) snapshot[ch * 4 + tid] = st[tid];
+    M2 acc_m = m_identity();
+    V2 acc_v{0.0, 0.0};
     V2 final_y{0.0, 0.0};
     bool have_final = false;
 
-    for (int64_t base = 0; base < n; base += kBvTile) {
+    const int64_t tile0 = (int64_t)seg * seg_tiles;
+    for (int t = 0; t < seg_tiles; ++t) {
+        const int64_t base = (tile0 + t) * kBvTile;
+        if (base >= n) break;
         const int64_t f0 = base + (int64_t)tid * kBvT;
         double ff[kBvT], ca1[kBvT], ca2[kBvT];
         // x history for the feed-forward part
@@ -1004,38 +1096,8 @@ k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr
                 cv = nv;
             }
         }
-        // inclusive wave scan over (matrix, vector) pairs: right o left
-        M2 im = cm;
-        V2 iv = cv;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            M2 om = shfl_up_m2(im, 1 << k);
-            V2 ov = shfl_up_v2(iv, 1 << k);
-            if (lane >= (1 << k)) {
-                iv = vadd(mv(im, ov), iv);
-                im = mm(im, om);
-            }
-        }
-        if (lane == 63) {
-            sh.wm[wave] = im;
-            sh.wv[wave] = iv;
-        }
-        __syncthreads();
-        V2 cw = carry, cn = carry;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            M2 tm = sh.wm[w];
-            V2 tv = sh.wv[w];
-            if (w < wave) cw = vadd(mv(tm, cw), tv);
-            cn = vadd(mv(tm, cn), tv);
-        }
-        __syncthreads();
-        carry = cn;
-        // exclusive prefix within the wave applied to the wave carry-in
-        M2 em = shfl_up_m2(im, 1);
-        V2 ev = shfl_up_v2(iv, 1);
-        V2 s = cw;
-        if (lane > 0) s = vadd(mv(em, cw), ev);
+        V2 s = scan2_tile<MODE>(sh, cm, cv, carry, acc_m, acc_v);
+        if (MODE == 0) continue;
 
         float yf[kBvT];
 #pragma unroll
@@ -1052,6 +1114,13 @@ k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr
             }
         }
         store_frames<kBvT>(out, f0, n, channels, ch, yf);
+    }
+    if (MODE == 0) {
+        if (tid == 0) {
+            double *a = ag + (int64_t)seg * 6;
+            a[0] = acc_m.a; a[1] = acc_m.b; a[2] = acc_m.c; a[3] = acc_m.d; a[4] = acc_v.x; a[5] = acc_v.y;
+        }
+        return;
     }
     if (have_final) {
         // x1 = x[n-1]; x2 = x[n-2] (or the previous x1 when n == 1), numba kernel semantics
@@ -1129,15 +1198,24 @@ __device__ __forceinline__ SvCoef svf_coef(int mode, double freq, double q, doub
     return c;
 }
 
+// state[channel] = {s0, s1}; snapshot / agg as for the varying biquad.
+template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx_biquad_var_params *params,
-      const float *freq, const float *qs, double a_lin, const double *coef, double *state) {
+      const float *freq, const float *qs, double a_lin, const double *coef, double *state, double *snapshot,
+      double *agg, int seg_tiles, int nseg) {
     __shared__ BvShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x, ch = blockIdx.y;
     const pgx_biquad_var_params p = params[0];
     double *st = state + ch * 2;
-    V2 carry{st[0], st[1]};
+    const double *init = (MODE == 1) ? snapshot + ch * 2 : st;
+    double *ag = agg + ((int64_t)ch * nseg) * 6;
+    V2 carry{init[0], init[1]};
+    if (MODE == 1) carry = scan2_fold(ag, seg, carry);
+    if (MODE == 0 && seg == 0 && tid < 2) snapshot[ch * 2 + tid] = st[tid];
+    M2 acc_m = m_identity();
+    V2 acc_v{0.0, 0.0};
     V2 final_s{0.0, 0.0};
     bool have_final = false;
     const bool varying = (freq != nullptr) || (qs != nullptr);
@@ -1148,7 +1226,10 @@ k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx
         cconst = svf_coef(p.mode, p.freq, p.q, a_lin, sr);
     }
 
-    for (int64_t base = 0; base < n; base += kSvTile) {
+    const int64_t tile0 = (int64_t)seg * seg_tiles;
+    for (int t = 0; t < seg_tiles; ++t) {
+        const int64_t base = (tile0 + t) * kSvTile;
+        if (base >= n) break;
         const int64_t f0 = base + (int64_t)tid * kSvT;
         SvCoef cf[kSvT];
         double xs[kSvT];
@@ -1173,36 +1254,8 @@ k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx
                 cm = mm(A, cm);
             }
         }
-        M2 im = cm;
-        V2 iv = cv;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            M2 om = shfl_up_m2(im, 1 << k);
-            V2 ov = shfl_up_v2(iv, 1 << k);
-            if (lane >= (1 << k)) {
-                iv = vadd(mv(im, ov), iv);
-                im = mm(im, om);
-            }
-        }
-        if (lane == 63) {
-            sh.wm[wave] = im;
-            sh.wv[wave] = iv;
-        }
-        __syncthreads();
-        V2 cw = carry, cn = carry;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            M2 tm = sh.wm[w];
-            V2 tv = sh.wv[w];
-            if (w < wave) cw = vadd(mv(tm, cw), tv);
-            cn = vadd(mv(tm, cn), tv);
-        }
-        __syncthreads();
-        carry = cn;
-        M2 em = shfl_up_m2(im, 1);
-        V2 ev = shfl_up_v2(iv, 1);
-        V2 s = cw;
-        if (lane > 0) s = vadd(mv(em, cw), ev);
+        V2 s = scan2_tile<MODE>(sh, cm, cv, carry, acc_m, acc_v);
+        if (MODE == 0) continue;
 
         float yf[kSvT];
 #pragma unroll
@@ -1222,6 +1275,13 @@ k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx
             }
         }
         store_frames<kSvT>(out, f0, n, channels, ch, yf);
+    }
+    if (MODE == 0) {
+        if (tid == 0) {
+            double *a = ag + (int64_t)seg * 6;
+            a[0] = acc_m.a; a[1] = acc_m.b; a[2] = acc_m.c; a[3] = acc_m.d; a[4] = acc_v.x; a[5] = acc_v.y;
+        }
+        return;
     }
     if (have_final) {
         st[0] = final_s.x;
@@ -1494,16 +1554,38 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
 
 // A = 10^(gain_db/40) is a host-side Python float pow in the reference (biquad_pe.py:250); the
 // binding passes it and its square root by value so the device never calls pow().
+size_t pgx_scan2_workspace_bytes(int64_t n, int channels) {
+    if (n <= 0 || channels <= 0) return 0;
+    const Scan2Plan p = scan2_plan(n, kBvTile);
+    if (p.nseg <= 1) return 0;
+    return (size_t)channels * (4 + (size_t)p.nseg * 6) * sizeof(double);
+}
+
 int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, double sample_rate,
                        const pgx_biquad_var_params *params, const float *freq, const float *q,
-                       double gain_a, double gain_sqrt_a, double *state) {
+                       double gain_a, double gain_sqrt_a, double *state, void *workspace) {
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && params && state && channels >= 1 && sample_rate > 0,
                   "pgx_biquad_varying: bad argument");
-    hipLaunchKernelGGL(k_biquad_varying, dim3(channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels,
-                       sample_rate, params, freq, q, gain_a, gain_sqrt_a, state);
-    PGX_LAUNCH_CHECK("k_biquad_varying");
+    const Scan2Plan p = scan2_plan(n, kBvTile);
+    double *snap = (double *)workspace;
+    double *agg = snap ? snap + (size_t)channels * 4 : nullptr;
+    if (p.nseg <= 1 || workspace == nullptr) {
+        hipLaunchKernelGGL(k_biquad_varying<2>, dim3(1, channels), dim3(kBlock), 0, pgx::stream(), out, in, n,
+                           channels, sample_rate, params, freq, q, gain_a, gain_sqrt_a, state, snap, agg,
+                           (int)pgx::ceil_div(n, kBvTile), 1);
+        PGX_LAUNCH_CHECK("k_biquad_varying");
+        return PGX_OK;
+    }
+    hipLaunchKernelGGL(k_biquad_varying<0>, dim3(p.nseg, channels), dim3(kBlock), 0, pgx::stream(), out, in, n,
+                       channels, sample_rate, params, freq, q, gain_a, gain_sqrt_a, state, snap, agg, p.seg_tiles,
+                       p.nseg);
+    PGX_LAUNCH_CHECK("k_biquad_varying<reduce>");
+    hipLaunchKernelGGL(k_biquad_varying<1>, dim3(p.nseg, channels), dim3(kBlock), 0, pgx::stream(), out, in, n,
+                       channels, sample_rate, params, freq, q, gain_a, gain_sqrt_a, state, snap, agg, p.seg_tiles,
+                       p.nseg);
+    PGX_LAUNCH_CHECK("k_biquad_varying<apply>");
     return PGX_OK;
 }
 
@@ -1540,14 +1622,27 @@ int pgx_sine_stateful(float *out, int64_t n, int channels, double sample_rate,
 
 int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_rate,
             const pgx_biquad_var_params *params, const float *freq, const float *q, double gain_a,
-            const double *coef, double *state) {
+            const double *coef, double *state, void *workspace) {
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && params && state && channels >= 1 && sample_rate > 0, "pgx_svf: bad argument");
     PGX_CHECK_ARG(!(coef && (freq || q)), "pgx_svf: constant coefficients exclude control streams");
-    hipLaunchKernelGGL(k_svf, dim3(channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels, sample_rate,
-                       params, freq, q, gain_a, coef, state);
-    PGX_LAUNCH_CHECK("k_svf");
+    const Scan2Plan p = scan2_plan(n, kSvTile);
+    double *snap = (double *)workspace;
+    double *agg = snap ? snap + (size_t)channels * 4 : nullptr;
+    if (p.nseg <= 1 || workspace == nullptr) {
+        hipLaunchKernelGGL(k_svf<2>, dim3(1, channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels,
+                           sample_rate, params, freq, q, gain_a, coef, state, snap, agg,
+                           (int)pgx::ceil_div(n, kSvTile), 1);
+        PGX_LAUNCH_CHECK("k_svf");
+        return PGX_OK;
+    }
+    hipLaunchKernelGGL(k_svf<0>, dim3(p.nseg, channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels,
+                       sample_rate, params, freq, q, gain_a, coef, state, snap, agg, p.seg_tiles, p.nseg);
+    PGX_LAUNCH_CHECK("k_svf<reduce>");
+    hipLaunchKernelGGL(k_svf<1>, dim3(p.nseg, channels), dim3(kBlock), 0, pgx::stream(), out, in, n, channels,
+                       sample_rate, params, freq, q, gain_a, coef, state, snap, agg, p.seg_tiles, p.nseg);
+    PGX_LAUNCH_CHECK("k_svf<apply>");
     return PGX_OK;
 }
 

@@ -76,7 +76,8 @@ _SIGNATURES = [
     ("pgx_biquad_table_doubles", _Z, []),
     ("pgx_biquad_tables", _I, [_P, _P, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _L, _P, _P]),
-    ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P]),
+    ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P, _P]),
+    ("pgx_scan2_workspace_bytes", _Z, [_L, _I]),
     ("pgx_convolve_fft_size", _L, [_L]),
     ("pgx_convolve_fft_spectrum_bytes", _Z, [_L, _I]),
     ("pgx_convolve_fft_workspace_bytes", _Z, [_L, _L, _I, _L]),
@@ -87,7 +88,7 @@ _SIGNATURES = [
     ("pgx_piecewise", _I, [_P, _L, _L, _I, _P, _P, _I, _I, _I, _I]),
     ("pgx_f32_to_pcm16", _I, [_P, _P, _L]),
     ("pgx_pcm16_to_f32", _I, [_P, _P, _L]),
-    ("pgx_svf", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _P, _P]),
+    ("pgx_svf", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _P, _P, _P]),
     ("pgx_envelope", _I, [_P, _P, _L, _I, _D, _D, _I, _I, _P, _P]),
     ("pgx_transform", _I, [_P, _P, _L, _P, _I]),
     ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P]),

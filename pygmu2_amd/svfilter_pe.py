@@ -89,6 +89,7 @@ class SVFilterPE(ProcessingElement):
         self._params: DeviceBuffer | None = None      # pgx_biquad_var_params
         self._state: DeviceBuffer | None = None       # [C][2] float64
         self._state_channels = 0
+        self._workspace: DeviceBuffer | None = None
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -143,9 +144,13 @@ class SVFilterPE(ProcessingElement):
         if constant and self._coef is None:
             self._coef = DeviceBuffer.from_host(np.asarray(
                 svf_coefficients(self._mode, self._frequency, self._q, self._gain_db, sr), dtype=np.float64))
-        check(lib().pgx_svf(out.ptr, src.dev.ptr, duration, ch, sr, self._params.ptr, ptr(f_buf), ptr(q_buf),
-                            10.0 ** (self._gain_db / 40.0), self._coef.ptr if constant else None,
-                            self._state.ptr), "pgx_svf")
+        L = lib()
+        need = L.pgx_scan2_workspace_bytes(duration, ch)
+        if need and (self._workspace is None or self._workspace.nbytes < need):
+            self._workspace = DeviceBuffer((need,), np.uint8)
+        check(L.pgx_svf(out.ptr, src.dev.ptr, duration, ch, sr, self._params.ptr, ptr(f_buf), ptr(q_buf),
+                        10.0 ** (self._gain_db / 40.0), self._coef.ptr if constant else None,
+                        self._state.ptr, ptr(self._workspace) if need else None), "pgx_svf")
         return Snippet(start, out)
 
     def __repr__(self) -> str:
