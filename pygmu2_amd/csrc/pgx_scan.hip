@@ -1382,7 +1382,9 @@ k_env_onepole(float *out, const double *det, int64_t n, int channels, double coe
 // target > previous level contradicts the regime; the walk continues from there with the other
 // coefficient.  A chunk that needs more than kEnvMaxPasses passes (noise-like input) is finished one
 // sample at a time.  Levels come out of a scan instead of the literal sum: ~1e-16 relative, and a
-// comparison that flips at a near-tie picks between two branches that agree there.
+// comparison that flips at a near-tie picks between two branches that agree there.  Within a regime the
+// multipliers are constant, so the scan carries one value per lane and the powers of (1 - c) come from
+// per-lane tables built once per launch.
 constexpr int kEnvMaxPasses = 10;
 
 template <int CTRL, int ROW_MASK>
@@ -1397,14 +1399,37 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // sr
     return __hiloint2double(hi, lo);
 }
 
-// (m, p) <- (m, p) o (pm, pp): apply the earlier map first
-#define ENV_COMPOSE(CTRL, MASK)                                        \
-    {                                                                  \
-        const double pm = dpp_f64_keep<CTRL, MASK>(1.0, m);            \
-        const double pp = dpp_f64_keep<CTRL, MASK>(0.0, p);            \
-        p = __builtin_fma(m, pp, p);                                   \
-        m = m * pm;                                                    \
+// lambda^e for a per-lane exponent e in [0, 64] (repeated squaring over the bits of e)
+__device__ __forceinline__ double lane_power(double lambda, int e) {
+    double r = 1.0, sq = lambda;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        if (e & (1 << k)) r = r * sq;
+        sq = sq * sq;
     }
+    return r;
+}
+
+// Powers of one regime's lambda = 1 - c that the chunk scan needs.
+struct EnvRegime {
+    double c;
+    double l1, l2, l4, l8;      // lambda^(2^k): Kogge-Stone inside a 16-lane row
+    double p16, p32;            // lambda^((lane&15)+1), lambda^((lane&31)+1): joining the rows
+    double run;                 // lambda^(lane+1): the carried level's weight, shifted to the open lane
+};
+__device__ __forceinline__ EnvRegime env_regime(double c, int lane) {
+    EnvRegime r;
+    const double l = 1.0 - c;
+    r.c = c;
+    r.l1 = l;
+    r.l2 = l * l;
+    r.l4 = r.l2 * r.l2;
+    r.l8 = r.l4 * r.l4;
+    r.p16 = lane_power(l, (lane & 15) + 1);
+    r.p32 = lane_power(l, (lane & 31) + 1);
+    r.run = lane_power(l, lane + 1);
+    return r;
+}
 
 __global__ void __launch_bounds__(64)
 k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_coeff, double release_coeff,
@@ -1412,6 +1437,7 @@ k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_c
     const int ch = blockIdx.x, lane = threadIdx.x;
     const double *d = det + ch;
     float *o = out + ch;
+    const EnvRegime ra = env_regime(attack_coeff, lane), rr = env_regime(release_coeff, lane);
     double e_in = state[ch];
     double t_next = (lane < n) ? d[(int64_t)lane * channels] : 0.0;
     for (int64_t base = 0; base < n; base += 64) {
@@ -1424,16 +1450,17 @@ k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_c
             ++passes;
             const double t_f = readlane_f64(t, f);
             const bool attack = t_f > e_in;
-            const double c = attack ? attack_coeff : release_coeff;
-            // affine maps e -> m*e + p of the open lanes, identity on the closed ones; inclusive scan
-            double m = (lane >= f) ? 1.0 - c : 1.0;
-            double p = (lane >= f) ? c * t : 0.0;
-            ENV_COMPOSE(0x111, 0xf)
-            ENV_COMPOSE(0x112, 0xf)
-            ENV_COMPOSE(0x114, 0xf)
-            ENV_COMPOSE(0x118, 0xf)
-            ENV_COMPOSE(0x142, 0xa)
-            ENV_COMPOSE(0x143, 0xc)
+            const EnvRegime &g = attack ? ra : rr;
+            // e_k = lambda^(k-f+1) e_in + sum_{j=f..k} lambda^(k-j) c t_j for the open lanes k >= f: the sum is a
+            // scan with constant multipliers (closed lanes contribute 0), the first term a shifted table
+            double p = (lane >= f) ? g.c * t : 0.0;
+            p = __builtin_fma(g.l1, dpp_f64<0x111, 0xf>(p), p);
+            p = __builtin_fma(g.l2, dpp_f64<0x112, 0xf>(p), p);
+            p = __builtin_fma(g.l4, dpp_f64<0x114, 0xf>(p), p);
+            p = __builtin_fma(g.l8, dpp_f64<0x118, 0xf>(p), p);
+            p = __builtin_fma(g.p16, dpp_f64<0x142, 0xa>(p), p);
+            p = __builtin_fma(g.p32, dpp_f64<0x143, 0xc>(p), p);
+            const double m = __shfl(g.run, lane - f, 64);                         // lambda^(lane-f+1) for lane >= f
             const double e = __builtin_fma(m, e_in, p);
             double prev = dpp_f64_keep<0x138, 0xf>(e_in, e);                       // wave_shr:1
             if (lane == f) prev = e_in;
@@ -1454,7 +1481,6 @@ k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_c
     }
     if (lane == 0) state[ch] = e_in;
 }
-#undef ENV_COMPOSE
 
 // ================================================================================================
 // TransformPE: chains of named element-wise float64 operations (pygmu2_amd/transforms.py)
