@@ -165,6 +165,69 @@ __device__ __forceinline__ double block_scan_scalar_affine(double e, const doubl
     return lam_lane * cw + ex;
 }
 
+// Wide forms for a workgroup of NW = 4*G waves that must reproduce, bit for bit, what a 4-wave workgroup
+// computes on G consecutive tiles: the wave values are the same, so it is enough to fold them in the same
+// order.  sum_carry: running sum entering the first of the G tiles (advanced to the one leaving the last).
+template <int NW>
+__device__ __forceinline__ double block_excl_sum_wide(double v, double *lds, double &sum_carry) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = o + inc;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    double base = sum_carry, mine_base = sum_carry, woff = 0.0;
+#pragma unroll
+    for (int g = 0; g < NW / kWaves; ++g) {
+        double tot = 0.0, w_local = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const double t = lds[g * kWaves + w];
+            if (g * kWaves + w < wave) w_local = w_local + t;
+            tot = tot + t;
+        }
+        if (g == wave / kWaves) {
+            mine_base = base;
+            woff = w_local;
+        }
+        base = base + tot;                                   // carry_sum = carry_sum + tile_total
+    }
+    __syncthreads();
+    sum_carry = base;
+    double ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0.0;
+    return mine_base + (woff + ex);                          // chunk_base = carry_sum + off
+}
+
+template <int NW>
+__device__ __forceinline__ double block_scan_scalar_affine_wide(double e, const double (&lamp)[6], double lam_wave,
+                                                                double lam_lane, double *lds, double &carry) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = e;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double o = __shfl_up(inc, 1 << k, 64);
+        if (lane >= (1 << k)) inc = lamp[k] * o + inc;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    double cw = carry, cn = carry;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        double t = lds[w];
+        if (w < wave) cw = lam_wave * cw + t;
+        cn = lam_wave * cn + t;
+    }
+    __syncthreads();
+    carry = cn;
+    double ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0.0;
+    return lam_lane * cw + ex;
+}
+
 // ================================================================================================
 // BiquadPE, constant coefficients
 // ================================================================================================
@@ -685,9 +748,10 @@ constexpr int kSawT = 8;
 constexpr int kSawTile = kBlock * kSawT;   // 2048 frames
 constexpr double kPi = 3.141592653589793;
 
+constexpr int kSawWideWaves = 8;                  // 512-thread form for a handful of oscillators (203 VGPRs: 2 waves per SIMD)
 struct SawShared {
-    double sum[kWaves];
-    double aff[kWaves];
+    double sum[kSawWideWaves];
+    double aff[kSawWideWaves];
 };
 
 // Per-sample constants of the Dirichlet kernel derived from the frequency (blit_saw_pe.py:166-173,196).
@@ -717,8 +781,11 @@ __device__ __forceinline__ SawConst saw_const(double f, double sr, double m_para
 
 // STREAMS = false: scalar frequency / amplitude / M (every voice-bank and SuperSaw launch): the
 // per-voice constants are hoisted out of the sample loops.
-template <bool STREAMS>
-__global__ void __launch_bounds__(kBlock)
+// NW = 4: 256 threads, 2048-frame tiles (banks of oscillators).  NW = 8: 512 threads, 4096-frame tiles --
+// the same wave values folded in the same order, i.e. bit-identical output with half of the
+// dependent tile steps, for graphs with a few oscillators where the chain length is what costs.
+template <bool STREAMS, int NW>
+__global__ void __launch_bounds__(NW * 64)
 k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, const pgx_blitsaw_params *params,
           const float *freq, int64_t freq_stride, const float *amp, int64_t amp_stride, const float *mstream,
           int64_t m_stride, double *state) {
@@ -755,7 +822,8 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     double final_phase = 0.0, final_y = 0.0;
     bool have_final = false;
 
-    for (int64_t base = 0; base < n; base += kSawTile) {
+    constexpr int kTile = NW * 64 * kSawT;
+    for (int64_t base = 0; base < n; base += kTile) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
         SawConst kc[kSawT];
         // ---- phase increment and inclusive local cumsum (blit_saw_pe.py:188-191) ----
@@ -773,10 +841,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             run = run + (live ? kc[j].inc : 0.0);
             loc[j] = run;
         }
-        double tile_total;
-        double off = block_excl_sum(run, sh.sum, tile_total);
-        const double chunk_base = carry_sum + off;
-        carry_sum = carry_sum + tile_total;
+        const double chunk_base = block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
 
         // ---- Dirichlet kernel (blit_saw_pe.py:194-217) ----
         double xb[kSawT];
@@ -801,7 +866,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         double e = 0.0;
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
-        double y = block_scan_scalar_affine(e, lamp, lam_wave, lam_lane, sh.aff, carry_y);
+        double y = block_scan_scalar_affine_wide<NW>(e, lamp, lam_wave, lam_lane, sh.aff, carry_y);
 
         float yf[kSawT];
 #pragma unroll
@@ -1622,13 +1687,18 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && params && state && channels >= 1 && sample_rate > 0, "pgx_blitsaw: bad argument");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_blitsaw: out_stride too small");
-    if (freq || amp || m) {
-        hipLaunchKernelGGL(k_blitsaw<true>, dim3(batch), dim3(kBlock), 0, pgx::stream(), out, out_stride, n,
-                           channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state);
-    } else {
-        hipLaunchKernelGGL(k_blitsaw<false>, dim3(batch), dim3(kBlock), 0, pgx::stream(), out, out_stride, n,
-                           channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state);
-    }
+    // a few oscillators: 512-thread workgroups (half of the dependent tile steps, same bits);
+    // a bank: 256-thread workgroups, the oscillators themselves fill the machine
+    const bool wide = batch < 128 && n > kSawTile;
+    const bool streams = freq || amp || m;
+#define PGX_SAW_LAUNCH(S, NWAVES)                                                                              \
+    hipLaunchKernelGGL((k_blitsaw<S, NWAVES>), dim3(batch), dim3(NWAVES * 64), 0, pgx::stream(), out, out_stride, \
+                       n, channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state)
+    if (streams && wide) PGX_SAW_LAUNCH(true, kSawWideWaves);
+    else if (streams) PGX_SAW_LAUNCH(true, kWaves);
+    else if (wide) PGX_SAW_LAUNCH(false, kSawWideWaves);
+    else PGX_SAW_LAUNCH(false, kWaves);
+#undef PGX_SAW_LAUNCH
     PGX_LAUNCH_CHECK("k_blitsaw");
     return PGX_OK;
 }

@@ -104,3 +104,32 @@ def test_sharded_world1_equals_mix():
     gb = _render_blocks(b, 48000, [(0, 6000), (6000, 6000)])
     for x, y in zip(ga, gb):
         assert np.array_equal(x, y)
+
+
+def test_wide_blitsaw_workgroups_reproduce_the_bank_kernel_bit_for_bit():
+    """A lone oscillator renders with 512-thread workgroups (4096-frame tiles), an oscillator inside a bank of
+    128+ with 256-thread ones (2048-frame tiles): the wave values are folded in the same order, so the samples
+    must be identical -- also across block boundaries and with a partial last tile."""
+    import numpy as np
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+    sr = 48000.0
+    freqs = [27.5 * 2 ** (i / 48.0) for i in range(130)]
+    rec = np.zeros(len(freqs), dtype=device.BLITSAW_PARAMS)
+    for i, f in enumerate(freqs):
+        rec[i] = (f, 1.0, 0.999, 0.0)
+    params = device.upload_structs(rec)
+    blocks = [20000, 8192, 8193, 3000]
+    state_bank = device.DeviceBuffer((len(freqs), 2), np.float64, zero=True)
+    state_one = device.DeviceBuffer((1, 2), np.float64, zero=True)
+    pick = 77
+    one_params = device.upload_structs(rec[pick:pick + 1])
+    for n in blocks:
+        bank = device.DeviceBuffer((len(freqs), n, 1), np.float32)
+        device.check(lib.pgx_blitsaw(bank.ptr, n, len(freqs), n, 1, sr, params.ptr, None, 0, None, 0, None, 0,
+                                     state_bank.ptr))
+        one = device.DeviceBuffer((1, n, 1), np.float32)
+        device.check(lib.pgx_blitsaw(one.ptr, n, 1, n, 1, sr, one_params.ptr, None, 0, None, 0, None, 0,
+                                     state_one.ptr))
+        assert np.array_equal(bank.to_host()[pick], one.to_host()[0]), n
+    assert np.array_equal(state_bank.to_host()[pick], state_one.to_host()[0])
