@@ -250,6 +250,16 @@ int pgx_piecewise(float *out, int64_t start, int64_t n, int channels, const int6
 int pgx_f32_to_pcm16(int16_t *out, const float *in, int64_t n_elems);
 int pgx_pcm16_to_f32(float *out, const int16_t *in, int64_t n_elems);
 
+/* ------------------------------------------------------------------ SpatialPE (section 8f rank 2)
+ * SpatialAdapter.render (spatial_pe.py:94-144): M -> N channels. */
+int pgx_channel_adapt(float *out, const float *in, int64_t n, int src_channels, int out_channels);
+/* SpatialLinear / SpatialConstantPower.render (spatial_pe.py:179-214, 250-286): mono mix of the source
+ * panned to stereo; azimuth in degrees, clipped to +-90; azimuth_stream: per-frame float32 or NULL. */
+int pgx_pan(float *out, const float *in, int64_t n, int src_channels, float azimuth,
+            const float *azimuth_stream, int constant_power);
+/* out[i] = float32 mean of frame i's channels (the mono mix SpatialHRTF convolves, spatial_pe.py:483) */
+int pgx_mono_mean(float *out, const float *in, int64_t n, int src_channels);
+
 /* ------------------------------------------------------------------ BlitSawPE / SuperSawPE
  * BlitSawPE._render (blit_saw_pe.py:150-264): phase cumsum -> mod 1 -> Dirichlet kernel
  * -> leaky integrator -> *2 *amp -> float32.  state[instance] = {phase, integrator}.

@@ -50,6 +50,9 @@ def load_reference():
     nb.jit = _passthrough
     nb.njit = _passthrough
     sys.modules["numba"] = nb
+    # spatial_pe imports soundfile (absent) at module level; only SpatialHRTF._load_ir calls it, and the
+    # HRTF cases pre-fill the instance's IR cache from the fixture WAVs, so an empty module is enough
+    sys.modules.setdefault("soundfile", types.ModuleType("soundfile"))
     pkg = types.ModuleType("pygmu2")
     pkg.__path__ = [REF]
     sys.modules["pygmu2"] = pkg
@@ -59,7 +62,7 @@ def load_reference():
                  "blit_saw_pe", "super_saw_pe", "ladder_pe", "comb_pe", "adsr_pe",
                  "periodic_gate", "periodic_trigger", "convolve_pe", "svfilter_pe", "envelope_pe",
                  "transform_pe", "wavetable_pe", "delay_pe", "piecewise_pe", "trigger_restart_pe", "cache_pe",
-                 "reverb_pe"):
+                 "reverb_pe", "assets", "spatial_pe"):
         mods[name] = importlib.import_module(f"pygmu2.{name}")
     return mods
 
@@ -130,6 +133,24 @@ def build(spec, M):
         if "mode" in kw:
             kw["mode"] = M["envelope_pe"].DetectionMode(kw["mode"])
         return M["envelope_pe"].EnvelopePE(**kw)
+    if kind == "SpatialPE":
+        sp = M["spatial_pe"]
+        method = kw["method"]
+        if method == "adapter":
+            meth = sp.SpatialAdapter(kw["channels"])
+        elif method == "linear":
+            meth = sp.SpatialLinear(kw["azimuth"])
+        elif method == "constant_power":
+            meth = sp.SpatialConstantPower(kw["azimuth"])
+        else:
+            meth = sp.SpatialHRTF(kw["azimuth"], kw.get("elevation", 0.0))
+            name = sp.SpatialHRTF.hrtf_filename_for(meth.azimuth, meth.elevation)
+            import wave
+            with wave.open(os.path.join(ROOT, "tests", "golden", "kemar", name), "rb") as w:
+                pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, w.getnchannels())
+                # libsndfile's PCM16 -> float32 (x / 32768), what sf.read(dtype="float32") returns
+                meth._ir_cache[name] = ((pcm.astype(np.float32) * np.float32(1.0 / 32768.0)), w.getframerate())
+        return sp.SpatialPE(kw["source"], method=meth)
     if kind == "DelayPE":
         if "interpolation" in kw:
             kw["interpolation"] = M["wavetable_pe"].InterpolationMode(kw["interpolation"])

@@ -405,6 +405,27 @@ def cases():
                                                               S("SinePE", frequency=3.0, amplitude=0.4)]),
           fft_size=1024), blocks_contig(0, [1000, 1400]))
 
+    # ---------------------------------------------------------------- SpatialPE
+    def chans(c, seed):
+        return S("ArrayPE", data={"rng": seed, "n": 1500, "ch": c, "scale": 0.5})
+    for src_c, out_c in ((1, 2), (2, 1), (2, 4), (4, 2), (3, 5), (5, 2), (1, 4), (2, 2)):
+        add(f"spatial_adapter_{src_c}_to_{out_c}", 44100,
+            S("SpatialPE", source=chans(src_c, 50 + src_c), method="adapter", channels=out_c), [[-10, 800], [790, 800]])
+    sweep = S("SinePE", frequency=0.7, amplitude=120.0)           # beyond +-90: exercises the clip
+    add("spatial_linear_scalar", 44100, S("SpatialPE", source=chans(2, 60), method="linear", azimuth=-35.0),
+        [[0, 1500]])
+    add("spatial_linear_pe", 44100, S("SpatialPE", source=chans(1, 61), method="linear", azimuth=sweep),
+        blocks_contig(0, [1000, 500]))
+    add("spatial_constant_power_scalar", 44100,
+        S("SpatialPE", source=chans(2, 62), method="constant_power", azimuth=50.0), [[0, 1500]])
+    add("spatial_constant_power_pe", 44100,
+        S("SpatialPE", source=chans(3, 63), method="constant_power", azimuth=sweep), blocks_contig(0, [1000, 500]))
+    add("spatial_hrtf_right", 44100, S("SpatialPE", source=chans(1, 64), method="hrtf", azimuth=45.0),
+        blocks_contig(0, [700, 100, 17, 683]))
+    add("spatial_hrtf_left_stereo_src", 44100,
+        S("SpatialPE", source=chans(2, 65), method="hrtf", azimuth=-30.0, elevation=2.0),
+        [[0, 600], [600, 600], [100, 300]])                       # last block not contiguous: tail cleared
+
     # ---------------------------------------------------------------- Convolve
     add("conv_kat", 10000,
         S("ConvolvePE", src=S("ArrayPE", data={"values": [1.0, 2.0, 3.0, 4.0]}),

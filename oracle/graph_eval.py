@@ -101,6 +101,8 @@ class Node:
             self.state = O.convolve_state()
         elif k == "TriggerRestartPE":
             self.state = {"t0": None}
+        elif k == "SpatialPE" and kw["method"] == "hrtf":
+            self.state = getattr(self, "state", None) or O.hrtf_state()     # survives start() like the reference's
         if not recursive:
             return
         for s in self.sub.values():
@@ -120,6 +122,8 @@ class Node:
             return self.sub["inputs"][0].channels()
         if k == "PiecewisePE":
             return int(kw.get("channels", 1))
+        if k == "SpatialPE":
+            return int(kw["channels"]) if kw["method"] == "adapter" else 2
         if k == "TriggerRestartPE":
             return self.sub["src"].channels()
         if k == "ConvolvePE":
@@ -307,6 +311,22 @@ class Node:
             return self._trigger_restart(start, n)
         if k == "ReverbPE":
             return self._reverb(start, n)
+        if k == "SpatialPE":
+            x = self.sub["source"].render(start, n)
+            m = kw["method"]
+            if m == "adapter":
+                return O.spatial_adapter(x, int(kw["channels"]))
+            if m in ("linear", "constant_power"):
+                az = self.sub["azimuth"].render(start, n)[:, 0] if "azimuth" in self.sub else kw["azimuth"]
+                return O.spatial_pan(x, az, m == "constant_power")
+            if "ir" not in self.state:
+                import os
+                from pygmu2_amd import wav_io
+                path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                    "kemar", O.kemar_filename(kw["azimuth"], kw.get("elevation", 0.0)))
+                info = wav_io.read_info(path)
+                self.state["ir"] = O.pcm16_to_float(wav_io.read_frames(path, info, 0, info.frames))
+            return O.spatial_hrtf(self.state, x, start, self.state["ir"], float(kw["azimuth"]))
         if k == "ConvolvePE":
             if "h" not in self.state:
                 L = self.sub["fir"].extent()[1]

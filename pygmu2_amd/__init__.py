@@ -46,6 +46,8 @@ from .delay_pe import DelayPE, InterpolationMode
 from .piecewise_pe import PiecewisePE, TransitionType
 from .trigger_restart_pe import TriggerRestartPE
 from .reverb_pe import ReverbPE
+from .spatial_pe import (SpatialAdapter, SpatialConstantPower, SpatialHRTF, SpatialLinear, SpatialMethod,
+                         SpatialPE)
 from .wav_writer_pe import WavWriterPE
 from .wav_reader_pe import WavReaderPE
 from .utils import render_to_file
@@ -59,5 +61,6 @@ __all__ = [
     "SuperSawPE", "LadderMode", "LadderPE", "CombPE", "PeriodicGate", "PeriodicTrigger", "AdsrGatedPE",
     "AdsrTriggeredPE", "ConvolvePE", "SVFilterPE", "DetectionMode", "EnvelopePE", "TransformPE",
     "transforms", "DelayPE", "InterpolationMode", "PiecewisePE", "TransitionType", "TriggerRestartPE",
-    "ReverbPE", "WavWriterPE", "WavReaderPE", "render_to_file", "device", "diagnostics",
+    "ReverbPE", "SpatialPE", "SpatialMethod", "SpatialAdapter", "SpatialLinear", "SpatialConstantPower",
+    "SpatialHRTF", "WavWriterPE", "WavReaderPE", "render_to_file", "device", "diagnostics",
 ]

@@ -158,9 +158,106 @@ k_pcm16_to_f32(float *out, const int16_t *in, int64_t n) {
         out[i] = (float)in[i] * (1.0f / 32768.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SpatialPE (spatial_pe.py:94-144, 179-214, 250-286): channel adaptation and stereo panning, float32
+// arithmetic like the reference's numpy expressions (np.mean of a float32 row: sequential float32 sum / n).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_mean(const float *row, int from, int to) {
+    float acc = row[from];
+    for (int c = from + 1; c < to; ++c) acc = acc + row[c];
+    return acc / (float)(to - from);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_channel_adapt(float *out, const float *in, int64_t n, int src_ch, int out_ch) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float *x = in + i * src_ch;
+        float *y = out + i * out_ch;
+        if (src_ch == 1) {
+            for (int c = 0; c < out_ch; ++c) y[c] = x[0];
+        } else if (out_ch == 1) {
+            y[0] = row_mean(x, 0, src_ch);
+        } else if (src_ch == 2 && out_ch == 4) {
+            const float cs = row_mean(x, 0, 2);
+            y[0] = x[0]; y[1] = x[1]; y[2] = cs; y[3] = cs;
+        } else if (src_ch == 4 && out_ch == 2) {
+            y[0] = x[0]; y[1] = x[1];
+        } else if (out_ch > src_ch) {
+            for (int c = 0; c < src_ch; ++c) y[c] = x[c];
+            for (int c = src_ch; c < out_ch; ++c) y[c] = x[src_ch - 1];
+        } else {
+            for (int c = 0; c < out_ch; ++c) y[c] = x[c];
+            y[out_ch - 1] = y[out_ch - 1] + row_mean(x, out_ch, src_ch);
+        }
+    }
+}
+
+// mode 0: linear (L = 1 - pan, R = pan, pan = (az + 90) / 180); 1: constant power (cos / sin of (az + 90) / 2 deg)
+__global__ void __launch_bounds__(kBlock)
+k_pan(float *out, const float *in, int64_t n, int src_ch, float az_scalar, const float *az_stream, int mode) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float mono = row_mean(in + i * src_ch, 0, src_ch);
+        float az = az_stream ? az_stream[i] : az_scalar;
+        az = az < -90.0f ? -90.0f : (az > 90.0f ? 90.0f : az);
+        float lg, rg;
+        if (mode == 0) {
+            const float pan = (az + 90.0f) / 180.0f;
+            lg = 1.0f - pan;
+            rg = pan;
+        } else {
+            const float ang = ((az + 90.0f) / 2.0f) * (float)(3.141592653589793 / 180.0);   // np.deg2rad in float32
+            lg = cosf(ang);
+            rg = sinf(ang);
+        }
+        out[i * 2 + 0] = mono * lg;
+        out[i * 2 + 1] = mono * rg;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_mono_mean(float *out, const float *in, int64_t n, int src_ch) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = row_mean(in + i * src_ch, 0, src_ch);
+}
+
 }  // namespace
 
 extern "C" {
+
+int pgx_channel_adapt(float *out, const float *in, int64_t n, int src_channels, int out_channels) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && src_channels >= 1 && out_channels >= 1, "pgx_channel_adapt: bad argument");
+    hipLaunchKernelGGL(k_channel_adapt, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out, in, n,
+                       src_channels, out_channels);
+    PGX_LAUNCH_CHECK("k_channel_adapt");
+    return PGX_OK;
+}
+
+int pgx_pan(float *out, const float *in, int64_t n, int src_channels, float azimuth, const float *azimuth_stream,
+            int constant_power) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && src_channels >= 1, "pgx_pan: bad argument");
+    hipLaunchKernelGGL(k_pan, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out, in, n,
+                       src_channels, azimuth, azimuth_stream, constant_power ? 1 : 0);
+    PGX_LAUNCH_CHECK("k_pan");
+    return PGX_OK;
+}
+
+int pgx_mono_mean(float *out, const float *in, int64_t n, int src_channels) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && src_channels >= 1, "pgx_mono_mean: bad argument");
+    hipLaunchKernelGGL(k_mono_mean, dim3(pgx::grid_for(n, kBlock)), dim3(kBlock), 0, pgx::stream(), out, in, n,
+                       src_channels);
+    PGX_LAUNCH_CHECK("k_mono_mean");
+    return PGX_OK;
+}
+
 
 int pgx_interp_lookup(float *out, const float *window, int64_t window_start, int64_t window_len, int channels,
                       int64_t start, int64_t n, double delay_scalar, const float *delay, int cubic, int bounded,

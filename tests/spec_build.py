@@ -51,6 +51,20 @@ def build(spec):
         return pg.EnvelopePE(**kw)
     if kind == "TransformPE":
         return pg.TransformPE(kw["source"], func=pg.transforms.from_spec(kw["ops"]), name="ops")
+    if kind == "SpatialPE":
+        import os
+        m = kw["method"]
+        if m == "adapter":
+            method = pg.SpatialAdapter(kw["channels"])
+        elif m == "linear":
+            method = pg.SpatialLinear(kw["azimuth"])
+        elif m == "constant_power":
+            method = pg.SpatialConstantPower(kw["azimuth"])
+        else:
+            method = pg.SpatialHRTF(kw["azimuth"], kw.get("elevation", 0.0),
+                                    kemar_dir=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                           "kemar"))
+        return pg.SpatialPE(kw["source"], method=method)
     if kind == "DelayPE":
         if "interpolation" in kw:
             kw["interpolation"] = pg.InterpolationMode(kw["interpolation"])

@@ -37,6 +37,9 @@ BIT_EXACT = {
     "transform_chain",
     "delay_int", "delay_int_negative", "delay_float_linear", "delay_float_cubic",
     "piecewise_step", "piecewise_linear", "piecewise_single_point", "piecewise_single_point_zero",
+    "spatial_adapter_1_to_2", "spatial_adapter_2_to_1", "spatial_adapter_2_to_4", "spatial_adapter_4_to_2",
+    "spatial_adapter_3_to_5", "spatial_adapter_5_to_2", "spatial_adapter_1_to_4", "spatial_adapter_2_to_2",
+    "spatial_linear_scalar",
 }
 
 

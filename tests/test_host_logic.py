@@ -349,3 +349,21 @@ def test_biquad_settle_frames_bounds_the_state_matrix():
     assert np.max(np.abs(np.linalg.matrix_power(a, w // 2))) >= 2.0 ** -90
     assert settle_frames(-1.999, 0.9991) == 0          # poles at radius ~0.9995: no usable horizon
     assert settle_frames(-2.1, 1.2) == 0               # unstable
+
+
+def test_kemar_grid_and_nearest_file_rule():
+    from pygmu2_amd.spatial_pe import SpatialHRTF, kemar_entries
+    entries = kemar_entries()
+    assert len(entries) == 368 and entries[0] == (-40, 0, "H-40e000a.wav") and entries[-1] == (90, 0, "H90e000a.wav")
+    assert (50, 176, "H50e176a.wav") in entries and (-40, 6, "H-40e006a.wav") in entries
+    assert SpatialHRTF.hrtf_filename_for(45.0, 0.0) == "H0e045a.wav"
+    assert SpatialHRTF.hrtf_filename_for(-30.0, 2.0) == "H0e030a.wav"          # mirrored hemisphere, nearest elevation
+    assert SpatialHRTF.hrtf_filename_for(200.0, 95.0) == "H80e180a.wav"          # azimuth saturates at 180
+    assert SpatialHRTF.hrtf_filename_for(3.0, 95.0) == "H90e000a.wav"
+    with pytest.raises(ValueError, match="static"):
+        SpatialHRTF(pg.SinePE(frequency=1.0), 0.0)
+    with pytest.raises(ValueError, match="channels must be >= 1"):
+        pg.SpatialAdapter(0)
+    pe = pg.SpatialPE(pg.ConstantPE(0.5), method=pg.SpatialConstantPower(pg.SinePE(frequency=0.5, amplitude=90.0)))
+    assert pe.channel_count() == 2 and pe.is_pure() and len(pe.inputs()) == 2
+    assert "SpatialConstantPower(azimuth=SinePE)" in repr(pe)
