@@ -24,7 +24,7 @@ import numpy as np
 from . import device as _dev
 from ._kernels import DeviceBuffer, check, lib, ptr
 from .adsr_pe import AdsrGatedPE
-from .biquad_pe import BiquadPE, rbj_coefficients
+from .biquad_pe import BiquadPE, rbj_coefficients, settle_frames
 from .blit_saw_pe import BlitSawPE
 from .extent import Extent
 from .gain_pe import GainPE
@@ -148,6 +148,11 @@ class _BiquadNode(_Node):
         coef = np.array([rbj_coefficients(pe._mode, pe._frequency, pe._q, pe._gain_db, self.sr)
                          for pe in pes], dtype=np.float64)
         self.coef = DeviceBuffer.from_host(coef)
+        # one warm-up horizon for the batch (0 = some voice decays too slowly: exact path).  It only matters
+        # for small banks, where the library cuts each voice into time segments to fill the machine; a
+        # 512-voice bank is one workgroup per voice either way.
+        settles = [settle_frames(c[3], c[4]) for c in coef]
+        self.settle = 0 if min(settles) == 0 else max(settles)
         self.tables = None           # per-voice powers of A (pgx_biquad_tables), made on first render
         self.state = None
         self.ws = None
@@ -169,13 +174,12 @@ class _BiquadNode(_Node):
         if self.tables is None:
             self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
             check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
-        # settle_frames = 0: a bank has a workgroup per voice, nothing is gained by cutting voices in time
-        need = L.pgx_biquad_workspace_bytes(self.k, n, ch, 0)
+        need = L.pgx_biquad_workspace_bytes(self.k, n, ch, self.settle)
         if need and (self.ws is None or self.ws.nbytes < need):
             self.ws = DeviceBuffer((need,), np.uint8)
         out = DeviceBuffer((self.k, n, ch), np.float32)
         check(L.pgx_biquad_const(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.coef.ptr,
-                                 self.tables.ptr, 0, self.state.ptr, ptr(self.ws) if need else None),
+                                 self.tables.ptr, self.settle, self.state.ptr, ptr(self.ws) if need else None),
               "pgx_biquad_const")
         return out
 
