@@ -441,6 +441,13 @@ def main():
                                "voice_msamples_s": round(512 * vframes * 10 / vdt / 1e6, 1),
                                "ms_per_block": round(vdt / 10 * 1e3, 4), "scaling": "strong",
                                "workload": vname, "steps": 10, "warmup": 2}
+        # north_star's scaling case: 512 SuperSaw voices (3584 oscillators) -- throughput-bound, so it is the
+        # sharded workload that can scale with the GPU count (the C5 voices above are latency-bound chains)
+        sdt, sframes, sname = bench_voice_mix(pg, dist, 6, 2, config="supersaw")
+        result["supersaw_mix"] = {"value": round(sframes * 6 / sdt / 1e6, 3), "unit": "Msamples/s",
+                                  "oscillator_msamples_s": round(3584 * sframes * 6 / sdt / 1e6, 1),
+                                  "ms_per_block": round(sdt / 6 * 1e3, 4), "scaling": "strong",
+                                  "workload": sname, "steps": 6, "warmup": 2}
 
     if dist.rank == 0 and not args.no_extras:
         result["device"] = device.device_name()

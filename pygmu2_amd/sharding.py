@@ -54,7 +54,13 @@ class _Silence(ProcessingElement):
 
 
 class TorchReducer:
-    """all-reduce(sum) of a Snippet payload through torch.distributed (nccl == RCCL on ROCm)."""
+    """all-reduce(sum) of a Snippet payload through torch.distributed (nccl == RCCL on ROCm).
+
+    Device payloads are reduced in place, zero-copy (__cuda_array_interface__), without blocking the host:
+    the collective is ordered behind the library stream with stream waits, and the returned Snippet carries
+    a `ready` hook that orders the library stream behind the collective only when its payload is used.
+    Rendering the next block therefore overlaps the previous block's all-reduce over xGMI.
+    """
 
     def __init__(self):
         import torch
@@ -64,17 +70,31 @@ class TorchReducer:
             raise RuntimeError("torch.distributed is not initialised")
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self._lib_stream = None
+        self._comm_stream = None
+
+    def _streams(self):
+        if self._lib_stream is None:
+            from . import device as _dev
+            handle = _dev.ensure_init().pgx_stream_handle()
+            self._lib_stream = self.torch.cuda.ExternalStream(int(handle))
+            self._comm_stream = self.torch.cuda.Stream()
+        return self._lib_stream, self._comm_stream
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         torch, dist = self.torch, self.dist
         if snippet.on_device:
-            from . import device as _dev
             buf = snippet.dev
-            _dev.synchronize()                          # library stream -> visible to torch's stream
+            lib_stream, comm = self._streams()
             t = torch.as_tensor(buf, device="cuda")     # zero-copy via __cuda_array_interface__
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            torch.cuda.current_stream().synchronize()
-            return Snippet(snippet.start, buf)
+            comm.wait_stream(lib_stream)                # the collective starts after the local mix is complete
+            with torch.cuda.stream(comm):
+                work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+            def ready():
+                with torch.cuda.stream(lib_stream):
+                    work.wait()                         # stream-level wait: the host is not blocked
+            return Snippet(snippet.start, buf, ready=ready)
         t = torch.from_numpy(np.ascontiguousarray(snippet.data).copy())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return Snippet(snippet.start, t.numpy())
@@ -149,6 +169,11 @@ def c4_voice(pg, i: int):
                        frequency=1200.0, resonance=0.3, mode=pg.LadderMode.LP24, drive=1.0, oversample=2)
 
 
+def supersaw_voice(pg, i: int):
+    """north_star's "512-voice SuperSaw mix": voice i is a 7-oscillator SuperSawPE."""
+    return pg.SuperSawPE(55.0 * 2 ** (i / 96.0), voices=7, detune_cents=20.0, seed=i)
+
+
 def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c5"):
     """Sharded MixPE of BASELINE config 5 (512 voices) or 4 (64 SuperSaw->Ladder instances):
     inputs i = rank (mod world) on each GPU, one RCCL all-reduce of the (block, 1) partial mix
@@ -160,7 +185,7 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     pg.set_sample_rate(48000)
     world = dist.world if dist.enabled else 1
     rank = dist.rank if dist.enabled else 0
-    make = c5_voice if config == "c5" else c4_voice
+    make = {"c5": c5_voice, "c4": c4_voice, "supersaw": supersaw_voice}[config]
     root = ShardedMixPE([make(pg, i) for i in range(voices)], rank, world)
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
@@ -168,18 +193,27 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     keep = {}
     for i in range(warmup):
         keep["s"] = root.render(i * block, block)
+    keep["s"].dev
     device.synchronize()
+    if dist.enabled:
+        dist.torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         keep["s"] = root.render((warmup + i) * block, block)
-    device.synchronize()
+    keep["s"].dev                      # order the library stream behind the last block's all-reduce ...
+    device.synchronize()               # ... and wait for it: every block is rendered AND reduced
+    if dist.enabled:
+        dist.torch.cuda.synchronize()
     dist.barrier()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
     r.stop()
     if config == "c5":
         name = (f"C5: {voices}-voice polyphonic graph (BlitSawPE->BiquadPE->xAdsrGatedPE per voice)->MixPE, "
                 f"48 kHz mono, {block}-frame blocks, voices sharded i mod {world}")
+    elif config == "supersaw":
+        name = (f"{voices}-voice SuperSaw mix ({voices} x SuperSawPE 7 oscillators)->MixPE, 48 kHz mono, "
+                f"{block}-frame blocks, voices sharded i mod {world}")
     else:
         name = (f"C4: {voices} x LadderPE(SuperSawPE 7 voices)->MixPE, 48 kHz mono, {block}-frame blocks, "
                 f"instances sharded i mod {world}")

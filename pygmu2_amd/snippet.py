@@ -7,6 +7,11 @@ MI355X HBM (a DeviceBuffer produced by a HIP kernel).  `.data` is the reference'
 attribute: it returns a numpy view of the payload, copied device->host on first use and
 cached.  `.dev` returns the DeviceBuffer (uploading a host-constructed payload on first
 use), which is what downstream PEs consume, so a chain of PEs never leaves the device.
+
+A payload may still be in flight on another stream (the RCCL all-reduce of a sharded mix):
+`ready` is then a callable that orders the library stream behind that work; it runs once, the
+first time the payload is touched or when the Snippet is dropped (so the buffer cannot return to
+the pool early).
 """
 
 from __future__ import annotations
@@ -17,10 +22,11 @@ from .device import DeviceBuffer
 
 
 class Snippet:
-    __slots__ = ("_start", "_host", "_dev", "_shape")
+    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready")
 
-    def __init__(self, start: int, data):
+    def __init__(self, start: int, data, ready=None):
         self._start = int(start)
+        self._ready = ready
         if isinstance(data, DeviceBuffer):
             if data.dtype != np.float32 or len(data.shape) != 2:
                 raise ValueError("device payload must be float32 of shape (frames, channels)")
@@ -55,9 +61,21 @@ class Snippet:
     def channels(self) -> int:
         return self._shape[1]
 
+    def _resolve(self) -> None:
+        ready, self._ready = self._ready, None
+        if ready is not None:
+            ready()
+
+    def __del__(self):
+        try:
+            self._resolve()
+        except Exception:
+            pass
+
     @property
     def data(self) -> np.ndarray:
         """Host view (frames, channels) float32; treat as immutable."""
+        self._resolve()
         if self._host is None:
             self._host = self._dev.to_host()
         return self._host
@@ -65,6 +83,7 @@ class Snippet:
     @property
     def dev(self) -> DeviceBuffer:
         """Device payload (uploads a host-built snippet once)."""
+        self._resolve()
         if self._dev is None:
             self._dev = DeviceBuffer.from_host(np.ascontiguousarray(self._host))
         return self._dev

@@ -37,6 +37,19 @@ b = [plain.render(i * 4096, 4096).data for i in range(3)]
 r.stop()
 for x, y in zip(a, b):
     assert np.array_equal(x, y), float(np.max(np.abs(x - y)))
+# pipelined use: blocks are rendered back to back and dropped unread while their all-reduce may still be in
+# flight (the Snippet's `ready` hook must keep the buffer out of the pool until the collective is ordered)
+root2 = ShardedMixPE([c5_voice(pg, i) for i in range(6)], 0, 1)
+root2._world = 2
+root2._reducer = red
+r = pg.NullRenderer(48000); r.set_source(root2); r.start()
+keep = None
+for i in range(3):
+    keep = root2.render(i * 4096, 4096)
+assert keep._ready is not None       # nothing has forced the last reduce yet
+assert np.array_equal(keep.data, b[2])
+assert keep._ready is None
+r.stop()
 # the tensor view really aliases the library buffer
 from pygmu2_amd import device
 buf = device.DeviceBuffer.from_host(np.arange(8, dtype=np.float32))

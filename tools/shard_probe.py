@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""What one rank of a G-way sharded C5 run (argv: `supersaw` = the 512-voice SuperSaw mix) does -- its
+512/G voices, no collective: block time on one GPU.
+The per-voice chains are sequential in time, so this is the floor the RCCL version can reach."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pygmu2_amd as pg
+from pygmu2_amd import device
+from pygmu2_amd.sharding import c5_voice, shard_indices, supersaw_voice
+
+pg.set_sample_rate(48000)
+block = 48000
+make = supersaw_voice if sys.argv[1:] == ["supersaw"] else c5_voice
+for world in (1, 2, 4, 8):
+    voices = [make(pg, i) for i in shard_indices(512, 0, world)]
+    root = pg.MixPE(*voices)
+    r = pg.NullRenderer(sample_rate=48000)
+    r.set_source(root)
+    r.start()
+    for i in range(3):
+        root.render(i * block, block)
+    device.synchronize()
+    t0 = time.perf_counter()
+    reps = 20
+    for i in range(reps):
+        keep = root.render((3 + i) * block, block)
+    device.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    r.stop()
+    print(f"world={world}: {len(voices):3d} voices on this rank, {dt * 1e6:7.1f} us per 48000-frame block "
+          f"-> {block / dt / 1e6:6.1f} Msamples/s before the all-reduce", flush=True)
