@@ -27,43 +27,70 @@ _log = logging.getLogger("pygmu2_amd.renderer")
 
 @dataclass
 class PEProfile:
-    name: str
+    """Timing of one ProcessingElement (renderer.py:25-62: same fields and derived figures)."""
     pe_class: str
-    call_count: int = 0
+    pe_id: int
+    render_count: int = 0
     total_time_ns: int = 0
-    samples: int = 0
+    total_samples: int = 0
+    min_time_ns: int = 0
+    max_time_ns: int = 0
 
     @property
     def total_time_ms(self) -> float:
-        return self.total_time_ns / 1e6
+        return self.total_time_ns / 1_000_000
 
     @property
     def avg_time_ms(self) -> float:
-        return self.total_time_ms / self.call_count if self.call_count else 0.0
+        return self.total_time_ms / self.render_count if self.render_count else 0.0
+
+    @property
+    def samples_per_second(self) -> float:
+        return self.total_samples / (self.total_time_ns / 1_000_000_000) if self.total_time_ns else 0.0
+
+    def realtime_ratio(self, sample_rate: int = 44100) -> float:
+        if self.total_time_ns == 0:
+            return 0.0
+        return (self.total_samples / sample_rate) * 1_000_000_000 / self.total_time_ns
 
 
 @dataclass
 class ProfileReport:
+    """Profile of a render session (renderer.py:65-127).  On the device a block is a pipeline of
+    asynchronous launches, so the unit that can be timed honestly is the whole graph per render call (the
+    stream is synchronised around it while profiling); per-kernel times are rocprofv3's job."""
     pe_profiles: dict = field(default_factory=dict)
     total_render_time_ns: int = 0
+    total_output_time_ns: int = 0
     total_samples: int = 0
-    render_count: int = 0
+    render_calls: int = 0
 
-    @property
-    def total_render_time_ms(self) -> float:
-        return self.total_render_time_ns / 1e6
-
-    def realtime_ratio(self, sample_rate: int) -> float:
-        if not self.total_render_time_ns:
-            return 0.0
-        return (self.total_samples / sample_rate) / (self.total_render_time_ns / 1e9)
+    def add_pe_timing(self, pe: ProcessingElement, time_ns: int, samples: int) -> None:
+        key = id(pe)
+        prof = self.pe_profiles.get(key)
+        if prof is None:
+            prof = self.pe_profiles[key] = PEProfile(pe_class=type(pe).__name__, pe_id=key, min_time_ns=time_ns,
+                                                     max_time_ns=time_ns)
+        prof.render_count += 1
+        prof.total_time_ns += time_ns
+        prof.total_samples += samples
+        prof.min_time_ns = min(prof.min_time_ns, time_ns)
+        prof.max_time_ns = max(prof.max_time_ns, time_ns)
 
     def summary(self, sample_rate: int = 44100) -> str:
-        lines = [f"renders: {self.render_count}  samples: {self.total_samples}  "
-                 f"time: {self.total_render_time_ms:.3f} ms  "
-                 f"x{self.realtime_ratio(sample_rate):.1f} realtime"]
-        for p in sorted(self.pe_profiles.values(), key=lambda q: -q.total_time_ns):
-            lines.append(f"  {p.name:<40s} calls={p.call_count:<6d} total={p.total_time_ms:.3f} ms")
+        lines = ["=" * 70, "RENDER PROFILE REPORT", "=" * 70,
+                 f"Total render calls: {self.render_calls}", f"Total samples: {self.total_samples:,}",
+                 f"Total render time: {self.total_render_time_ns / 1_000_000:.2f} ms",
+                 f"Total output time: {self.total_output_time_ns / 1_000_000:.2f} ms"]
+        if self.total_render_time_ns > 0:
+            ratio = (self.total_samples / sample_rate) * 1_000_000_000 / self.total_render_time_ns
+            lines.append(f"Realtime ratio: {ratio:.1f}x (>1.0x is faster than realtime)")
+        lines += ["", "PER-PE BREAKDOWN (sorted by total time):", "-" * 70,
+                  f"{'PE Class':<20} {'Calls':>8} {'Total ms':>10} {'Avg ms':>10} {'Samples/s':>12}", "-" * 70]
+        for p in sorted(self.pe_profiles.values(), key=lambda q: q.total_time_ns, reverse=True):
+            lines.append(f"{p.pe_class:<20} {p.render_count:>8} {p.total_time_ms:>10.2f} {p.avg_time_ms:>10.4f} "
+                         f"{p.samples_per_second:>12,.0f}")
+        lines.append("=" * 70)
         return "\n".join(lines)
 
 
@@ -137,22 +164,25 @@ class Renderer(ABC):
                          fatal=True, exception_class=ValueError)
             return
         if self._profiling and self._profile_report is not None:
+            from . import device as _dev
+
+            def settle():                    # device work is asynchronous: drain the stream around the render
+                if _dev._initialised:
+                    _dev.synchronize()
+
+            rep = self._profile_report
+            settle()
             t0 = time.perf_counter_ns()
             snippet = self._source.render(start, duration)
+            settle()
+            t1 = time.perf_counter_ns()
             self._output(snippet)
-            dt = time.perf_counter_ns() - t0
-            rep = self._profile_report
-            rep.render_count += 1
-            rep.total_render_time_ns += dt
+            t2 = time.perf_counter_ns()
+            rep.render_calls += 1
             rep.total_samples += duration
-            key = id(self._source)
-            prof = rep.pe_profiles.get(key)
-            if prof is None:
-                cls = type(self._source).__name__
-                prof = rep.pe_profiles[key] = PEProfile(name=f"{cls} (whole graph)", pe_class=cls)
-            prof.call_count += 1
-            prof.total_time_ns += dt
-            prof.samples += duration
+            rep.total_render_time_ns += t1 - t0
+            rep.total_output_time_ns += t2 - t1
+            rep.add_pe_timing(self._source, t1 - t0, duration)      # the root stands for its whole graph
         else:
             self._output(self._source.render(start, duration))
 

@@ -206,7 +206,12 @@ def test_renderer_profiling_report():
     r.render(0, 100)
     r.render(100, 100)
     rep = r.get_profile_report()
-    assert rep.render_count == 2 and rep.total_samples == 200 and "whole graph" in rep.summary(1000)
+    assert rep.render_calls == 2 and rep.total_samples == 200 and rep.total_render_time_ns > 0
+    (prof,) = rep.pe_profiles.values()
+    assert prof.pe_class == "HostRamp" and prof.render_count == 2 and prof.total_samples == 200
+    assert prof.min_time_ns <= prof.max_time_ns and prof.samples_per_second > 0 and prof.realtime_ratio(1000) > 0
+    text = rep.summary(1000)
+    assert "RENDER PROFILE REPORT" in text and "Total render calls: 2" in text and "HostRamp" in text
 
 
 # ------------------------------------------------------------------ PE graph plumbing that needs no device
