@@ -5,6 +5,10 @@
 //   BlitSawPE            : prefix sum (phase) + 1-state constant map (leaky integrator)
 //                          (blit_saw_pe.py:150-264)
 //   SinePE (stateful)    : prefix sum (phase)        (sine_pe.py:177-232)
+//   SVFilterPE           : 2-state map with a full 2x2 A, constant or per sample (svfilter_pe.py:41-205)
+//   EnvelopePE           : 1-state map; with attack != release a walk over regimes (envelope_pe.py:128-271)
+//   TransformPE          : element-wise op chains (transform_pe.py:96-152) -- no recurrence, kept here
+//                          with the PEs of the same reference script
 //
 // Common structure (wave64, 256-thread workgroups = 4 waves):
 //   * a tile is 256 threads x T consecutive frames; every thread folds its T frames into one
@@ -19,10 +23,15 @@
 // So the only departure from the reference's sequential float64 arithmetic is the rounding
 // of each chunk's carry-in (O(1e-16) relative); everything is compiled with -ffp-contract=off.
 //
-// Long single chains (BiquadPE over 1M frames) are cut into segments, one workgroup each:
-// a reduce launch produces every segment's zero-state response, the apply launch folds the
-// preceding aggregates (binary powers of A^segment) into its carry-in.  Many short chains
-// (voices) use one workgroup per chain and no cross-workgroup traffic at all.
+// Long chains are cut into segments, one workgroup each, in one of three ways:
+//   * constant sections that forget (k_biquad_settled): each workgroup rebuilds its carry-in from a
+//     short warm-up over the frames before its range -- one launch, no cross-workgroup traffic;
+//   * constant sections that decay slowly (k_biquad_const<reduce/apply>): a reduce launch produces every
+//     segment's zero-state response, the apply launch folds the preceding aggregates (binary powers of
+//     A^segment) into its carry-in -- exact for any section;
+//   * time-varying maps (k_biquad_varying / k_svf <reduce/apply>): the reduce launch composes each
+//     segment's affine map, the apply launch folds the earlier maps onto the carried state.
+// Many short chains (voices) use one workgroup per chain and no cross-workgroup traffic at all.
 
 #include "pgx_common.h"
 
