@@ -249,6 +249,13 @@ __device__ __forceinline__ double adsr_chunk(AdsrCtx &cx, const pgx_adsr_params 
                 if (t >= 0 && t < take) mine = v;
                 c.env = c.env + (double)take * c.dq;               // exact: `take` regular steps
                 a += take;
+                if (bad) {
+                    // the sample that ended the run (no edge on it: edges sit at `limit`) takes its literal
+                    // step right here instead of costing another trip round the loop
+                    if (lane == a) mine = c.env;
+                    adsr_step(c, p, TRIG, now0 + a);
+                    a += 1;
+                }
                 continue;
             }
             c.have = false;
