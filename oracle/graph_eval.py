@@ -191,6 +191,8 @@ class Node:
             se = self.sub["source"].extent()
             L = self.sub["ir"].extent()[1]
             return _union(se, (se[0], None if se[1] is None else se[1] + L - 1))
+        if k in ("TransformPE", "EnvelopePE", "SpatialPE"):
+            return self.sub["source"].extent()       # transform_pe.py:92-94, envelope_pe.py:104-106, spatial_pe.py:638-640
         if k in ("SinePE", "BlitSawPE", "SuperSawPE", "PeriodicGate"):
             ext = INF
             for name in ("frequency", "amplitude", "phase", "m", "duty_cycle"):

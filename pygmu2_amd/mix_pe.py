@@ -64,6 +64,10 @@ class MixPE(ProcessingElement):
             self._bank = try_build_bank(self._inputs) or False
         return self._bank
 
+    def _read_ahead_condition(self) -> bool:
+        # the skip rule below looks at the requested window; with bounded inputs a larger window changes it
+        return all(pe.extent().start is None and pe.extent().end is None for pe in self._inputs)
+
     def _render(self, start: int, duration: int) -> Snippet:
         bank = self._voice_bank()
         if bank:

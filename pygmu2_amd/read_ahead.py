@@ -10,7 +10,10 @@ kernel on these paths computes a frame from its absolute index alone (IdentityPE
 numpy `arange` fill rule depends on the block start for |index| >= 2^24).
 
 Scope: SinePE with scalar parameters, GainPE, MixPE, ConstantPE, DiracPE, ArrayPE, CropPE,
-PeriodicGate, PeriodicTrigger -- and only when every input is itself eligible.
+PeriodicGate, PeriodicTrigger -- and only when every input is itself eligible.  MixPE only while all
+of its inputs have unbounded extents: its rule "skip an input whose extent misses the requested window"
+(mix_pe.py:81-85) makes the output depend on the window, not just the frame index, as soon as an input
+is non-zero outside its extent (ArrayPE / CropPE hold modes).
 Disable with PYGMU_READ_AHEAD=0.
 """
 
@@ -41,6 +44,9 @@ def eligible(pe) -> bool:
     if cached is None:
         cached = bool(getattr(pe, "_READ_AHEAD_SAFE", False)) and pe.is_pure() and all(
             eligible(child) for child in pe.inputs())
+        extra = getattr(pe, "_read_ahead_condition", None)     # PE-specific: e.g. MixPE's window-dependent skip rule
+        if cached and extra is not None:
+            cached = bool(extra())
         pe.__dict__["_ra_ok"] = cached
     return cached
 

@@ -1,0 +1,122 @@
+"""
+GPU: seeded random graphs of the supported PEs, rendered in random contiguous blocks (negative starts,
+odd lengths), HIP path vs oracle.  A differential net under the hand-picked golden cases: channel rules,
+extent intersections, state carried across awkward block boundaries, PE-valued parameters.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+ABS_FLOOR = 1e-7
+
+
+def _source(rng, ch):
+    kind = rng.choice(["sine", "array", "blitsaw", "const", "supersaw"])
+    if kind == "sine":
+        return {"pe": "SinePE", "frequency": float(rng.uniform(50, 3000)), "amplitude": float(rng.uniform(0.1, 1.0)),
+                "phase": float(rng.uniform(0, 6.0)), "channels": ch}
+    if kind == "array":
+        return {"pe": "ArrayPE", "data": {"rng": int(rng.integers(1000)), "n": int(rng.integers(500, 6000)), "ch": ch,
+                                          "scale": 0.5},
+                "extend_mode": str(rng.choice(["zero", "hold_last", "hold_both"]))}
+    if kind == "blitsaw":
+        return {"pe": "BlitSawPE", "frequency": float(rng.uniform(40, 2000)), "amplitude": float(rng.uniform(0.2, 1.0)),
+                "channels": ch}
+    if kind == "supersaw":
+        return {"pe": "SuperSawPE", "frequency": float(rng.uniform(60, 800)), "voices": int(rng.integers(2, 6)),
+                "seed": int(rng.integers(100)), "channels": ch}
+    return {"pe": "ConstantPE", "value": float(rng.uniform(-1, 1)), "channels": ch}
+
+
+def _control(rng, lo, hi):
+    mid, span = (lo + hi) / 2.0, (hi - lo) / 2.0 * 0.9
+    return {"pe": "MixPE", "inputs": [{"pe": "ConstantPE", "value": mid},
+                                      {"pe": "SinePE", "frequency": float(rng.uniform(0.5, 20)), "amplitude": span}]}
+
+
+def _effect(rng, src, ch):
+    kind = rng.choice(["gain", "gain_pe", "biquad", "biquad_var", "svf", "svf_var", "ladder", "comb", "delay",
+                       "delay_frac", "crop", "env", "transform", "spatial"])
+    if kind == "gain":
+        return {"pe": "GainPE", "source": src, "gain": float(rng.uniform(-2, 2))}, ch
+    if kind == "gain_pe":
+        return {"pe": "GainPE", "source": src, "gain": _control(rng, 0.0, 1.0)}, ch
+    if kind in ("biquad", "svf"):
+        modes = ["lowpass", "highpass", "bandpass", "notch", "peaking", "lowshelf", "highshelf"]
+        return {"pe": "BiquadPE" if kind == "biquad" else "SVFilterPE", "source": src,
+                "frequency": float(rng.uniform(80, 8000)), "q": float(rng.uniform(0.4, 6.0)),
+                "mode": str(rng.choice(modes)), "gain_db": float(rng.uniform(-9, 9))}, ch
+    if kind in ("biquad_var", "svf_var"):
+        return {"pe": "BiquadPE" if kind == "biquad_var" else "SVFilterPE", "source": src,
+                "frequency": _control(rng, 200.0, 4000.0), "q": float(rng.uniform(0.5, 4.0)),
+                "mode": str(rng.choice(["lowpass", "bandpass", "highpass"]))}, ch
+    if kind == "ladder":
+        return {"pe": "LadderPE", "source": src, "frequency": float(rng.uniform(200, 5000)),
+                "resonance": float(rng.uniform(0.0, 0.9)), "mode": str(rng.choice(["lp24", "lp12", "bp12", "hp24"])),
+                "drive": float(rng.uniform(0.5, 2.0)), "oversample": int(rng.integers(1, 4))}, ch
+    if kind == "comb":
+        return {"pe": "CombPE", "source": src, "frequency": float(rng.uniform(100, 1500)),
+                "feedback": float(rng.uniform(-0.9, 0.9))}, ch
+    if kind == "delay":
+        return {"pe": "DelayPE", "source": src, "delay": int(rng.integers(-300, 2000))}, ch
+    if kind == "delay_frac":
+        return {"pe": "DelayPE", "source": src, "delay": float(rng.uniform(0.1, 300.0)) + 0.37,
+                "interpolation": str(rng.choice(["linear", "cubic"]))}, ch
+    if kind == "crop":
+        return {"pe": "CropPE", "source": src, "start": int(rng.integers(-200, 800)), "duration": int(rng.integers(500, 9000)),
+                "extend_mode": "zero"}, ch
+    if kind == "env":
+        a = float(rng.uniform(0.001, 0.03))
+        return {"pe": "EnvelopePE", "source": src, "attack": a,
+                "release": a if rng.random() < 0.3 else float(rng.uniform(0.005, 0.2)),
+                "mode": str(rng.choice(["peak", "rms"]))}, ch
+    if kind == "transform":
+        return {"pe": "TransformPE", "source": src, "ops": [["abs"], ["affine", 0.8, 0.1], ["clip", 0.0, 1.5], ["sqrt"]]}, ch
+    method = str(rng.choice(["adapter", "linear", "constant_power"]))
+    if method == "adapter":
+        out = int(rng.integers(1, 5))
+        return {"pe": "SpatialPE", "source": src, "method": "adapter", "channels": out}, out
+    return {"pe": "SpatialPE", "source": src, "method": method, "azimuth": float(rng.uniform(-120, 120))}, 2
+
+
+def _graph(seed):
+    rng = np.random.default_rng(seed)
+    ch = int(rng.choice([1, 1, 2]))
+    g = _source(rng, ch)
+    for _ in range(int(rng.integers(1, 4))):
+        g, ch = _effect(rng, g, ch)
+    if rng.random() < 0.3:
+        other = _source(rng, ch)
+        g = {"pe": "MixPE", "inputs": [g, other]}
+    sizes = [int(v) for v in rng.choice([1, 17, 64, 257, 1024, 3000, 5000], size=int(rng.integers(2, 5)))]
+    start = int(rng.integers(-600, 400))
+    blocks, pos = [], start
+    for n in sizes:
+        blocks.append([pos, n])
+        pos += n
+    return {"name": f"fuzz_{seed}", "sr": int(rng.choice([22050, 44100, 48000])), "graph": g, "blocks": blocks,
+            "keep": list(range(len(blocks)))}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_SEEDS", "60"))))
+def test_random_graph_matches_oracle(seed):
+    from oracle.graph_eval import run_case as oracle_run
+    from spec_build import run_case as hip_run
+    case = _graph(seed)
+    got = hip_run(case)
+    want = oracle_run(case)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape, (case, i, g.shape, w.shape)
+        if not np.all(np.isfinite(w)):
+            # EnvelopePE(mode=RMS): scipy's running-sum uniform_filter1d can drift a hair below zero after a
+            # loud passage, and the reference then takes sqrt(negative) = NaN (envelope_pe.py:222).  The device
+            # sums each window afresh and returns the non-negative value; nothing to compare in that block.
+            assert np.all(np.isfinite(g))
+            pytest.skip("reference output contains NaN (running-sum RMS underflow)")
+        assert np.all(np.isfinite(g)), (case["graph"], i)
+        peak = float(np.max(np.abs(w))) if w.size else 0.0
+        err = float(np.max(np.abs(g.astype(np.float64) - w.astype(np.float64)))) if w.size else 0.0
+        assert err <= REL_TOL * peak + ABS_FLOOR, (case["graph"], case["blocks"], i, err, peak)

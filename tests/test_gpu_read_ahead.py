@@ -53,3 +53,32 @@ def test_read_ahead_skips_stateful_and_index_quirk_graphs():
     parts = _pull(a, [(i * 512, 512) for i in range(40)])
     whole = pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707).render(0, 40 * 512).data
     assert np.max(np.abs(np.concatenate(parts) - whole)) <= 1e-6 * np.max(np.abs(whole))
+
+
+def test_mix_with_bounded_inputs_is_not_read_ahead():
+    """MixPE skips an input whose extent misses the REQUESTED window (mix_pe.py:81-85); with a hold-mode ArrayPE
+    that makes the samples depend on the window, so such a MixPE must see exactly the caller's blocks."""
+    import numpy as np
+    import pygmu2_amd as pg
+    from pygmu2_amd import read_ahead
+    from oracle import graph_eval
+    from oracle.golden_cases import S
+    import spec_build
+    spec = S("MixPE", inputs=[
+        S("GainPE", source=S("ArrayPE", data={"rng": 688, "n": 2678, "ch": 1, "scale": 0.5}, extend_mode="hold_both"),
+          gain=0.97),
+        S("ArrayPE", data={"rng": 745, "n": 4314, "ch": 1, "scale": 0.5}, extend_mode="zero")])
+    blocks = [[-361, 1], [-360, 257], [-103, 257], [154, 1024]]
+    pg.set_sample_rate(48000)
+    pe = spec_build.build(spec)
+    assert not read_ahead.eligible(pe)
+    unbounded = pg.MixPE(pg.SinePE(100.0), pg.GainPE(pg.SinePE(200.0), gain=0.5))
+    assert read_ahead.eligible(unbounded)
+    r = pg.NullRenderer(sample_rate=48000)
+    r.set_source(pe)
+    r.start()
+    got = [pe.render(s, n).data for s, n in blocks]
+    r.stop()
+    g = graph_eval.Node(spec, 48000)
+    for (s, n), out in zip(blocks, got):
+        assert np.array_equal(out, g.render(s, n)), (s, n)
