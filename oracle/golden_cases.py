@@ -405,6 +405,28 @@ def cases():
                                                               S("SinePE", frequency=3.0, amplitude=0.4)]),
           fft_size=1024), blocks_contig(0, [1000, 1400]))
 
+    # ---- semantics a random-graph differential test tripped over (tests/test_gpu_fuzz.py), pinned by the reference
+    add("reverb_held_source_negative_blocks", 10000,       # MixPE inside ReverbPE skips blocks that miss both extents
+        S("ReverbPE", source=S("ArrayPE", data={"rng": 44, "n": 1500, "ch": 1, "scale": 0.5}, extend_mode="hold_both"),
+          ir=S("ArrayPE", data=room), mix=0.4, fft_size=1024), [[-445, 64], [-381, 1000], [619, 1200]])
+    add("trigger_restart_comb_keeps_state", 22050,         # CombPE has no _reset_state hook: restarts do not clear it
+        S("TriggerRestartPE", trigger=S("PeriodicTrigger", hz=60.0),
+          src=S("CombPE", source=S("SinePE", frequency=300.0, amplitude=0.5), frequency=1500.0, feedback=0.8)),
+        blocks_contig(-58, [1024, 17, 900]))
+    add("trigger_restart_fm_sine_keeps_phase", 22050,      # nor has SinePE: its phase runs on across restarts
+        S("TriggerRestartPE", trigger=S("PeriodicTrigger", hz=45.0),
+          src=S("SinePE", frequency=S("MixPE", inputs=[S("ConstantPE", value=400.0),
+                                                        S("SinePE", frequency=3.0, amplitude=100.0)]))),
+        blocks_contig(0, [1024, 1024]))
+    add("trigger_restart_reverb_memo", 22050,              # ReverbPE's CachePE memo survives restarts (equal segments!)
+        S("TriggerRestartPE", trigger=S("PeriodicTrigger", hz=63.0),
+          src=S("ReverbPE", source=S("BlitSawPE", frequency=500.0), ir=S("ArrayPE", data={"values": [0.5, 0.3, -0.2]}),
+                mix=0.6)), [[-244, 3000], [2756, 700]])
+    add("mix_transform_of_bounded_source", 44100,          # TransformPE passes its source's extent on to MixPE's skip rule
+        S("MixPE", inputs=[S("TransformPE", source=S("ArrayPE", data={"rng": 45, "n": 900, "ch": 1, "scale": 0.5}),
+                             ops=[["abs"], ["affine", 0.8, 0.1], ["sqrt"]]),
+                           S("ConstantPE", value=0.25)]), [[-182, 17], [-165, 64], [-101, 257], [800, 300], [1100, 50]])
+
     # ---------------------------------------------------------------- SpatialPE
     def chans(c, seed):
         return S("ArrayPE", data={"rng": seed, "n": 1500, "ch": c, "scale": 0.5})

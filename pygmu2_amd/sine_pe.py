@@ -54,12 +54,14 @@ class SinePE(ProcessingElement):
             ext = ext.intersection(pe.extent())
         return ext
 
-    def _reset_state(self) -> None:
+    def _clear_phase(self) -> None:
         if self._state is not None:
             self._state.zero_()
 
-    _on_start = _reset_state
-    _on_stop = _reset_state
+    # the reference resets the accumulated phase in _on_start/_on_stop only (sine_pe.py:109-116): there is
+    # no _reset_state hook, so reset_state() -- e.g. from TriggerRestartPE -- leaves a stateful SinePE running
+    _on_start = _clear_phase
+    _on_stop = _clear_phase
 
     def _pure_params(self) -> DeviceBuffer:
         if self._params is None:

@@ -10,10 +10,43 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5
-ABS_FLOOR = 1e-7
+# Every PE meets 1e-5 of ITS output peak; in a cascade a later stage can shrink the signal (a band-pass after a
+# near-DC convolution output) without shrinking the float32-MFMA rounding noise it inherited, so the floor is
+# 1e-5 of the O(0.1 .. 1) amplitudes every generated source has, not of the final block's peak.
+ABS_FLOOR = 1e-6
+
+
+def _mono_source(rng):
+    """Mono-only generators: envelopes, gates, curves, modulated oscillators."""
+    kind = rng.choice(["piecewise", "sine_fm", "blitsaw_fm", "adsr_gated", "adsr_trig", "gate", "dirac"])
+    if kind == "piecewise":
+        pts = sorted({int(t) for t in rng.integers(-300, 6000, size=int(rng.integers(2, 6)))})
+        return {"pe": "PiecewisePE", "points": [[t, float(rng.uniform(0.05, 1.0))] for t in pts],
+                "transition_type": str(rng.choice(["step", "linear", "exponential", "sigmoid", "constant_power"])),
+                "extend_mode": str(rng.choice(["zero", "hold_both", "hold_last"]))}
+    if kind == "sine_fm":
+        return {"pe": "SinePE", "frequency": _control(rng, 100.0, 900.0), "amplitude": float(rng.uniform(0.2, 1.0))}
+    if kind == "blitsaw_fm":
+        return {"pe": "BlitSawPE", "frequency": _control(rng, 80.0, 600.0), "amplitude": _control(rng, 0.2, 0.9)}
+    if kind == "adsr_gated":
+        return {"pe": "AdsrGatedPE", "gate": {"pe": "PeriodicGate", "frequency": float(rng.uniform(3.0, 40.0)),
+                                              "duty_cycle": float(rng.uniform(0.2, 0.8))},
+                "attack_time": float(rng.uniform(0.001, 0.02)), "decay_time": float(rng.uniform(0.002, 0.03)),
+                "sustain_level": float(rng.uniform(0.2, 0.9)), "release_time": float(rng.uniform(0.002, 0.05))}
+    if kind == "adsr_trig":
+        return {"pe": "AdsrTriggeredPE", "trigger": {"pe": "PeriodicTrigger", "hz": float(rng.uniform(5.0, 50.0))},
+                "attack_time": float(rng.uniform(0.001, 0.01)), "decay_time": float(rng.uniform(0.002, 0.02)),
+                "sustain_time": float(rng.uniform(0.0, 0.02)), "sustain_level": float(rng.uniform(0.2, 0.9)),
+                "release_time": float(rng.uniform(0.002, 0.03))}
+    if kind == "gate":
+        return {"pe": "PeriodicGate", "frequency": float(rng.uniform(5.0, 400.0)), "duty_cycle": float(rng.uniform(0.1, 0.9)),
+                "phase": float(rng.uniform(0.0, 1.0))}
+    return {"pe": "DiracPE"}      # (IdentityPE's ramp reaches 1e3..1e4: it swamps the relative budget of what follows)
 
 
 def _source(rng, ch):
+    if ch == 1 and rng.random() < 0.35:
+        return _mono_source(rng)
     kind = rng.choice(["sine", "array", "blitsaw", "const", "supersaw"])
     if kind == "sine":
         return {"pe": "SinePE", "frequency": float(rng.uniform(50, 3000)), "amplitude": float(rng.uniform(0.1, 1.0)),
@@ -39,7 +72,23 @@ def _control(rng, lo, hi):
 
 def _effect(rng, src, ch):
     kind = rng.choice(["gain", "gain_pe", "biquad", "biquad_var", "svf", "svf_var", "ladder", "comb", "delay",
-                       "delay_frac", "crop", "env", "transform", "spatial"])
+                       "delay_frac", "delay_pe", "crop", "env", "transform", "spatial", "convolve", "reverb",
+                       "trigger_restart"])
+    if kind in ("convolve", "reverb"):
+        taps = int(rng.choice([3, 40, 300, 2500]))                      # 2500: the FFT path
+        fir_ch = 1 if (ch == 1 and rng.random() < 0.5) or ch > 2 or kind == "reverb" else int(rng.choice([1, ch]))
+        fir = {"pe": "ArrayPE", "data": {"rng": int(rng.integers(1000)), "n": taps, "ch": fir_ch, "scale": 0.3,
+                                         "decay": taps / 4.0}}
+        if kind == "convolve":
+            return {"pe": "ConvolvePE", "src": src, "fir": fir}, max(ch, fir_ch)
+        return {"pe": "ReverbPE", "source": src, "ir": fir, "mix": float(rng.uniform(0.0, 1.0)),
+                "normalize_ir": bool(rng.random() < 0.7)}, ch
+    if kind == "delay_pe":
+        return {"pe": "DelayPE", "source": src, "delay": _control(rng, 5.0, 400.0),
+                "interpolation": str(rng.choice(["linear", "cubic"]))}, ch
+    if kind == "trigger_restart":
+        return {"pe": "TriggerRestartPE", "trigger": {"pe": "PeriodicTrigger", "hz": float(rng.uniform(8.0, 90.0))},
+                "src": src}, ch
     if kind == "gain":
         return {"pe": "GainPE", "source": src, "gain": float(rng.uniform(-2, 2))}, ch
     if kind == "gain_pe":
@@ -101,7 +150,7 @@ def _graph(seed):
             "keep": list(range(len(blocks)))}
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_SEEDS", "60"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_SEEDS", "300"))))
 def test_random_graph_matches_oracle(seed):
     from oracle.graph_eval import run_case as oracle_run
     from spec_build import run_case as hip_run
