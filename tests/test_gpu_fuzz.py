@@ -169,3 +169,83 @@ def test_random_graph_matches_oracle(seed):
         peak = float(np.max(np.abs(w))) if w.size else 0.0
         err = float(np.max(np.abs(g.astype(np.float64) - w.astype(np.float64)))) if w.size else 0.0
         assert err <= REL_TOL * peak + ABS_FLOOR, (case["graph"], case["blocks"], i, err, peak)
+
+
+# ------------------------------------------------------------------------------------------ voice banks
+def _bank_case(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    osc = str(rng.choice(["sine", "blitsaw", "supersaw"]))
+    flt = str(rng.choice(["none", "biquad", "ladder"]))
+    amp = str(rng.choice(["none", "gain", "adsr"]))
+    k = int(rng.integers(4, 13))
+    ch = 1 if (amp == "adsr" or rng.random() < 0.7) else 2
+
+    def voice(i):
+        f = float(rng.uniform(40, 1500))
+        if osc == "sine":
+            v = {"pe": "SinePE", "frequency": f, "amplitude": float(rng.uniform(0.2, 1.0)), "channels": ch}
+        elif osc == "blitsaw":
+            v = {"pe": "BlitSawPE", "frequency": f, "amplitude": float(rng.uniform(0.2, 1.0)), "channels": ch}
+        else:
+            v = {"pe": "SuperSawPE", "frequency": f, "voices": 3, "seed": int(rng.integers(1000)), "channels": ch}
+        if flt == "biquad":
+            v = {"pe": "BiquadPE", "source": v, "frequency": float(rng.uniform(200, 6000)), "q": float(rng.uniform(0.5, 4)),
+                 "mode": "lowpass"}
+        elif flt == "ladder":
+            v = {"pe": "LadderPE", "source": v, "frequency": float(rng.uniform(300, 4000)),
+                 "resonance": float(rng.uniform(0.0, 0.45)), "mode": "lp24", "oversample": 2}
+        if amp == "gain":
+            v = {"pe": "GainPE", "source": v, "gain": float(rng.uniform(0.1, 1.0))}
+        elif amp == "adsr":
+            v = {"pe": "GainPE", "source": v,
+                 "gain": {"pe": "AdsrGatedPE",
+                          "gate": {"pe": "PeriodicGate", "frequency": float(rng.uniform(2.0, 30.0)),
+                                   "duty_cycle": float(rng.uniform(0.2, 0.8))},
+                          "attack_time": float(rng.uniform(0.002, 0.02)), "decay_time": float(rng.uniform(0.005, 0.05)),
+                          "sustain_level": float(rng.uniform(0.3, 0.9)), "release_time": float(rng.uniform(0.005, 0.08))}}
+        return v
+
+    sizes = [int(v) for v in rng.choice([64, 1000, 4096, 9000, 20000], size=int(rng.integers(2, 4)))]
+    blocks, pos = [], 0
+    for n in sizes:
+        blocks.append([pos, n])
+        pos += n
+    return {"name": f"bank_{seed}", "sr": 48000, "graph": {"pe": "MixPE", "inputs": [voice(i) for i in range(k)]},
+            "blocks": blocks, "keep": list(range(len(blocks)))}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_BANKS", "40"))))
+def test_random_voice_bank_matches_oracle_and_per_voice_rendering(seed):
+    import pygmu2_amd as pg
+    import spec_build
+    from oracle.graph_eval import run_case as oracle_run
+    case = _bank_case(seed)
+    pg.set_sample_rate(case["sr"])
+
+    def render(bank_allowed):
+        pe = spec_build.build(case["graph"])
+        if not bank_allowed:
+            pe._bank = False
+        r = pg.NullRenderer(sample_rate=case["sr"])
+        r.set_source(pe)
+        r.start()
+        outs = [pe.render(s, n).data for s, n in case["blocks"]]
+        used = bool(pe._bank)
+        r.stop()
+        return outs, used
+
+    banked, used = render(True)
+    assert used, "identical voice trees should have been batched"
+    plain, _ = render(False)
+    want = oracle_run(case)
+    # A bank shares one warm-up length (the longest of its voices) in the time-segmented ladder, a lone voice uses
+    # its own: both are converged to ~1e-11, which can still flip the last bit of a float32 sample now and then.
+    ladder = '"LadderPE"' in __import__("json").dumps(case["graph"])
+    for i, (b, p, w) in enumerate(zip(banked, plain, want)):
+        if ladder:
+            assert float(np.max(np.abs(b.astype(np.float64) - p))) <= 1e-6 * float(np.max(np.abs(p))), (case["name"], i)
+        else:
+            assert np.array_equal(b, p), (case["name"], i, float(np.max(np.abs(b - p))))
+        peak = float(np.max(np.abs(w)))
+        err = float(np.max(np.abs(b.astype(np.float64) - w)))
+        assert err <= REL_TOL * peak + ABS_FLOOR, (case["name"], i, err, peak)
