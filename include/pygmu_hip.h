@@ -334,6 +334,12 @@ int pgx_periodic_gate(float *out, int64_t out_stride, int batch, int64_t start, 
                       const pgx_gate_params *params);
 int pgx_periodic_trigger(float *out, int64_t start, int64_t n, int64_t period,
                          int64_t phase_samples, float amplitude);
+/* PeriodicGate with PE-driven parameters: FunctionGenPE's stateful rectangle path (function_gen_pe.py:169-186).
+ * A stream pointer overrides its scalar; state = { carried phase in cycles } (the host zeroes it when a
+ * render is not contiguous with the previous one, function_gen_pe.py:170-171). */
+int pgx_gate_stateful(float *out, int64_t n, double sample_rate, double freq, double duty, double phase,
+                      const float *freq_stream, const float *duty_stream, const float *phase_stream,
+                      double *state);
 
 /* AdsrGatedPE._render (adsr_pe.py:124-196) / AdsrTriggeredPE._render (adsr_pe.py:279-335):
  * the reference's sequential float64 accumulation reproduced bit for bit (binade-linear runs, see

@@ -271,6 +271,21 @@ def cases():
         [[0, 48000 // 4], [48000 * 100, 4096], [-5000, 4096]])
     add("periodic_gate_odd", 44100, S("PeriodicGate", frequency=7.3, duty_cycle=0.31, phase=0.4),
         [[0, 20000], [44100 * 1000 + 17, 4096]])
+    # PE-driven parameters: FunctionGenPE's stateful path (running phase, restarted on a seek)
+    add("periodic_gate_fm", 48000,
+        S("PeriodicGate", frequency=S("MixPE", inputs=[S("ConstantPE", value=5.3),
+                                                       S("SinePE", frequency=0.7, amplitude=2.0)]),
+          duty_cycle=0.37),
+        blocks_contig(0, [3000, 5000, 1, 4096]) + [[100, 3000], [3100, 2900], [-700, 1500]])
+    add("periodic_gate_pwm", 44100,
+        S("PeriodicGate", frequency=6.1, duty_cycle=S("SinePE", frequency=1.3, amplitude=0.8),
+          phase=S("ConstantPE", value=0.21)),
+        blocks_contig(5000, [4096, 4096, 7]) + [[0, 9000]])
+    add("adsr_gate_fm", 48000,
+        S("AdsrGatedPE", gate=S("PeriodicGate", frequency=S("ArrayPE", data={"values": [3.0] * 9000 + [11.0] * 9000},
+                                                            extend_mode="hold_last"), duty_cycle=0.6),
+          attack_time=0.02, decay_time=0.03, sustain_level=0.6, release_time=0.05),
+        blocks_contig(0, [6000, 6000, 6000, 6000]))
     add("periodic_trigger", 44100, S("PeriodicTrigger", hz=7.0, phase=0.25, amplitude=2),
         [[0, 20000], [-9000, 9000], [44100 * 3000, 8000]])
     g1 = {"values": [1.0] * 500 + [0.0] * 500}

@@ -96,6 +96,8 @@ class Node:
             self.state = {"ratios": r, "gains": g, "osc": [O.blitsaw_state(x) for x in p]}
         elif k in ("BiquadPE", "LadderPE", "CombPE", "SVFilterPE"):
             self.state = None          # lazily sized by channel count
+        elif k == "PeriodicGate":
+            self.state = O.gate_state()
         elif k == "EnvelopePE":
             self.state = O.envelope_state()
         elif k in ("AdsrGatedPE", "AdsrTriggeredPE"):
@@ -292,6 +294,10 @@ class Node:
             return O.comb(self.state, x, self._param("frequency", start, n),
                           self._param("feedback", start, n, 0.0), kw.get("min_frequency", 20.0),
                           kw.get("smoothing_samples", 2400), sr)
+        if k == "PeriodicGate" and any(x in self.sub for x in ("frequency", "duty_cycle", "phase")):
+            return O.periodic_gate_stateful(self.state, start, n, self._param("frequency", start, n, 1.0),
+                                            self._param("duty_cycle", start, n, 0.5),
+                                            self._param("phase", start, n, 0.0), sr)
         if k == "PeriodicGate":
             return O.periodic_gate(start, n, kw.get("frequency", 1.0), kw.get("duty_cycle", 0.5),
                                    kw.get("phase", 0.0), sr)

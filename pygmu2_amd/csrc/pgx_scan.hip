@@ -1208,6 +1208,49 @@ k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr
 }
 
 // ================================================================================================
+// PeriodicGate with PE-driven frequency / duty / phase: FunctionGenPE's stateful rectangle path
+// (function_gen_pe.py:157-193): base = mod(phase0 + [0, cumsum(f/sr)[:-1]], 1); gate = mod(base + ph, 1) < duty.
+// One workgroup: exclusive prefix sum of the increments, like the stateful sine.
+// state = { carried phase }.
+// ================================================================================================
+constexpr int kGateT = 8;
+constexpr int kGateTile = kBlock * kGateT;
+
+__global__ void __launch_bounds__(kBlock)
+k_gate_stateful(float *out, int64_t n, double sr, double freq_scalar, double duty_scalar, double phase_scalar,
+                const float *freq, const float *duty, const float *phase, double *state) {
+    __shared__ double lds[kWaves];
+    const int tid = threadIdx.x;
+    const double phase0 = state[0];
+    double carry_sum = 0.0;
+    for (int64_t base = 0; base < n; base += kGateTile) {
+        const int64_t f0 = base + (int64_t)tid * kGateT;
+        double loc[kGateT];
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kGateT; ++j) {
+            loc[j] = run;                                             // exclusive within the chunk
+            const double f = freq ? ((f0 + j < n) ? (double)freq[f0 + j] : 0.0) : freq_scalar;
+            run = run + ((f0 + j < n) ? f / sr : 0.0);
+        }
+        double tile_total;
+        const double off = block_excl_sum(run, lds, tile_total);
+        const double chunk_base = carry_sum + off;
+        carry_sum = carry_sum + tile_total;
+#pragma unroll
+        for (int j = 0; j < kGateT; ++j) {
+            if (f0 + j >= n) break;
+            const double b = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));
+            const double ph = pgx::pgx_mod1(b + (phase ? (double)phase[f0 + j] : phase_scalar));
+            double d = duty ? (double)duty[f0 + j] : duty_scalar;
+            d = d < 0.0 ? 0.0 : (d > 1.0 ? 1.0 : d);
+            out[f0 + j] = (ph < d) ? 1.0f : 0.0f;
+        }
+    }
+    if (tid == 0) state[0] = pgx::pgx_mod1(phase0 + carry_sum);       // mod(phase + sum(dt), 1)
+}
+
+// ================================================================================================
 // SVFilterPE (svfilter_pe.py:41-205, 404-500): trapezoidal state variable filter,
 //   out = c0*x + c1*s0 + c2*s1;   s' = B*x + A*s   with a full (possibly per-sample) 2x2 A.
 // One workgroup per channel chain, time-varying 2x2 affine scan like the varying biquad.
@@ -1709,6 +1752,17 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     else PGX_SAW_LAUNCH(false, kWaves);
 #undef PGX_SAW_LAUNCH
     PGX_LAUNCH_CHECK("k_blitsaw");
+    return PGX_OK;
+}
+
+int pgx_gate_stateful(float *out, int64_t n, double sample_rate, double freq, double duty, double phase,
+                      const float *freq_stream, const float *duty_stream, const float *phase_stream, double *state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && state && sample_rate > 0, "pgx_gate_stateful: bad argument");
+    hipLaunchKernelGGL(k_gate_stateful, dim3(1), dim3(kBlock), 0, pgx::stream(), out, n, sample_rate, freq, duty,
+                       phase, freq_stream, duty_stream, phase_stream, state);
+    PGX_LAUNCH_CHECK("k_gate_stateful");
     return PGX_OK;
 }
 

@@ -86,6 +86,7 @@ _SIGNATURES = [
     ("pgx_channel_adapt", _I, [_P, _P, _L, _I, _I]),
     ("pgx_pan", _I, [_P, _P, _L, _I, C.c_float, _P, _I]),
     ("pgx_mono_mean", _I, [_P, _P, _L, _I]),
+    ("pgx_gate_stateful", _I, [_P, _L, _D, _D, _D, _D, _P, _P, _P, _P]),
     ("pgx_interp_lookup", _I, [_P, _P, _L, _L, _I, _L, _L, _D, _P, _I, _I, _D, _D]),
     ("pgx_index_range", _I, [_P, _P, _L, _L]),
     ("pgx_piecewise", _I, [_P, _L, _L, _I, _P, _P, _I, _I, _I, _I]),

@@ -339,7 +339,7 @@ def _signature(pe):
         sub = _signature(pe._source)
         return None if sub is None else ("ladder", sub)
     if isinstance(pe, PeriodicGate):
-        return ("gate",)
+        return ("gate",) if pe.is_pure() else None        # PE-driven gates carry a phase: not batched
     if isinstance(pe, AdsrGatedPE):
         sub = _signature(pe._gate)
         return None if sub is None else ("adsr_gated", sub)

@@ -18,7 +18,8 @@ ABS_FLOOR = 1e-6
 
 def _mono_source(rng):
     """Mono-only generators: envelopes, gates, curves, modulated oscillators."""
-    kind = rng.choice(["piecewise", "sine_fm", "blitsaw_fm", "adsr_gated", "adsr_trig", "gate", "dirac"])
+    kind = rng.choice(["piecewise", "sine_fm", "blitsaw_fm", "adsr_gated", "adsr_trig", "gate", "gate_fm",
+                       "dirac"])
     if kind == "piecewise":
         pts = sorted({int(t) for t in rng.integers(-300, 6000, size=int(rng.integers(2, 6)))})
         return {"pe": "PiecewisePE", "points": [[t, float(rng.uniform(0.05, 1.0))] for t in pts],
@@ -41,6 +42,16 @@ def _mono_source(rng):
     if kind == "gate":
         return {"pe": "PeriodicGate", "frequency": float(rng.uniform(5.0, 400.0)), "duty_cycle": float(rng.uniform(0.1, 0.9)),
                 "phase": float(rng.uniform(0.0, 1.0))}
+    if kind == "gate_fm":
+        # stateful gate (PE-driven frequency / duty): bit-exact control curves, so only the summation order of the
+        # running phase differs from the reference (1e-13 cycles against a threshold: no flipped samples)
+        pts = sorted({int(t) for t in rng.integers(-300, 20000, size=int(rng.integers(2, 6)))})
+        freq = {"pe": "PiecewisePE", "points": [[t, float(rng.uniform(20.0, 300.0))] for t in pts],
+                "transition_type": "step", "extend_mode": "hold_both"}
+        duty = ({"pe": "ArrayPE", "data": {"rng": int(rng.integers(1000)), "n": int(rng.integers(500, 6000)), "ch": 1,
+                                           "scale": 0.5}, "extend_mode": "hold_both"}
+                if rng.random() < 0.5 else float(rng.uniform(0.1, 0.9)))
+        return {"pe": "PeriodicGate", "frequency": freq, "duty_cycle": duty}
     return {"pe": "DiracPE"}      # (IdentityPE's ramp reaches 1e3..1e4: it swamps the relative budget of what follows)
 
 

@@ -31,6 +31,7 @@ BIT_EXACT = {
     "constant_stereo", "identity_neg", "dirac_window", "array_zero", "array_hold_both",
     "crop_zero", "crop_hold", "crop_open_end", "gain_const_third",
     "periodic_gate", "periodic_gate_odd", "periodic_trigger",
+    "periodic_gate_fm", "periodic_gate_pwm", "adsr_gate_fm",
     "adsr_full_cycle", "adsr_early_release_chunked", "adsr_bad_gate_values", "adsr_periodic_gate",
     "adsr_sustain_edges", "adsr_triggered", "adsr_triggered_retrigger",
     "comb_kat", "comb_high_freq", "comb_step",
