@@ -33,6 +33,8 @@
 //     segment's affine map, the apply launch folds the earlier maps onto the carried state.
 // Many short chains (voices) use one workgroup per chain and no cross-workgroup traffic at all.
 
+#include <type_traits>
+
 #include "pgx_common.h"
 
 namespace {
@@ -1490,113 +1492,161 @@ k_env_onepole(float *out, const double *det, int64_t n, int channels, double coe
     if (have_final) state[ch] = final_y;
 }
 
-// attack != release (envelope_pe.py:259-271):  e += (target > e ? attack : release) * (target - e).
-// The coefficient depends on the state, so this is not a linear scan -- but between two switches it
-// is one (e' = (1-c) e + c t with a constant c), and envelopes switch rarely: a few times per period of
-// the input.  One wave per channel walks 64-sample chunks: it takes the regime of the first open
-// sample (known from the carried level), scans the chunk as if that regime held to the end
-// (Kogge-Stone over affine maps, DPP), and accepts the samples up to the first one whose comparison
-// target > previous level contradicts the regime; the walk continues from there with the other
-// coefficient.  A chunk that needs more than kEnvMaxPasses passes (noise-like input) is finished one
-// sample at a time.  Levels come out of a scan instead of the literal sum: ~1e-16 relative, and a
-// comparison that flips at a near-tie picks between two branches that agree there.  Within a regime the
-// multipliers are constant, so the scan carries one value per lane and the powers of (1 - c) come from
-// per-lane tables built once per launch.
-constexpr int kEnvMaxPasses = 10;
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64_keep(double old, double v) {     // lanes without a source keep `old`
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
 
-// lambda^e for a per-lane exponent e in [0, 64] (repeated squaring over the bits of e)
-__device__ __forceinline__ double lane_power(double lambda, int e) {
-    double r = 1.0, sq = lambda;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        if (e & (1 << k)) r = r * sq;
-        sq = sq * sq;
-    }
-    return r;
-}
-
-// Powers of one regime's lambda = 1 - c that the chunk scan needs.
-struct EnvRegime {
-    double c;
-    double l1, l2, l4, l8;      // lambda^(2^k): Kogge-Stone inside a 16-lane row
-    double p16, p32;            // lambda^((lane&15)+1), lambda^((lane&31)+1): joining the rows
-    double run;                 // lambda^(lane+1): the carried level's weight, shifted to the open lane
-};
-__device__ __forceinline__ EnvRegime env_regime(double c, int lane) {
-    EnvRegime r;
-    const double l = 1.0 - c;
-    r.c = c;
-    r.l1 = l;
-    r.l2 = l * l;
-    r.l4 = r.l2 * r.l2;
-    r.l8 = r.l4 * r.l4;
-    r.p16 = lane_power(l, (lane & 15) + 1);
-    r.p32 = lane_power(l, (lane & 31) + 1);
-    r.run = lane_power(l, lane + 1);
-    return r;
-}
-
-__global__ void __launch_bounds__(64)
-k_env_ar(float *out, const double *det, int64_t n, int channels, double attack_coeff, double release_coeff,
-         double *state) {
-    const int ch = blockIdx.x, lane = threadIdx.x;
-    const double *d = det + ch;
-    float *o = out + ch;
-    const EnvRegime ra = env_regime(attack_coeff, lane), rr = env_regime(release_coeff, lane);
+// attack != release (envelope_pe.py:259-271), time-parallel.  One sample's update
+//     e' = e + c(e) * (t - e),   c = attack if t > e else release
+// is a continuous, increasing, two-piece linear map of e, so a thread's T samples compose to a piecewise linear
+// map whose piece around a given entry level is found by stepping the samples literally from that level.  A
+// window of NW*64*T samples is solved by Newton's method on that piecewise linear system: every thread steps its
+// samples from its current entry level (reference arithmetic), recording the affine piece (A, B) it passed
+// through; a workgroup scan of the pieces gives every thread a new entry level; repeat until no entry level
+// moves by more than 1e-13 of itself.  Thread k's entry is final after at most k+1 rounds (it only depends on
+// threads before it), so the loop ends; in practice it takes 2..6 rounds (semismooth Newton).  The samples written
+// are literal steps from entry levels within 1e-13 of the converged ones: against the sequential reference they
+// differ by that much (float32 output resolves 6e-8).  `det` == nullptr: peak detection fused (|in|).
+constexpr double kEnvSettled = 1e-13;
+template <int NW, int T, bool PEAK>
+__global__ void __launch_bounds__(NW * 64)
+k_env_newton(float *out, const float *in, const double *det, int64_t n, int channels, double attack_coeff,
+             double release_coeff, double *state) {
+    __shared__ double s_a[2][NW], s_b[2][NW], s_pa[T + 1], s_pr[T + 1];
+    __shared__ int s_moved[2][NW];
+    constexpr int kWindow = NW * 64 * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = blockIdx.x;
     double e_in = state[ch];
-    double t_next = (lane < n) ? d[(int64_t)lane * channels] : 0.0;
-    for (int64_t base = 0; base < n; base += 64) {
-        const int nv = (n - base < 64) ? (int)(n - base) : 64;
-        const double t = t_next;
-        if (base + 64 + lane < n) t_next = d[(base + 64 + lane) * channels];      // next chunk, in flight
-        double mine = 0.0;
-        int f = 0, passes = 0;
-        while (f < nv && passes < kEnvMaxPasses) {
-            ++passes;
-            const double t_f = readlane_f64(t, f);
-            const bool attack = t_f > e_in;
-            const EnvRegime &g = attack ? ra : rr;
-            // e_k = lambda^(k-f+1) e_in + sum_{j=f..k} lambda^(k-j) c t_j for the open lanes k >= f: the sum is a
-            // scan with constant multipliers (closed lanes contribute 0), the first term a shifted table
-            double p = (lane >= f) ? g.c * t : 0.0;
-            p = __builtin_fma(g.l1, dpp_f64<0x111, 0xf>(p), p);
-            p = __builtin_fma(g.l2, dpp_f64<0x112, 0xf>(p), p);
-            p = __builtin_fma(g.l4, dpp_f64<0x114, 0xf>(p), p);
-            p = __builtin_fma(g.l8, dpp_f64<0x118, 0xf>(p), p);
-            p = __builtin_fma(g.p16, dpp_f64<0x142, 0xa>(p), p);
-            p = __builtin_fma(g.p32, dpp_f64<0x143, 0xc>(p), p);
-            const double m = __shfl(g.run, lane - f, 64);                         // lambda^(lane-f+1) for lane >= f
-            const double e = __builtin_fma(m, e_in, p);
-            double prev = dpp_f64_keep<0x138, 0xf>(e_in, e);                       // wave_shr:1
-            if (lane == f) prev = e_in;
-            const bool consistent = (t > prev) == attack;
-            const unsigned long long bad = __ballot(lane >= f && lane < nv && !consistent);
-            const int v = bad ? (__ffsll((long long)bad) - 1) : nv;               // v > f: lane f is consistent
-            if (lane >= f && lane < v) mine = e;
-            e_in = readlane_f64(e, v - 1);
-            f = v;
+    if (tid == 0) {                                   // (1-c)^k: a thread's slope is a product of these
+        double pa = 1.0, pr = 1.0;
+        for (int k = 0; k <= T; ++k) {
+            s_pa[k] = pa;
+            s_pr[k] = pr;
+            pa = pa * (1.0 - attack_coeff);
+            pr = pr * (1.0 - release_coeff);
         }
-        for (; f < nv; ++f) {                                                      // pathological chunk: literal steps
-            const double t_f = readlane_f64(t, f);
-            const double c = t_f > e_in ? attack_coeff : release_coeff;
-            e_in = e_in + c * (t_f - e_in);
-            if (lane == f) mine = e_in;
-        }
-        if (lane < nv) o[(base + lane) * channels] = (float)mine;
     }
-    if (lane == 0) state[ch] = e_in;
+    __syncthreads();
+
+    // HBM is touched with lane-contiguous accesses (element i of thread tid is frame i*NW*64 + tid of the window);
+    // the rounds want T consecutive frames per thread.  Both directions go through LDS, a chunk of T frames padded
+    // to T+1 words so that neither access pattern conflicts.  (Thread-contiguous global accesses cost 8x the L1->L2
+    // requests here: 2 us per window, as much as the rounds.)
+    using Raw = typename std::conditional<PEAK, float, double>::type;
+    constexpr int kThreads = NW * 64;
+    __shared__ Raw s_x[kWindow + kWindow / T];
+    __shared__ float s_y[kWindow + kWindow / T];
+    Raw raw[T];
+    auto fetch = [&](int64_t wbase) {                 // branch-free (clamped) so that the loads pipeline
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            int64_t f = wbase + i * kThreads + tid;
+            f = f < n ? f : n - 1;
+            if constexpr (PEAK) raw[i] = in[f * channels + ch];
+            else raw[i] = det[f * channels + ch];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int k = i * kThreads + tid;
+            s_x[k + k / T] = raw[i];
+        }
+    };
+    double t[T];
+    auto take = [&]() {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const Raw v = s_x[tid * (T + 1) + j];
+            t[j] = PEAK ? fabs((double)v) : (double)v;
+        }
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
+    take();
+    for (int64_t base = 0; base < n; base += kWindow) {
+        const int64_t f0 = base + (int64_t)tid * T;
+        const int live = (n - f0 >= T) ? T : (n - f0 > 0 ? (int)(n - f0) : 0);
+        const bool has_next = base + kWindow < n;
+        if (has_next) fetch(base + kWindow);                               // next window, in flight
+
+        // Two barriers per round (pieces, then the "an entry level moved" flags); LDS is double-buffered by round
+        // parity so that no third one is needed.
+        double entry = e_in, exit_level = e_in;
+        double y[T];
+        for (int round = 0; round <= NW * 64 + 1; ++round) {
+            double e = entry;
+            int attacks = 0, releases = 0;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const bool on = j < live;
+                const bool attack = t[j] > e;
+                const double stepped = e + (attack ? attack_coeff : release_coeff) * (t[j] - e);
+                attacks += (on && attack) ? 1 : 0;
+                releases += (on && !attack) ? 1 : 0;
+                e = on ? stepped : e;
+                y[j] = e;
+            }
+            // the affine piece this thread passed through: slope from the regime counts, offset from the exit
+            double a = s_pa[attacks] * s_pr[releases];
+            double b = __builtin_fma(-a, entry, e);
+            // inclusive scan of the pieces over the wave (lanes without a source see the identity)
+#define PGX_ENV_STEP(CTRL, MASK)                                            \
+            {                                                               \
+                const double ao = dpp_f64_keep<CTRL, MASK>(1.0, a);         \
+                const double bo = dpp_f64_keep<CTRL, MASK>(0.0, b);         \
+                b = __builtin_fma(a, bo, b);                                \
+                a = a * ao;                                                 \
+            }
+            PGX_ENV_STEP(0x111, 0xf) PGX_ENV_STEP(0x112, 0xf) PGX_ENV_STEP(0x114, 0xf) PGX_ENV_STEP(0x118, 0xf)
+            PGX_ENV_STEP(0x142, 0xa) PGX_ENV_STEP(0x143, 0xc)
+#undef PGX_ENV_STEP
+            const int buf = round & 1;
+            if (lane == 63) {
+                s_a[buf][wave] = a;
+                s_b[buf][wave] = b;
+            }
+            __syncthreads();
+            double cw = e_in, cn = e_in;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const double wa = s_a[buf][w], wb = s_b[buf][w];
+                if (w < wave) cw = __builtin_fma(wa, cw, wb);
+                cn = __builtin_fma(wa, cn, wb);
+            }
+            exit_level = cn;
+            const double aex = dpp_f64_keep<0x138, 0xf>(1.0, a);            // wave_shr:1 -> exclusive
+            const double bex = dpp_f64_keep<0x138, 0xf>(0.0, b);
+            const double fresh = __builtin_fma(aex, cw, bex);
+            // settled when no entry level moves by more than rounding noise (the offsets above carry ~1e-16)
+            const bool moved = live > 0 && fabs(fresh - entry) > kEnvSettled * (fabs(fresh) + fabs(entry));
+            entry = fresh;
+            const bool wave_moved = __ballot(moved) != 0ull;
+            if (lane == 0) s_moved[buf][wave] = wave_moved ? 1 : 0;
+            __syncthreads();
+            int any = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) any |= s_moved[buf][w];
+            if (!any) break;
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) s_y[tid * (T + 1) + j] = (float)y[j];
+        if (has_next) stage();
+        __syncthreads();                               // (the next writes to s_x / s_y come after the next rounds' barriers)
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int k = i * kThreads + tid;
+            if (base + k < n) out[(base + k) * channels + ch] = s_y[k + k / T];
+        }
+        if (has_next) take();
+        e_in = exit_level;                           // composition of all pieces (dead samples are the identity)
+    }
+    if (tid == 0) state[ch] = e_in;
 }
 
 // ================================================================================================
@@ -1810,17 +1860,36 @@ int pgx_envelope(float *out, const float *in, int64_t n, int channels, double at
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && state && scratch && channels >= 1, "pgx_envelope: bad argument");
-    hipLaunchKernelGGL(k_env_detect, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(),
-                       scratch, in, n, channels, rms_window);
-    PGX_LAUNCH_CHECK("k_env_detect");
+    const bool fused_peak = !one_pole && rms_window <= 0;                   // |x| is taken inside the follower
+    if (!fused_peak) {
+        hipLaunchKernelGGL(k_env_detect, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(),
+                           scratch, in, n, channels, rms_window);
+        PGX_LAUNCH_CHECK("k_env_detect");
+    }
     if (one_pole) {
         hipLaunchKernelGGL(k_env_onepole, dim3(channels), dim3(kBlock), 0, pgx::stream(), out,
                            (const double *)scratch, n, channels, attack_coeff, state);
         PGX_LAUNCH_CHECK("k_env_onepole");
     } else {
-        hipLaunchKernelGGL(k_env_ar, dim3(channels), dim3(64), 0, pgx::stream(), out,
-                           (const double *)scratch, n, channels, attack_coeff, release_coeff, state);
-        PGX_LAUNCH_CHECK("k_env_ar");
+        const double *det = fused_peak ? nullptr : (const double *)scratch;
+#define PGX_ENV_LAUNCH(NW, T, PEAK)                                                                               \
+        hipLaunchKernelGGL((k_env_newton<NW, T, PEAK>), dim3(channels), dim3(NW * 64), 0, pgx::stream(), out, in, det, \
+                           n, channels, attack_coeff, release_coeff, state)
+        if (n <= 1024) {
+            if (fused_peak) PGX_ENV_LAUNCH(4, 4, true);
+            else PGX_ENV_LAUNCH(4, 4, false);
+        } else if (n <= 2048) {
+            if (fused_peak) PGX_ENV_LAUNCH(8, 4, true);
+            else PGX_ENV_LAUNCH(8, 4, false);
+        } else if (n <= 4096) {
+            if (fused_peak) PGX_ENV_LAUNCH(8, 8, true);
+            else PGX_ENV_LAUNCH(8, 8, false);
+        } else {                                     // 8192-sample windows: fewest rounds x windows (measured)
+            if (fused_peak) PGX_ENV_LAUNCH(8, 16, true);
+            else PGX_ENV_LAUNCH(8, 16, false);
+        }
+#undef PGX_ENV_LAUNCH
+        PGX_LAUNCH_CHECK("k_env_newton");
     }
     return PGX_OK;
 }

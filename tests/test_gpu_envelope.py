@@ -1,8 +1,9 @@
 """
-GPU: EnvelopePE's attack/release follower (pgx_envelope, wave-cooperative regime walk) against the
-oracle's literal loop (orc_envelope_ar, envelope_pe.py:259-271) on inputs that exercise every path:
-long regimes (periodic input), regime flips every few samples (noise -> literal fallback inside a chunk),
-instant attack, silence, odd block lengths, stereo, state carried across blocks.
+GPU: EnvelopePE's attack/release follower (pgx_envelope, time-parallel Newton rounds over windows of
+1024..8192 samples) against the oracle's literal loop (orc_envelope_ar, envelope_pe.py:259-271) on inputs
+that exercise every path: long regimes (periodic input), regime flips every few samples (noise: most rounds),
+instant attack / instant release (zero slopes), silence, block lengths around every window size, stereo,
+state carried across blocks, RMS detection (separate detector pass).
 """
 
 import numpy as np
@@ -27,7 +28,7 @@ def _signals(n):
 
 
 @pytest.mark.parametrize("name", ["sine", "noise", "bursts", "silence_then_step", "slow_am"])
-@pytest.mark.parametrize("attack,release", [(0.005, 0.05), (0.0, 0.03), (0.05, 0.001)])
+@pytest.mark.parametrize("attack,release", [(0.005, 0.05), (0.0, 0.03), (0.05, 0.001), (0.02, 0.0)])
 def test_attack_release_follower_matches_oracle(name, attack, release):
     from oracle import pe_oracle as O
     import pygmu2_amd as pg
@@ -39,7 +40,7 @@ def test_attack_release_follower_matches_oracle(name, attack, release):
     r = pg.NullRenderer(sample_rate=44100)
     r.set_source(pe)
     r.start()
-    sizes = [1024, 63, 64, 65, 1, 20000, 28783]
+    sizes = [1024, 63, 64, 65, 1, 1025, 2048, 2049, 4096, 4097, 8192, 5, 27271]      # sums to n
     pos, got = 0, []
     for s in sizes:
         got.append(pe.render(pos, s).data)
@@ -52,3 +53,26 @@ def test_attack_release_follower_matches_oracle(name, attack, release):
     err = float(np.max(np.abs(got.astype(np.float64) - want)))
     assert err <= REL_TOL * peak + 1e-7, (name, attack, release, err, peak)
     assert np.all(got >= 0.0)
+
+
+@pytest.mark.parametrize("mode", ["peak", "rms"])
+def test_follower_long_block_and_detectors(mode):
+    """One 300 000-frame render (74 windows of the widest kernel) and the RMS detector in front of the follower."""
+    from oracle import pe_oracle as O
+    import pygmu2_amd as pg
+    pg.set_sample_rate(48000)
+    n = 300_000
+    rng = np.random.default_rng(5)
+    t = np.arange(n) / 48000.0
+    x = (np.sin(2 * np.pi * 97.0 * t) * (0.2 + 0.8 * (np.sin(2 * np.pi * 0.7 * t) > 0)) +
+         0.05 * rng.standard_normal(n)).astype(np.float32).reshape(-1, 1)
+    pe = pg.EnvelopePE(pg.ArrayPE(x), attack=0.002, release=0.12, mode=pg.DetectionMode(mode))
+    r = pg.NullRenderer(sample_rate=48000)
+    r.set_source(pe)
+    r.start()
+    got = pe.render(0, n).data
+    r.stop()
+    want = O.envelope(O.envelope_state(), x, attack=0.002, release=0.12, mode=mode, sr=48000)
+    peak = float(np.max(np.abs(want)))
+    err = float(np.max(np.abs(got.astype(np.float64) - want)))
+    assert err <= REL_TOL * peak + 1e-7, (mode, err, peak)
