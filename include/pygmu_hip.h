@@ -278,7 +278,11 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
                 const float *freq, int64_t freq_stride,
                 const float *amp, int64_t amp_stride,
                 const float *m, int64_t m_stride,
-                double *state /* [batch][2] */);
+                double *state /* [batch][2] */,
+                void *workspace /* pgx_blitsaw_workspace_bytes, or NULL: one workgroup per instance */);
+/* A long stream of a few scalar-parameter oscillators is rendered by several workgroups per oscillator
+ * (two passes that replay the single workgroup's carry chains: same bits).  0 = not applicable. */
+size_t pgx_blitsaw_workspace_bytes(int batch, int64_t n, int streams /* any of freq/amp/m is a stream */);
 
 /* SuperSawPE._render (super_saw_pe.py:287-318): out = float(amp * sum_v double(voice_v))
  * where voice_v is the float32 output of BlitSaw v.  `voices` = [batch*nvoices] float32

@@ -29,4 +29,16 @@ def ptr(buf) -> int | None:
     return None if buf is None else buf.ptr
 
 
-__all__ = ["lib", "new_output", "ptr", "check", "DeviceBuffer"]
+def blitsaw_workspace(owner, batch: int, frames: int, streams: bool) -> DeviceBuffer | None:
+    """Scratch for pgx_blitsaw's several-workgroups-per-oscillator form, cached on `owner` (grown on demand)."""
+    need = lib().pgx_blitsaw_workspace_bytes(int(batch), int(frames), 1 if streams else 0)
+    if not need:
+        return None
+    ws = getattr(owner, "_saw_workspace", None)
+    if ws is None or ws.nbytes < need:
+        ws = DeviceBuffer((need,), np.uint8)
+        owner._saw_workspace = ws
+    return ws
+
+
+__all__ = ["lib", "new_output", "ptr", "check", "DeviceBuffer", "blitsaw_workspace"]

@@ -13,7 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import device as _dev
-from ._kernels import DeviceBuffer, check, lib, new_output, ptr
+from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, new_output, ptr
 from .extent import Extent
 from .processing_element import ProcessingElement
 from .snippet import Snippet
@@ -93,9 +93,10 @@ class BlitSawPE(ProcessingElement):
         if isinstance(self._m, ProcessingElement):
             _, m_buf = self._control_stream(self._m, start, duration)
         out = new_output(duration, self._channels)
+        ws = blitsaw_workspace(self, 1, duration, bool(f_buf or a_buf or m_buf))
         check(L.pgx_blitsaw(out.ptr, 0, 1, duration, self._channels, float(self.sample_rate),
                             self._params.ptr, ptr(f_buf), 0, ptr(a_buf), 0, ptr(m_buf), 0,
-                            self._state.ptr), "pgx_blitsaw")
+                            self._state.ptr, ptr(ws)), "pgx_blitsaw")
         self._last_render_end = start + duration
         return Snippet(start, out)
 

@@ -73,6 +73,12 @@ __device__ __forceinline__ M2 shfl_up_m2(const M2 &m, int d) {
     return M2{__shfl_up(m.a, d, 64), __shfl_up(m.b, d, 64), __shfl_up(m.c, d, 64), __shfl_up(m.d, d, 64)};
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -795,24 +801,38 @@ __device__ __forceinline__ SawConst saw_const(double f, double sr, double m_para
 // NW = 4: 256 threads, 2048-frame tiles (banks of oscillators).  NW = 8: 512 threads, 4096-frame tiles --
 // the same wave values folded in the same order, i.e. bit-identical output with half of the
 // dependent tile steps, for graphs with a few oscillators where the chain length is what costs.
-template <bool STREAMS, int NW>
+//
+// SEG: one long stream (scalar parameters) over several workgroups.  The two carries of a tile are its running
+// phase sum and the integrator level; both chains are replayed exactly as the single workgroup would run them,
+// so the output is the same bit for bit.  SEG = 1 (reduce): workgroup (inst, s) replays the phase chain up to
+// its first tile -- every full tile adds the same per-wave sums -- and records each wave's zero-state integrator
+// response (what block_scan_scalar_affine_wide folds).  SEG = 2 (apply): folds the recorded responses of the
+// tiles before it, then renders its tiles like SEG = 0.  Workspace per oscillator: {phase0, y0, wave responses}.
+template <bool STREAMS, int NW, int SEG>
 __global__ void __launch_bounds__(NW * 64)
 k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, const pgx_blitsaw_params *params,
           const float *freq, int64_t freq_stride, const float *amp, int64_t amp_stride, const float *mstream,
-          int64_t m_stride, double *state) {
+          int64_t m_stride, double *state, double *ws, int64_t ws_stride, int tiles_per_seg) {
+    static_assert(!(STREAMS && SEG), "segments need scalar parameters");
     __shared__ SawShared sh;
     const int tid = threadIdx.x, lane = tid & 63;
     const int inst = blockIdx.x;
+    const int seg = SEG ? blockIdx.y : 0;
+    double *wsi = SEG ? ws + (int64_t)inst * ws_stride : nullptr;
     const pgx_blitsaw_params p = params[inst];
     float *ob = out + (int64_t)inst * out_stride;
     const float *fs = (STREAMS && freq) ? freq + (int64_t)inst * freq_stride : nullptr;
     const float *as = (STREAMS && amp) ? amp + (int64_t)inst * amp_stride : nullptr;
     const float *ms = (STREAMS && mstream) ? mstream + (int64_t)inst * m_stride : nullptr;
 
-    const double phase0 = state[inst * 2 + 0];
+    const double phase0 = (SEG == 2) ? wsi[0] : state[inst * 2 + 0];
     double carry_sum = 0.0;                 // running np.cumsum(phase_inc) at the tile start
-    double carry_y = state[inst * 2 + 1];   // leaky integrator output y[n-1]
+    double carry_y = (SEG == 2) ? wsi[1] : state[inst * 2 + 1];   // leaky integrator output y[n-1]
     const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
+    if (SEG == 1 && seg == 0 && tid == 0) {                       // the apply pass must not read what it overwrites
+        wsi[0] = phase0;
+        wsi[1] = carry_y;
+    }
 
     // powers of leak for the affine scan
     const double leak = p.leak;
@@ -834,7 +854,44 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     bool have_final = false;
 
     constexpr int kTile = NW * 64 * kSawT;
-    for (int64_t base = 0; base < n; base += kTile) {
+    const int first_tile = seg * tiles_per_seg;
+    if (SEG && first_tile > 0) {
+        // phase chain of the tiles before this segment: block_excl_sum_wide's carry, one add per group of waves
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) run = run + k0.inc;
+        double inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            double o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc = o + inc;
+        }
+        if (lane == 63) sh.sum[tid >> 6] = inc;
+        __syncthreads();
+        double tot[NW / kWaves];
+#pragma unroll
+        for (int g = 0; g < NW / kWaves; ++g) {
+            tot[g] = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) tot[g] = tot[g] + sh.sum[g * kWaves + w];
+        }
+        __syncthreads();
+        for (int tile = 0; tile < first_tile; ++tile)
+#pragma unroll
+            for (int g = 0; g < NW / kWaves; ++g) carry_sum = carry_sum + tot[g];
+        if (SEG == 2) {
+            // integrator chain: cn = lam_wave * cn + t over every wave of every earlier tile, in order
+            const int64_t prev = (int64_t)first_tile * NW;
+            for (int64_t i0 = 0; i0 < prev; i0 += 64) {
+                const double mine = (i0 + lane < prev) ? wsi[2 + i0 + lane] : 0.0;
+                const int cnt = (prev - i0 < 64) ? (int)(prev - i0) : 64;
+                for (int i = 0; i < cnt; ++i) carry_y = lam_wave * carry_y + readlane_f64(mine, i);
+            }
+        }
+    }
+    const int64_t seg_begin = SEG ? (int64_t)first_tile * kTile : 0;
+    const int64_t seg_end = SEG ? ((seg_begin + (int64_t)tiles_per_seg * kTile < n) ? seg_begin + (int64_t)tiles_per_seg * kTile : n) : n;
+    for (int64_t base = seg_begin; base < seg_end; base += kTile) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
         SawConst kc[kSawT];
         // ---- phase increment and inclusive local cumsum (blit_saw_pe.py:188-191) ----
@@ -878,6 +935,11 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
         double y = block_scan_scalar_affine_wide<NW>(e, lamp, lam_wave, lam_lane, sh.aff, carry_y);
+        if (SEG == 1) {                      // the wave responses the scan just folded are still in LDS
+            if (tid < NW) wsi[2 + (base / kTile) * NW + tid] = sh.aff[tid];
+            __syncthreads();
+            continue;
+        }
 
         float yf[kSawT];
 #pragma unroll
@@ -891,10 +953,24 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         }
         store_frames_tiled<kSawT>(ob, f0, n, channels, yf);
     }
-    if (have_final) {
+    if (SEG != 1 && have_final) {
         state[inst * 2 + 0] = final_phase;
         state[inst * 2 + 1] = final_y;
     }
+}
+
+// Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
+struct SawPlan {
+    int nseg, tiles_per_seg;
+    int64_t tiles;
+};
+SawPlan saw_plan(int batch, int64_t n, bool streams) {
+    constexpr int64_t tile = kSawWideWaves * 64 * kSawT;
+    SawPlan p{1, 0, (n + tile - 1) / tile};
+    if (streams || batch >= 128 || p.tiles < 3 || p.tiles > 2048) return p;
+    p.tiles_per_seg = (int)((p.tiles + 255) / 256);
+    p.nseg = (int)((p.tiles + p.tiles_per_seg - 1) / p.tiles_per_seg);
+    return p;
 }
 
 // ================================================================================================
@@ -1782,9 +1858,15 @@ int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, dou
     return PGX_OK;
 }
 
+size_t pgx_blitsaw_workspace_bytes(int batch, int64_t n, int streams) {
+    if (batch <= 0 || n <= 0) return 0;
+    const SawPlan p = saw_plan(batch, n, streams != 0);
+    return p.nseg > 1 ? (size_t)batch * (2 + (size_t)p.tiles * kSawWideWaves) * sizeof(double) : 0;
+}
+
 int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channels, double sample_rate,
                 const pgx_blitsaw_params *params, const float *freq, int64_t freq_stride, const float *amp,
-                int64_t amp_stride, const float *m, int64_t m_stride, double *state) {
+                int64_t amp_stride, const float *m, int64_t m_stride, double *state, void *workspace) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && params && state && channels >= 1 && sample_rate > 0, "pgx_blitsaw: bad argument");
@@ -1793,13 +1875,20 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     // a bank: 256-thread workgroups, the oscillators themselves fill the machine
     const bool wide = batch < 128 && n > kSawTile;
     const bool streams = freq || amp || m;
-#define PGX_SAW_LAUNCH(S, NWAVES)                                                                              \
-    hipLaunchKernelGGL((k_blitsaw<S, NWAVES>), dim3(batch), dim3(NWAVES * 64), 0, pgx::stream(), out, out_stride, \
-                       n, channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state)
-    if (streams && wide) PGX_SAW_LAUNCH(true, kSawWideWaves);
-    else if (streams) PGX_SAW_LAUNCH(true, kWaves);
-    else if (wide) PGX_SAW_LAUNCH(false, kSawWideWaves);
-    else PGX_SAW_LAUNCH(false, kWaves);
+    const SawPlan plan = saw_plan(batch, n, streams);
+#define PGX_SAW_LAUNCH(S, NWAVES, SEG, GRID)                                                                   \
+    hipLaunchKernelGGL((k_blitsaw<S, NWAVES, SEG>), GRID, dim3(NWAVES * 64), 0, pgx::stream(), out, out_stride, \
+                       n, channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state,  \
+                       (double *)workspace, ws_stride, plan.tiles_per_seg)
+    const int64_t ws_stride = 2 + plan.tiles * kSawWideWaves;
+    if (workspace && plan.nseg > 1) {        // long streams of a few oscillators: several workgroups each
+        PGX_SAW_LAUNCH(false, kSawWideWaves, 1, dim3(batch, plan.nseg));
+        PGX_LAUNCH_CHECK("k_blitsaw<reduce>");
+        PGX_SAW_LAUNCH(false, kSawWideWaves, 2, dim3(batch, plan.nseg));
+    } else if (streams && wide) PGX_SAW_LAUNCH(true, kSawWideWaves, 0, dim3(batch));
+    else if (streams) PGX_SAW_LAUNCH(true, kWaves, 0, dim3(batch));
+    else if (wide) PGX_SAW_LAUNCH(false, kSawWideWaves, 0, dim3(batch));
+    else PGX_SAW_LAUNCH(false, kWaves, 0, dim3(batch));
 #undef PGX_SAW_LAUNCH
     PGX_LAUNCH_CHECK("k_blitsaw");
     return PGX_OK;

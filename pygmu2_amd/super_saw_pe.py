@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import device as _dev
-from ._kernels import DeviceBuffer, check, lib, new_output, ptr
+from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, new_output, ptr
 from .blit_saw_pe import BlitSawPE
 from .cache_pe import CachePE
 from .extent import Extent
@@ -163,8 +163,9 @@ class SuperSawPE(ProcessingElement):
                                        float(np.float32(ratio))), "pgx_gain_const")
             f_stride = duration
         voices = DeviceBuffer((nv, duration), np.float32)
+        ws = blitsaw_workspace(self, nv, duration, f_buf is not None)
         check(L.pgx_blitsaw(voices.ptr, duration, nv, duration, 1, sr, self._params.ptr,
-                            ptr(f_buf), f_stride, None, 0, None, 0, self._state.ptr), "pgx_blitsaw")
+                            ptr(f_buf), f_stride, None, 0, None, 0, self._state.ptr, ptr(ws)), "pgx_blitsaw")
 
         a_s, a_buf = self._control_stream(self._amplitude, start, duration)
         if self._amp_scalar is None:

@@ -22,7 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import device as _dev
-from ._kernels import DeviceBuffer, check, lib, ptr
+from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, ptr
 from .adsr_pe import AdsrGatedPE
 from .biquad_pe import BiquadPE, rbj_coefficients, settle_frames
 from .blit_saw_pe import BlitSawPE
@@ -105,8 +105,9 @@ class _BlitSawNode(_Node):
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        ws = blitsaw_workspace(self, self.k, n, False)
         check(lib().pgx_blitsaw(out.ptr, n * self.ch, self.k, n, self.ch, self.sr, self.params.ptr,
-                                None, 0, None, 0, None, 0, self.state.ptr), "pgx_blitsaw")
+                                None, 0, None, 0, None, 0, self.state.ptr, ptr(ws)), "pgx_blitsaw")
         self.last_end = start + n
         return out
 
@@ -133,8 +134,9 @@ class _SuperSawNode(_Node):
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
         voices = DeviceBuffer((self.k * self.nv, n), np.float32)
+        ws = blitsaw_workspace(self, self.k * self.nv, n, False)
         check(L.pgx_blitsaw(voices.ptr, n, self.k * self.nv, n, 1, self.sr, self.params.ptr,
-                            None, 0, None, 0, None, 0, self.state.ptr), "pgx_blitsaw")
+                            None, 0, None, 0, None, 0, self.state.ptr, ptr(ws)), "pgx_blitsaw")
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
         check(L.pgx_supersaw_sum(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, voices.ptr,
                                  self.amp.ptr, None, 0), "pgx_supersaw_sum")

@@ -119,17 +119,30 @@ def test_wide_blitsaw_workgroups_reproduce_the_bank_kernel_bit_for_bit():
     for i, f in enumerate(freqs):
         rec[i] = (f, 1.0, 0.999, 0.0)
     params = device.upload_structs(rec)
-    blocks = [20000, 8192, 8193, 3000]
+    blocks = [20000, 8192, 8193, 3000, 100000, 12289]
     state_bank = device.DeviceBuffer((len(freqs), 2), np.float64, zero=True)
     state_one = device.DeviceBuffer((1, 2), np.float64, zero=True)
+    state_seg = device.DeviceBuffer((3, 2), np.float64, zero=True)
     pick = 77
     one_params = device.upload_structs(rec[pick:pick + 1])
+    seg_params = device.upload_structs(rec[pick - 1:pick + 2])
     for n in blocks:
         bank = device.DeviceBuffer((len(freqs), n, 1), np.float32)
         device.check(lib.pgx_blitsaw(bank.ptr, n, len(freqs), n, 1, sr, params.ptr, None, 0, None, 0, None, 0,
-                                     state_bank.ptr))
+                                     state_bank.ptr, None))
         one = device.DeviceBuffer((1, n, 1), np.float32)
         device.check(lib.pgx_blitsaw(one.ptr, n, 1, n, 1, sr, one_params.ptr, None, 0, None, 0, None, 0,
-                                     state_one.ptr))
+                                     state_one.ptr, None))
         assert np.array_equal(bank.to_host()[pick], one.to_host()[0]), n
+        # several workgroups per oscillator (two passes over a workspace): the same chains replayed
+        need = lib.pgx_blitsaw_workspace_bytes(3, n, 0)
+        assert (need > 0) == (n > 2 * 4096), (n, need)
+        ws = device.DeviceBuffer((max(need, 8),), np.uint8)
+        seg = device.DeviceBuffer((3, n, 1), np.float32)
+        device.check(lib.pgx_blitsaw(seg.ptr, n, 3, n, 1, sr, seg_params.ptr, None, 0, None, 0, None, 0,
+                                     state_seg.ptr, ws.ptr if need else None))
+        assert np.array_equal(seg.to_host()[1], one.to_host()[0]), n
+        assert np.array_equal(seg.to_host()[0], bank.to_host()[pick - 1]), n
+        assert np.array_equal(seg.to_host()[2], bank.to_host()[pick + 1]), n
+    assert np.array_equal(state_seg.to_host()[1], state_one.to_host()[0])
     assert np.array_equal(state_bank.to_host()[pick], state_one.to_host()[0])
