@@ -213,7 +213,8 @@ int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_
  * one_pole != 0: attack == release, scipy lfilter one-pole as a scan; else the attack/release
  * switch of _envelope_ar_numba (envelope_pe.py:259-271), one lane per channel.
  * rms_window > 0 selects DetectionMode.RMS (block-local uniform_filter1d, mode='nearest').
- * state[channel] = envelope; scratch: n*channels doubles. */
+ * state[channel] = envelope; scratch: pgx_envelope_scratch_bytes (detector output + 64-frame block sums). */
+size_t pgx_envelope_scratch_bytes(int64_t n, int channels);
 int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
                  double release_coeff, int one_pole, int rms_window, double *state, double *scratch);
 
@@ -259,6 +260,45 @@ int pgx_pan(float *out, const float *in, int64_t n, int src_channels, float azim
             const float *azimuth_stream, int constant_power);
 /* out[i] = float32 mean of frame i's channels (the mono mix SpatialHRTF convolves, spatial_pe.py:483) */
 int pgx_mono_mean(float *out, const float *in, int64_t n, int src_channels);
+
+/* ------------------------------------------------------------------ LoopPE / WindowPE / DynamicsPE
+ * (the remaining configurations of benchmarks/benchmark_pes.py:309-350)
+ * LoopPE._render (loop_pe.py:159-232): out[i] = loop[(start + i) mod loop_len] (numpy's non-negative modulo),
+ * silence from total_len on (count * loop_len; < 0 = endless); the last `crossfade` frames of the loop blend
+ * into its first ones with the reference's float64 weights.  `loop` = the source rendered over the loop region
+ * (loop_len, channels).  Bit-exact. */
+int pgx_loop(float *out, const float *loop, int64_t start, int64_t n, int channels, int64_t loop_len,
+             int64_t total_len, int64_t crossfade);
+/* WindowPE._render (window_pe.py:118-254): centred window of 2*half_window + 1 frames; `padded` = the source
+ * rendered over [start - half_window, start + n + half_window).  mode 0 max, 1 min, 2 mean, 3 rms;
+ * rectify: |x| first.  max / min are exact, mean / rms sum the window directly (the reference differences a
+ * cumulative sum).  workspace: pgx_window_workspace_bytes (64-frame block statistics, float64). */
+size_t pgx_window_workspace_bytes(int64_t n, int channels, int64_t half_window);
+int pgx_window(float *out, const float *padded, int64_t n, int channels, int64_t half_window, int mode,
+               int rectify, void *workspace);
+/* DynamicsPE._render (dynamics_pe.py:190-372): out = audio * 10**((gain_db(20 log10(max(env, 1e-10))) +
+ * makeup) / 20) with numpy's float32 typing of every step.  The host rounds the Python scalars the way numpy's
+ * weak-scalar promotion does (pygmu2_amd/dynamics_pe.py). */
+typedef struct {
+    int mode;              /* 0 compress, 1 limit (ratio = inf), 2 expand, 3 gate */
+    int soft;              /* knee > 0 */
+    int stereo_link;
+    int wide_makeup;       /* the make-up gain is a numpy float64 scalar (automatic value): float64 from its addition on */
+    float threshold;       /* float32(threshold) */
+    float slope;           /* float32(1/ratio - 1) (compress), float32(ratio - 1) (expand) */
+    float neg_slope;       /* float32(-(ratio - 1)) */
+    float half_knee;       /* float32(knee / 2) */
+    float two_knee;        /* float32(2 * knee) */
+    float knee;            /* float32(knee) */
+    float knee_lo;         /* float32(threshold - knee/2) */
+    float knee_hi;         /* float32(threshold + knee/2) */
+    float gate_range;      /* float32(gate_range) */
+    float makeup;          /* float32(makeup_gain_db) */
+    double gate_range_d;   /* the hard-knee gate is float64 in numpy */
+    double makeup_d;
+} pgx_dynamics_params;
+int pgx_dynamics(float *out, const float *audio, const float *envelope, int64_t n, int channels,
+                 int env_channels, const pgx_dynamics_params *params);
 
 /* ------------------------------------------------------------------ BlitSawPE / SuperSawPE
  * BlitSawPE._render (blit_saw_pe.py:150-264): phase cumsum -> mod 1 -> Dirichlet kernel

@@ -62,7 +62,8 @@ def load_reference():
                  "blit_saw_pe", "super_saw_pe", "ladder_pe", "comb_pe", "adsr_pe",
                  "periodic_gate", "periodic_trigger", "convolve_pe", "svfilter_pe", "envelope_pe",
                  "transform_pe", "wavetable_pe", "delay_pe", "piecewise_pe", "trigger_restart_pe", "cache_pe",
-                 "reverb_pe", "assets", "spatial_pe"):
+                 "reverb_pe", "assets", "spatial_pe", "loop_pe", "window_pe", "conversions", "dynamics_pe",
+                 "compressor_pe"):
         mods[name] = importlib.import_module(f"pygmu2.{name}")
     return mods
 
@@ -162,6 +163,22 @@ def build(spec, M):
         return M["trigger_restart_pe"].TriggerRestartPE(kw["trigger"], kw["src"])
     if kind == "ReverbPE":
         return M["reverb_pe"].ReverbPE(kw.pop("source"), kw.pop("ir"), kw.pop("mix", 0.5), **kw)
+    if kind == "LoopPE":
+        return M["loop_pe"].LoopPE(kw.pop("source"), **kw)
+    if kind == "WindowPE":
+        if "mode" in kw:
+            kw["mode"] = M["window_pe"].WindowMode(kw["mode"])
+        return M["window_pe"].WindowPE(**kw)
+    if kind == "DynamicsPE":
+        if "mode" in kw:
+            kw["mode"] = M["dynamics_pe"].DynamicsMode(kw["mode"])
+        return M["dynamics_pe"].DynamicsPE(**kw)
+    if kind in ("CompressorPE", "LimiterPE", "ExpanderPE"):
+        if "detection" in kw:
+            kw["detection"] = M["envelope_pe"].DetectionMode(kw["detection"])
+        return getattr(M["compressor_pe"], kind)(kw.pop("source"), **kw)
+    if kind == "CachePE":
+        return M["cache_pe"].CachePE(kw["source"])
     if kind == "TransformPE":
         return M["transform_pe"].TransformPE(kw["source"], func=numpy_func(kw["ops"]), name="ops")
     raise KeyError(kind)

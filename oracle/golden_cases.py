@@ -266,6 +266,58 @@ def cases():
           feedback=0.8, smoothing_samples=480),
         blocks_contig(0, [2500, 2500]))
 
+    # ---------------------------------------------------------------- LoopPE (bit-exact) / WindowPE / dynamics
+    add("loop_sine_region", 44100,                       # benchmark_pes.py:310
+        S("LoopPE", source=S("CropPE", source=S("SinePE", frequency=440.0), start=0, duration=4410)),
+        [[0, 10000], [10000, 4410], [-3000, 5000], [44100 * 50 + 7, 4096]])
+    add("loop_count_crossfade", 48000,
+        S("LoopPE", source=S("ArrayPE", data={"rng": 21, "n": 3000, "ch": 2, "scale": 0.5}),
+          loop_start=200, loop_end=2600, count=4, crossfade_seconds=0.01),
+        [[0, 5000], [5000, 4000], [9000, 2000], [9600, 100], [-100, 300]])
+    add("loop_crossfade_clamped", 1000,
+        S("LoopPE", source=S("IdentityPE"), loop_start=5, loop_end=16, crossfade_seconds=1.0),
+        [[0, 40], [-7, 30]])
+    win_src = S("ArrayPE", data={"rng": 22, "n": 9000, "ch": 2, "scale": 0.6}, extend_mode="zero")
+    for mode in ("max", "min", "mean", "rms"):
+        add(f"window_{mode}", 44100, S("WindowPE", source=win_src, window=0.01, mode=mode),
+            [[0, 4000], [4000, 5200], [-500, 700], [8800, 600]])
+    add("window_mean_signed", 44100, S("WindowPE", source=win_src, window=0.003, mode="mean", rectify=False),
+        [[100, 3000]])
+    add("window_max_default_sine", 44100, S("WindowPE", source=S("SinePE", frequency=440.0)),      # benchmark_pes.py:349
+        [[0, 8192], [8192, 1000]])
+    add("window_tiny", 44100, S("WindowPE", source=win_src, window=0.0, mode="max"), [[0, 300]])
+    dyn_src = S("GainPE", source=S("SinePE", frequency=220.0, channels=2),
+                gain=S("PiecewisePE", points=[[0, 0.02], [6000, 1.0], [12000, 0.05], [20000, 0.6]],
+                       transition_type="linear", extend_mode="hold_both"))
+    dyn_env = S("EnvelopePE", source=dyn_src, attack=0.002, release=0.02)
+    for mode, extra in (("compress", {}), ("compress", {"knee": 6.0}), ("limit", {}), ("limit", {"knee": 4.0}),
+                        ("expand", {"ratio": 2.0}), ("expand", {"ratio": 2.0, "knee": 8.0}),
+                        ("gate", {"threshold": -25.0}), ("gate", {"threshold": -25.0, "knee": 10.0})):
+        name = f"dynamics_{mode}" + ("_soft" if "knee" in extra else "")
+        kw = dict(threshold=-18.0, ratio=4.0, mode=mode)
+        kw.update(extra)
+        add(name, 44100, S("DynamicsPE", source=dyn_src, envelope=dyn_env, **kw), blocks_contig(0, [8000, 8000, 6000]))
+    add("dynamics_bench", 44100,                         # benchmark_pes.py:315-321
+        S("DynamicsPE", source=S("SinePE", frequency=440.0), envelope=S("EnvelopePE", source=S("SinePE", frequency=440.0)),
+          mode="compress", threshold=-10.0, ratio=4.0), blocks_contig(0, [8192, 8192]))
+    add("dynamics_unlinked_makeup", 44100,
+        S("DynamicsPE", source=dyn_src, envelope=dyn_env, threshold=-15.0, ratio=8.0, makeup_gain=3.0,
+          stereo_link=False), blocks_contig(0, [9000]))
+    add("dynamics_mono_env_sidechain", 44100,
+        S("DynamicsPE", source=dyn_src,
+          envelope=S("EnvelopePE", source=S("SinePE", frequency=3.0, amplitude=0.9), attack=0.001, release=0.05),
+          threshold=-12.0, ratio=6.0, knee=3.0), blocks_contig(0, [9000, 9000]))
+    add("compressor_default", 44100, S("CompressorPE", source=dyn_src), blocks_contig(0, [8192, 8192, 4000]))
+    add("compressor_bench", 44100, S("CompressorPE", source=S("SinePE", frequency=440.0)),          # benchmark_pes.py:325
+        blocks_contig(0, [8192, 8192]))
+    add("compressor_peak_lookahead", 44100,
+        S("CompressorPE", source=dyn_src, threshold=-24.0, ratio=3.0, attack=0.005, release=0.05, knee=0.0,
+          makeup_gain=2.0, lookahead=0.003, detection="peak"), blocks_contig(0, [8000, 8000]))
+    add("limiter_default", 44100, S("LimiterPE", source=dyn_src), blocks_contig(0, [8192, 8192, 4000]))
+    add("expander_default", 44100, S("ExpanderPE", source=dyn_src, threshold=-20.0), blocks_contig(0, [8192, 8192, 4000]))
+    add("expander_soft", 44100, S("ExpanderPE", source=dyn_src, threshold=-20.0, knee=6.0, gate_range=-40.0),
+        blocks_contig(0, [8192, 8192]))
+
     # ---------------------------------------------------------------- gates / ADSR (bit-exact)
     add("periodic_gate", 48000, S("PeriodicGate", frequency=2.0, duty_cycle=0.5),
         [[0, 48000 // 4], [48000 * 100, 4096], [-5000, 4096]])

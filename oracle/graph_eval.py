@@ -71,7 +71,37 @@ class Node:
             self.array = materialize_array(self.kw["data"])
             if self.array.ndim == 1:
                 self.array = self.array.reshape(-1, 1)
+        if self.kind in ("CompressorPE", "LimiterPE", "ExpanderPE"):
+            self._build_dynamics_processor()
         self.reset()
+
+    def _build_dynamics_processor(self):
+        """compressor_pe.py:121-161, 237-259, 293-326: CachePE(source) feeds an EnvelopePE and a DynamicsPE."""
+        kw = self.kw
+        cache = Node({"pe": "CachePE", "source": self.spec["source"]}, self.sr)
+        if self.kind == "ExpanderPE":
+            env = {"pe": "EnvelopePE", "attack": kw.get("attack", 0.001), "release": kw.get("release", 0.05),
+                   "mode": "peak"}
+            dyn = {"pe": "DynamicsPE", "threshold": kw.get("threshold", -40.0), "ratio": 1.0,
+                   "knee": kw.get("knee", 0.0), "makeup_gain": 0.0, "mode": "gate",
+                   "stereo_link": kw.get("stereo_link", True), "gate_range": kw.get("gate_range", -80.0)}
+        elif self.kind == "LimiterPE":
+            env = {"pe": "EnvelopePE", "attack": kw.get("attack", 0.0005), "release": kw.get("release", 0.05),
+                   "lookahead": kw.get("lookahead", 0.005), "mode": "peak"}
+            dyn = {"pe": "DynamicsPE", "threshold": kw.get("ceiling", -1.0), "ratio": 100.0, "knee": 0.0,
+                   "makeup_gain": 0.0, "mode": "compress", "stereo_link": kw.get("stereo_link", True)}
+        else:
+            env = {"pe": "EnvelopePE", "attack": kw.get("attack", 0.01), "release": kw.get("release", 0.1),
+                   "lookahead": kw.get("lookahead", 0.0), "mode": kw.get("detection", "rms")}
+            dyn = {"pe": "DynamicsPE", "threshold": kw.get("threshold", -20.0), "ratio": kw.get("ratio", 4.0),
+                   "knee": kw.get("knee", 6.0), "makeup_gain": kw.get("makeup_gain", "auto"), "mode": "compress",
+                   "stereo_link": kw.get("stereo_link", True)}
+        env_node = Node(env, self.sr)
+        env_node.sub["source"] = cache
+        dyn_node = Node(dyn, self.sr)
+        dyn_node.sub["source"] = cache
+        dyn_node.sub["envelope"] = env_node
+        self.sub = {"dynamics": dyn_node}
 
     # ------------------------------------------------------------------ state
     def reset(self, recursive=True):
@@ -100,6 +130,8 @@ class Node:
             self.state = O.gate_state()
         elif k == "EnvelopePE":
             self.state = O.envelope_state()
+        elif k == "CachePE":
+            self.state = {"key": None, "data": None}
         elif k in ("AdsrGatedPE", "AdsrTriggeredPE"):
             self.state = O.adsr_state()
         elif k in ("ConvolvePE", "ReverbPE"):
@@ -134,6 +166,8 @@ class Node:
         if k == "ConvolvePE":
             sc, fc = self.sub["src"].channels(), self.sub["fir"].channels()
             return sc if fc == 1 else (fc if sc == 1 else sc)
+        if k in ("CompressorPE", "LimiterPE", "ExpanderPE"):
+            return self.sub["dynamics"].channels()
         return self.sub["source"].channels()
 
     def extent(self):
@@ -196,6 +230,16 @@ class Node:
             se = self.sub["source"].extent()
             L = self.sub["ir"].extent()[1]
             return _union(se, (se[0], None if se[1] is None else se[1] + L - 1))
+        if k == "LoopPE":
+            _, length, _ = O.loop_geometry(self.sub["source"].extent(), kw.get("loop_start"), kw.get("loop_end"),
+                                           kw.get("crossfade_seconds"), self.sr)
+            return (0, None) if kw.get("count") is None else (0, kw["count"] * length)      # loop_pe.py:109-120
+        if k == "DynamicsPE":
+            return _isect(self.sub["source"].extent(), self.sub["envelope"].extent())         # dynamics_pe.py:184-188
+        if k in ("CompressorPE", "LimiterPE", "ExpanderPE"):
+            return self.sub["dynamics"].extent()
+        if k in ("WindowPE", "CachePE"):
+            return self.sub["source"].extent()
         if k in ("TransformPE", "EnvelopePE", "SpatialPE"):
             return self.sub["source"].extent()       # transform_pe.py:92-94, envelope_pe.py:104-106, spatial_pe.py:638-640
         if k in ("SinePE", "BlitSawPE", "SuperSawPE", "PeriodicGate"):
@@ -272,6 +316,29 @@ class Node:
                               kw.get("mode", "peak"), sr)
         if k == "TransformPE":
             return O.transform(self.sub["source"].render(start, n), kw["ops"])
+        if k == "CachePE":
+            if self.state["key"] != (start, n):
+                self.state = {"key": (start, n), "data": self.sub["source"].render(start, n)}
+            return self.state["data"]
+        if k == "LoopPE":
+            s0, length, xf = O.loop_geometry(self.sub["source"].extent(), kw.get("loop_start"), kw.get("loop_end"),
+                                             kw.get("crossfade_seconds"), sr)
+            count = kw.get("count")
+            if count is not None and (start >= count * length or min(n, count * length - start) <= 0):
+                return np.zeros((n, self.channels()), dtype=np.float32)       # no source pull (loop_pe.py:176-187)
+            return O.loop(self.sub["source"].render(s0, length), start, n, length, count, xf)
+        if k == "WindowPE":
+            half = O.window_half(kw.get("window", 0.05), sr)
+            x = self.sub["source"].render(start - half, n + 2 * half)
+            return O.window_stat(x, n, half, kw.get("mode", "max"), kw.get("rectify", True))
+        if k == "DynamicsPE":
+            audio = self.sub["source"].render(start, n)
+            env = self.sub["envelope"].render(start, n)
+            return O.dynamics(audio, env, kw.get("threshold", -20.0), kw.get("ratio", 4.0), kw.get("knee", 0.0),
+                              kw.get("makeup_gain", "auto"), kw.get("mode", "compress"),
+                              kw.get("stereo_link", True), kw.get("gate_range", -80.0))
+        if k in ("CompressorPE", "LimiterPE", "ExpanderPE"):
+            return self.sub["dynamics"].render(start, n)
         if k == "BlitSawPE":
             return O.blitsaw(self.state, start, n, self._param("frequency", start, n),
                              self._param("amplitude", start, n, 1.0), self._param("m", start, n, None),

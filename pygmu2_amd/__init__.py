@@ -48,6 +48,10 @@ from .trigger_restart_pe import TriggerRestartPE
 from .reverb_pe import ReverbPE
 from .spatial_pe import (SpatialAdapter, SpatialConstantPower, SpatialHRTF, SpatialLinear, SpatialMethod,
                          SpatialPE)
+from .loop_pe import LoopPE
+from .window_pe import WindowMode, WindowPE
+from .dynamics_pe import DynamicsMode, DynamicsPE, db_to_ratio, ratio_to_db
+from .compressor_pe import CompressorPE, ExpanderPE, LimiterPE
 from .wav_writer_pe import WavWriterPE
 from .wav_reader_pe import WavReaderPE
 from .utils import render_to_file
@@ -62,5 +66,6 @@ __all__ = [
     "AdsrTriggeredPE", "ConvolvePE", "SVFilterPE", "DetectionMode", "EnvelopePE", "TransformPE",
     "transforms", "DelayPE", "InterpolationMode", "PiecewisePE", "TransitionType", "TriggerRestartPE",
     "ReverbPE", "SpatialPE", "SpatialMethod", "SpatialAdapter", "SpatialLinear", "SpatialConstantPower",
-    "SpatialHRTF", "WavWriterPE", "WavReaderPE", "render_to_file", "device", "diagnostics",
+    "SpatialHRTF", "LoopPE", "WindowMode", "WindowPE", "DynamicsMode", "DynamicsPE", "CompressorPE", "LimiterPE",
+    "ExpanderPE", "db_to_ratio", "ratio_to_db", "WavWriterPE", "WavReaderPE", "render_to_file", "device", "diagnostics",
 ]

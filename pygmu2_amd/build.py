@@ -27,6 +27,7 @@ SOURCES = [
     "pgx_adsr.hip",
     "pgx_convolve.hip",
     "pgx_lookup.hip",
+    "pgx_dynamics.hip",
     "pgx_fftconv.hip",
 ]
 

@@ -1489,27 +1489,64 @@ k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx
 // ================================================================================================
 // Detector: |x| (peak) or the block-local centred running RMS of scipy.ndimage.uniform_filter1d(x^2,
 // size=window, mode='nearest') (envelope_pe.py:208-225).  Output float64 (frames, channels).
+// RMS sums each window as head + whole 64-frame blocks + tail (k_env_blocks holds the block sums of squares),
+// with the 'nearest' edge samples weighted by how often the clamped window repeats them.
+constexpr int kEnvBlock = 64;
+
 __global__ void __launch_bounds__(kBlock)
-k_env_detect(double *det, const float *in, int64_t n, int channels, int rms_window) {
+k_env_blocks(double *blocks, const float *in, int64_t n, int channels) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nblk = (n + kEnvBlock - 1) / kEnvBlock;
+    const int64_t item = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);          // one wave per (block, channel)
+    if (item >= nblk * channels) return;
+    const int64_t b = item / channels;
+    const int c = (int)(item - b * channels);
+    const int64_t f = b * kEnvBlock + lane;
+    double v = 0.0;
+    if (f < n) {
+        v = (double)in[f * channels + c];
+        v = v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_down(v, d, 64);
+    if (lane == 0) blocks[item] = v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_env_detect(double *det, const float *in, const double *blocks, int64_t n, int channels, int rms_window) {
     const int64_t total = n * channels;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    auto sq = [&](int64_t f, int c) {
+        const double v = (double)in[f * channels + c];
+        return v * v;
+    };
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
         const int64_t i = e / channels;
         const int c = (int)(e - i * channels);
         if (rms_window <= 0) {
             det[e] = fabs((double)in[e]);
-        } else {
-            // window [i - size/2, i - size/2 + size) with indices clamped to the block ('nearest')
-            const int64_t lo = i - rms_window / 2;
-            double acc = 0.0;
-            for (int w = 0; w < rms_window; ++w) {
-                int64_t j = lo + w;
-                j = j < 0 ? 0 : (j >= n ? n - 1 : j);
-                const double v = fabs((double)in[j * channels + c]);
-                acc += v * v;
-            }
-            det[e] = sqrt(acc / (double)rms_window);
+            continue;
         }
+        // window [i - size/2, i - size/2 + size) with indices clamped to the block ('nearest')
+        int64_t lo = i - rms_window / 2, hi = lo + rms_window;
+        double acc = 0.0;
+        if (lo < 0) {
+            acc = acc + (double)(-lo) * sq(0, c);
+            lo = 0;
+        }
+        if (hi > n) {
+            acc = acc + (double)(hi - n) * sq(n - 1, c);
+            hi = n;
+        }
+        const int64_t b0 = (lo + kEnvBlock - 1) / kEnvBlock, b1 = hi / kEnvBlock;        // whole blocks [b0, b1)
+        if (b0 < b1) {
+            for (int64_t f = lo; f < b0 * kEnvBlock; ++f) acc = acc + sq(f, c);
+            for (int64_t b = b0; b < b1; ++b) acc = acc + blocks[b * channels + c];
+            for (int64_t f = b1 * kEnvBlock; f < hi; ++f) acc = acc + sq(f, c);
+        } else {
+            for (int64_t f = lo; f < hi; ++f) acc = acc + sq(f, c);
+        }
+        det[e] = sqrt(acc / (double)rms_window);
     }
 }
 
@@ -1944,6 +1981,11 @@ int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_
     return PGX_OK;
 }
 
+size_t pgx_envelope_scratch_bytes(int64_t n, int channels) {
+    if (n <= 0 || channels <= 0) return 0;
+    return (size_t)(n + (n + kEnvBlock - 1) / kEnvBlock) * channels * sizeof(double);
+}
+
 int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
                  double release_coeff, int one_pole, int rms_window, double *state, double *scratch) {
     PGX_REQUIRE_INIT();
@@ -1951,8 +1993,15 @@ int pgx_envelope(float *out, const float *in, int64_t n, int channels, double at
     PGX_CHECK_ARG(out && in && state && scratch && channels >= 1, "pgx_envelope: bad argument");
     const bool fused_peak = !one_pole && rms_window <= 0;                   // |x| is taken inside the follower
     if (!fused_peak) {
+        double *blocks = scratch + n * channels;                            // after the detector output
+        if (rms_window > 0) {
+            const int64_t items = (n + kEnvBlock - 1) / kEnvBlock * channels;
+            hipLaunchKernelGGL(k_env_blocks, dim3((unsigned)((items + kWaves - 1) / kWaves)), dim3(kBlock), 0,
+                               pgx::stream(), blocks, in, n, channels);
+            PGX_LAUNCH_CHECK("k_env_blocks");
+        }
         hipLaunchKernelGGL(k_env_detect, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(),
-                           scratch, in, n, channels, rms_window);
+                           scratch, in, blocks, n, channels, rms_window);
         PGX_LAUNCH_CHECK("k_env_detect");
     }
     if (one_pole) {

@@ -86,6 +86,10 @@ _SIGNATURES = [
     ("pgx_channel_adapt", _I, [_P, _P, _L, _I, _I]),
     ("pgx_pan", _I, [_P, _P, _L, _I, C.c_float, _P, _I]),
     ("pgx_mono_mean", _I, [_P, _P, _L, _I]),
+    ("pgx_loop", _I, [_P, _P, _L, _L, _I, _L, _L, _L]),
+    ("pgx_window_workspace_bytes", _Z, [_L, _I, _L]),
+    ("pgx_window", _I, [_P, _P, _L, _I, _L, _I, _I, _P]),
+    ("pgx_dynamics", _I, [_P, _P, _P, _L, _I, _I, _P]),
     ("pgx_gate_stateful", _I, [_P, _L, _D, _D, _D, _D, _P, _P, _P, _P]),
     ("pgx_interp_lookup", _I, [_P, _P, _L, _L, _I, _L, _L, _D, _P, _I, _I, _D, _D]),
     ("pgx_index_range", _I, [_P, _P, _L, _L]),
@@ -93,6 +97,7 @@ _SIGNATURES = [
     ("pgx_f32_to_pcm16", _I, [_P, _P, _L]),
     ("pgx_pcm16_to_f32", _I, [_P, _P, _L]),
     ("pgx_svf", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _P, _P, _P]),
+    ("pgx_envelope_scratch_bytes", _Z, [_L, _I]),
     ("pgx_envelope", _I, [_P, _P, _L, _I, _D, _D, _I, _I, _P, _P]),
     ("pgx_transform", _I, [_P, _P, _L, _P, _I]),
     ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P, _P]),
@@ -119,6 +124,10 @@ SINE_STATEFUL_PARAMS = np.dtype([("freq", "<f8"), ("amp", "<f8"), ("phase", "<f8
                                  ("phase_is_stream", "<i4"), ("pad", "<i4")])
 BIQUAD_VAR_PARAMS = np.dtype([("freq", "<f8"), ("q", "<f8"), ("gain_db", "<f8"),
                               ("mode", "<i4"), ("pad", "<i4")])
+DYNAMICS_PARAMS = np.dtype([("mode", "<i4"), ("soft", "<i4"), ("stereo_link", "<i4"), ("wide_makeup", "<i4"),
+                            ("threshold", "<f4"), ("slope", "<f4"), ("neg_slope", "<f4"), ("half_knee", "<f4"),
+                            ("two_knee", "<f4"), ("knee", "<f4"), ("knee_lo", "<f4"), ("knee_hi", "<f4"),
+                            ("gate_range", "<f4"), ("makeup", "<f4"), ("gate_range_d", "<f8"), ("makeup_d", "<f8")])
 BLITSAW_PARAMS = np.dtype([("freq", "<f8"), ("amp", "<f8"), ("leak", "<f8"), ("m", "<f8")])
 LADDER_PARAMS = np.dtype([("freq", "<f8"), ("resonance", "<f8"), ("drive", "<f8"),
                           ("passband_gain", "<f8"), ("oversample", "<i4"), ("mode", "<i4")])

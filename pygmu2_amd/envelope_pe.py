@@ -6,7 +6,7 @@ The source is rendered `int(lookahead * sr)` samples ahead, rectified (PEAK) or 
 a block-local running RMS (RMS) and smoothed:
   * attack == release: a one-pole low-pass, run as a time-parallel scalar affine scan;
   * otherwise: e += (target > e ? attack_coeff : release_coeff) * (target - e), which
-    switches on its own output and runs one lane per channel.
+    switches on its own output: solved in windows by time-parallel Newton rounds (k_env_newton).
 The per-channel envelope lives in HBM and is zeroed by on_start / on_stop.
 """
 
@@ -71,9 +71,9 @@ class EnvelopePE(ProcessingElement):
         if self._state is None or self._state_channels != ch:
             self._state = DeviceBuffer((ch,), np.float64, zero=True)
             self._state_channels = ch
-        need = duration * ch
-        if self._scratch_buf is None or self._scratch_buf.nbytes < need * 8:
-            self._scratch_buf = DeviceBuffer((need,), np.float64)
+        need = lib().pgx_envelope_scratch_bytes(duration, ch)
+        if self._scratch_buf is None or self._scratch_buf.nbytes < need:
+            self._scratch_buf = DeviceBuffer((need // 8,), np.float64)
         # envelope_pe.py:153-158
         attack_coeff = float(1.0 - np.exp(-1.0 / (self._attack * sr))) if self._attack > 0 else 1.0
         release_coeff = float(1.0 - np.exp(-1.0 / (self._release * sr))) if self._release > 0 else 1.0

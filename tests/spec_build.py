@@ -49,6 +49,22 @@ def build(spec):
         if "mode" in kw:
             kw["mode"] = pg.DetectionMode(kw["mode"])
         return pg.EnvelopePE(**kw)
+    if kind == "LoopPE":
+        return pg.LoopPE(kw.pop("source"), **kw)
+    if kind == "WindowPE":
+        if "mode" in kw:
+            kw["mode"] = pg.WindowMode(kw["mode"])
+        return pg.WindowPE(**kw)
+    if kind == "DynamicsPE":
+        if "mode" in kw:
+            kw["mode"] = pg.DynamicsMode(kw["mode"])
+        return pg.DynamicsPE(**kw)
+    if kind in ("CompressorPE", "LimiterPE", "ExpanderPE"):
+        if "detection" in kw:
+            kw["detection"] = pg.DetectionMode(kw["detection"])
+        return getattr(pg, kind)(kw.pop("source"), **kw)
+    if kind == "CachePE":
+        return pg.CachePE(kw["source"])
     if kind == "TransformPE":
         return pg.TransformPE(kw["source"], func=pg.transforms.from_spec(kw["ops"]), name="ops")
     if kind == "SpatialPE":

@@ -84,7 +84,34 @@ def _control(rng, lo, hi):
 def _effect(rng, src, ch):
     kind = rng.choice(["gain", "gain_pe", "biquad", "biquad_var", "svf", "svf_var", "ladder", "comb", "delay",
                        "delay_frac", "delay_pe", "crop", "env", "transform", "spatial", "convolve", "reverb",
-                       "trigger_restart"])
+                       "trigger_restart", "loop", "window", "dynamics", "compressor"])
+    if kind == "loop":
+        a = int(rng.integers(-100, 900))
+        return {"pe": "LoopPE", "source": src, "loop_start": a, "loop_end": a + int(rng.integers(30, 4000)),
+                "count": None if rng.random() < 0.5 else int(rng.integers(1, 5)),
+                "crossfade_seconds": None if rng.random() < 0.4 else float(rng.uniform(0.0, 0.02))}, ch
+    if kind == "window":
+        return {"pe": "WindowPE", "source": src, "window": float(rng.choice([0.0, 0.0007, 0.004, 0.03])),
+                "mode": str(rng.choice(["max", "min", "mean", "rms"])), "rectify": bool(rng.random() < 0.8)}, ch
+    if kind == "dynamics":
+        # (the hard-knee gate jumps by gate_range at the threshold: one ulp of level would flip a sample; its
+        # golden cases cover it)
+        mode = str(rng.choice(["compress", "limit", "expand", "gate"]))
+        env = {"pe": "EnvelopePE", "source": _source(rng, int(rng.choice([1, ch]))), "attack": float(rng.uniform(0.001, 0.02)),
+               "release": float(rng.uniform(0.01, 0.1))}
+        return {"pe": "DynamicsPE", "source": src, "envelope": env, "threshold": float(rng.uniform(-40.0, -6.0)),
+                "ratio": float(rng.uniform(1.5, 10.0)), "knee": float(rng.uniform(2.0, 12.0)) if mode == "gate" or rng.random() < 0.5 else 0.0,
+                "makeup_gain": "auto" if rng.random() < 0.5 else float(rng.uniform(-3.0, 6.0)), "mode": mode,
+                "stereo_link": bool(rng.random() < 0.5)}, ch
+    if kind == "compressor":
+        which = str(rng.choice(["CompressorPE", "LimiterPE", "ExpanderPE"]))
+        if which == "CompressorPE":
+            return {"pe": which, "source": src, "threshold": float(rng.uniform(-30.0, -6.0)), "ratio": float(rng.uniform(2.0, 8.0)),
+                    "detection": str(rng.choice(["peak", "rms"])), "lookahead": float(rng.choice([0.0, 0.002]))}, ch
+        if which == "LimiterPE":
+            return {"pe": which, "source": src, "ceiling": float(rng.uniform(-12.0, -0.5))}, ch
+        return {"pe": which, "source": src, "threshold": float(rng.uniform(-40.0, -10.0)), "knee": float(rng.uniform(3.0, 10.0)),
+                "gate_range": float(rng.uniform(-60.0, -20.0))}, ch
     if kind in ("convolve", "reverb"):
         taps = int(rng.choice([3, 40, 300, 2500]))                      # 2500: the FFT path
         fir_ch = 1 if (ch == 1 and rng.random() < 0.5) or ch > 2 or kind == "reverb" else int(rng.choice([1, ch]))

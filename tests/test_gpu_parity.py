@@ -41,6 +41,7 @@ BIT_EXACT = {
     "spatial_adapter_1_to_2", "spatial_adapter_2_to_1", "spatial_adapter_2_to_4", "spatial_adapter_4_to_2",
     "spatial_adapter_3_to_5", "spatial_adapter_5_to_2", "spatial_adapter_1_to_4", "spatial_adapter_2_to_2",
     "spatial_linear_scalar",
+    "loop_count_crossfade", "loop_crossfade_clamped", "window_max", "window_min", "window_tiny",
 }
 
 
