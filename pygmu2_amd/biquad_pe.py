@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from enum import Enum
 
+import math
+
 import numpy as np
 
 from . import device as _dev
@@ -129,6 +131,8 @@ class BiquadPE(ProcessingElement):
         self._state: DeviceBuffer | None = None       # [C][2] or [C][4] float64
         self._state_channels = 0
         self._workspace: DeviceBuffer | None = None
+        self._ws_key: tuple[int, int] | None = None
+        self._ws_need = 0
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -186,7 +190,10 @@ class BiquadPE(ProcessingElement):
                 if self._settle:
                     self._tables = DeviceBuffer((L.pgx_biquad_table_doubles(),), np.float64)
                     check(L.pgx_biquad_tables(self._tables.ptr, self._coef.ptr, 1), "pgx_biquad_tables")
-            need = L.pgx_biquad_workspace_bytes(1, duration, ch, self._settle)
+            if self._ws_key != (duration, ch):
+                self._ws_need = L.pgx_biquad_workspace_bytes(1, duration, ch, self._settle)
+                self._ws_key = (duration, ch)
+            need = self._ws_need
             if need and (self._workspace is None or self._workspace.nbytes < need):
                 self._workspace = DeviceBuffer((need,), np.uint8)
             check(L.pgx_biquad_const(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, self._coef.ptr,
@@ -201,11 +208,14 @@ class BiquadPE(ProcessingElement):
                 _dev.BIQUAD_VAR_PARAMS, freq=0.0 if f_s is None else f_s, q=0.0 if q_s is None else q_s,
                 gain_db=float(self._gain_db), mode=_MODE_INDEX[self._mode])
         gain_a = 10.0 ** (self._gain_db / 40.0)
-        need = L.pgx_scan2_workspace_bytes(duration, ch)
+        if self._ws_key != (duration, ch):                   # (the plan only depends on the block shape)
+            self._ws_need = L.pgx_scan2_workspace_bytes(duration, ch)
+            self._ws_key = (duration, ch)
+        need = self._ws_need
         if need and (self._workspace is None or self._workspace.nbytes < need):
             self._workspace = DeviceBuffer((need,), np.uint8)
         check(L.pgx_biquad_varying(out.ptr, src.dev.ptr, duration, ch, sr, self._params.ptr,
-                                   ptr(f_buf), ptr(q_buf), gain_a, float(np.sqrt(gain_a)),
+                                   ptr(f_buf), ptr(q_buf), gain_a, math.sqrt(gain_a),
                                    self._state.ptr, ptr(self._workspace) if need else None),
               "pgx_biquad_varying")
         return Snippet(start, out)

@@ -217,6 +217,9 @@ def device_name() -> str:
     return buf.value.decode()
 
 
+_F32 = np.dtype(np.float32)
+
+
 class DeviceBuffer:
     """
     A typed, shaped block of device memory owned by this Python object (returned to the
@@ -227,15 +230,20 @@ class DeviceBuffer:
     __slots__ = ("ptr", "shape", "dtype", "nbytes", "_owner", "__weakref__")
 
     def __init__(self, shape, dtype=np.float32, *, zero: bool = False):
-        lib = ensure_init()
-        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
-        self.dtype = np.dtype(dtype)
+        lib = _lib if _initialised else ensure_init()
+        if type(shape) is tuple:
+            self.shape = shape if all(type(v) is int for v in shape) else tuple(int(v) for v in shape)
+        else:
+            self.shape = tuple(int(v) for v in shape) if isinstance(shape, list) else (int(shape),)
+        self.dtype = _F32 if dtype is np.float32 else np.dtype(dtype)
         n = 1
-        for s in self.shape:
-            n *= s
+        for v in self.shape:
+            n *= v
         self.nbytes = n * self.dtype.itemsize
         p = C.c_void_p(0)
-        check(lib.pgx_malloc(C.byref(p), max(self.nbytes, 1)), "pgx_malloc")
+        rc = lib.pgx_malloc(C.byref(p), self.nbytes or 1)
+        if rc:
+            check(rc, "pgx_malloc")
         self.ptr = p.value
         self._owner = True
         if zero and self.nbytes:

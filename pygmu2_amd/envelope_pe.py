@@ -38,6 +38,9 @@ class EnvelopePE(ProcessingElement):
         self._state: DeviceBuffer | None = None
         self._state_channels = 0
         self._scratch_buf: DeviceBuffer | None = None
+        self._plan_key = None
+        self._scratch_need = 0
+        self._coeffs = (1.0, 1.0, 0, 0)
 
     source = property(lambda self: self._source)
     attack = property(lambda self: self._attack)
@@ -71,17 +74,21 @@ class EnvelopePE(ProcessingElement):
         if self._state is None or self._state_channels != ch:
             self._state = DeviceBuffer((ch,), np.float64, zero=True)
             self._state_channels = ch
-        need = lib().pgx_envelope_scratch_bytes(duration, ch)
+        if self._plan_key != (duration, ch, sr):             # per block shape: scratch size and the coefficients
+            self._plan_key = (duration, ch, sr)
+            self._scratch_need = lib().pgx_envelope_scratch_bytes(duration, ch)
+            # envelope_pe.py:153-158
+            a = float(1.0 - np.exp(-1.0 / (self._attack * sr))) if self._attack > 0 else 1.0
+            r = float(1.0 - np.exp(-1.0 / (self._release * sr))) if self._release > 0 else 1.0
+            window = max(1, int(min(0.01, self._attack) * sr)) if self._mode == DetectionMode.RMS else 0
+            self._coeffs = (a, r, 1 if (self._attack == self._release and a < 1.0) else 0, window)
+        need = self._scratch_need
         if self._scratch_buf is None or self._scratch_buf.nbytes < need:
             self._scratch_buf = DeviceBuffer((need // 8,), np.float64)
-        # envelope_pe.py:153-158
-        attack_coeff = float(1.0 - np.exp(-1.0 / (self._attack * sr))) if self._attack > 0 else 1.0
-        release_coeff = float(1.0 - np.exp(-1.0 / (self._release * sr))) if self._release > 0 else 1.0
-        one_pole = self._attack == self._release and attack_coeff < 1.0
-        window = max(1, int(min(0.01, self._attack) * sr)) if self._mode == DetectionMode.RMS else 0
+        attack_coeff, release_coeff, one_pole, window = self._coeffs
         out = new_output(duration, ch)
         check(lib().pgx_envelope(out.ptr, src.dev.ptr, duration, ch, attack_coeff, release_coeff,
-                                 1 if one_pole else 0, window, self._state.ptr, self._scratch_buf.ptr),
+                                 one_pole, window, self._state.ptr, self._scratch_buf.ptr),
               "pgx_envelope")
         return Snippet(start, out)
 

@@ -69,8 +69,8 @@ class _ExtentWindowPE(ProcessingElement):
         hold_last = self._extend_mode in (ExtendMode.HOLD_LAST, ExtendMode.HOLD_BOTH)
         L = lib()
 
-        if ws is None and we is not None and start < we and end <= we:
-            return self._source.render(start, duration)          # fully inside an open-start window
+        if lo == start and hi == end:
+            return self._source.render(start, duration)          # fully inside the window: nothing to cut
 
         if lo >= hi:                                               # request misses the window
             ch = self._guess_channels()

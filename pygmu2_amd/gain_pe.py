@@ -42,6 +42,8 @@ class GainPE(ProcessingElement):
                 # producer + constant gain in one launch (same float32 roundings as two launches)
                 return fused(start, duration, float(np.float32(self._gain)))
         src = self._source.render(start, duration)
+        if not self._gain_is_pe and self._gain == 1.0:
+            return src                                           # x * float32(1) is x, bit for bit
         ch = src.channels
         out = new_output(duration, ch)
         if self._gain_is_pe:
@@ -54,8 +56,10 @@ class GainPE(ProcessingElement):
             check(lib().pgx_gain_vec(out.ptr, src.dev.ptr, g.dev.ptr, duration, ch, gch), "pgx_gain_vec")
         else:
             # the reference multiplies by np.float32(gain): round the scalar to float32 first
-            check(lib().pgx_gain_const(out.ptr, src.dev.ptr, duration * ch,
-                                       float(np.float32(self._gain))), "pgx_gain_const")
+            g32 = self.__dict__.get("_gain_f32")
+            if g32 is None:
+                g32 = self.__dict__["_gain_f32"] = float(np.float32(self._gain))
+            check(lib().pgx_gain_const(out.ptr, src.dev.ptr, duration * ch, g32), "pgx_gain_const")
         return Snippet(start, out)
 
     def __repr__(self) -> str:

@@ -65,18 +65,21 @@ class ProcessingElement(ABC):
     def render(self, start: int, duration: int) -> Snippet:
         if duration < 0:
             raise ValueError(f"duration must be >= 0, got {duration}")
-        if is_enabled() and pull_count_enabled():
+        diag = is_enabled()
+        if diag and pull_count_enabled():
             record_pull(self)
         if duration == 0:
             ch = self.channel_count()
             return Snippet.from_zeros(start, 0, int(ch) if ch is not None else 1)
-        if is_enabled() and timing_enabled():
+        if diag and timing_enabled():
             t0 = time.perf_counter_ns()
             out = self._render(start, duration)
             record_timing(self, time.perf_counter_ns() - t0)
             return out
-        if duration <= _read_ahead.SMALL_BLOCK:
-            ahead = _read_ahead.render(self, start, duration)     # pure sub-graphs, sequential small pulls
+        # pure sub-graphs, sequential small pulls (the verdict of read_ahead.eligible is cached on the instance:
+        # a PE that is not eligible skips the call altogether)
+        if duration <= _read_ahead.SMALL_BLOCK and self.__dict__.get("_ra_ok", True):
+            ahead = _read_ahead.render(self, start, duration)
             if ahead is not None:
                 return ahead
         return self._render(start, duration)
