@@ -31,6 +31,7 @@ constexpr int kIdle = 0, kAttack = 1, kDecay = 2, kSustain = 3, kRelease = 4;
 constexpr double kTwo52 = 4503599627370496.0;        // 2^52
 constexpr double kTwo53 = 9007199254740992.0;        // 2^53
 constexpr int kGroupChunks = 8;                       // fast path granularity: 8 x 64 samples
+constexpr int kWideWalkBatch = 128;                   // up to here an envelope gets a whole workgroup (see k_adsr_walk)
 
 // ------------------------------------------------------------------------------------------------
 // k_adsr_edges
@@ -268,7 +269,11 @@ __device__ __forceinline__ double adsr_chunk(AdsrCtx &cx, const pgx_adsr_params 
     return mine;
 }
 
-template <bool TRIG>
+// WPE = waves per envelope.  1: a bank of envelopes, one wave each.  4: a few envelopes (a rank's share of a
+// sharded mix): the four waves of a workgroup walk the SAME envelope redundantly -- the walk is scalar control
+// flow, identical in each -- and split the emitting (conversions + stores), which is what the fast path spends
+// its issue slots on: chunk k of a group is written by wave k mod 4.  No LDS, no barrier.
+template <bool TRIG, int WPE>
 __global__ void __launch_bounds__(256)
 k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
             const pgx_adsr_params *params, const unsigned long long *masks, const unsigned long long *group_bits,
@@ -278,8 +283,10 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
     // (pgx_adsr_gated_periodic's detach_walk) it must win instruction arbitration, or it is the
     // block's critical path at a third of its speed.
     __builtin_amdgcn_s_setprio(3);
-    // one wave per envelope; readfirstlane makes the index provably wave-uniform (scalar loads)
-    const int inst = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // readfirstlane makes the indices provably wave-uniform (scalar loads)
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int inst = (WPE == 1) ? blockIdx.x * 4 + wave_id : blockIdx.x;
+    const int sub = (WPE == 1) ? 0 : wave_id;                    // which share of the chunks this wave writes
     if (inst >= batch) return;
     const pgx_adsr_params p = params[inst];
     float *o = out + (int64_t)inst * out_stride;
@@ -295,6 +302,7 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
     c.dir = 0;
     c.dq = 0.0;
     c.lim = 0.0;
+    if (WPE > 1) __syncthreads();           // every wave has read the state before wave 0 may overwrite it
 
     // The walk is a dependent chain on a single wave, so nothing on the common path may wait for
     // memory: "does group i contain an edge" is one bit of a per-voice bitmap, 64 groups (32 768
@@ -320,7 +328,8 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                     const double env = c.env, dq = c.dq;
 #pragma unroll
                     for (int k = 0; k < kGroupChunks; ++k)
-                        o[base + k * 64 + lane] = (float)(env + (double)(k * 64 + lane) * dq);    // exact
+                        if (WPE == 1 || (k & (WPE - 1)) == sub)
+                            o[base + k * 64 + lane] = (float)(env + (double)(k * 64 + lane) * dq);    // exact
                     c.env = env + (double)(64 * kGroupChunks) * dq;
                     continue;
                 }
@@ -339,12 +348,17 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
         }
 #pragma unroll 1
         for (int k = 0; k < kGroupChunks; ++k) {
-            // pick chunk k's masks with selects (a dynamically indexed register array would go to scratch)
-            unsigned long long amk = am[0], rmk = rm[0];
+            // pick chunk k's masks with selects (a dynamically indexed register array would go to scratch);
+            // a group that is slow only because a run ends in it has none to pick
+            unsigned long long amk = 0ull, rmk = 0ull;
+            if (has_edge) {
+                amk = am[0];
+                rmk = rm[0];
 #pragma unroll
-            for (int j = 1; j < kGroupChunks; ++j) {
-                amk = (k == j) ? am[j] : amk;
-                rmk = (k == j) ? rm[j] : rmk;
+                for (int j = 1; j < kGroupChunks; ++j) {
+                    amk = (k == j) ? am[j] : amk;
+                    rmk = (k == j) ? rm[j] : rmk;
+                }
             }
             const int64_t i0 = (ch + k) * 64;
             if ((amk | rmk) == 0ull) {
@@ -356,14 +370,15 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                     bool ok = (c.dir > 0) ? (vlast <= c.lim) : ((c.dir < 0) ? (vlast >= c.lim) : true);
                     if (TRIG && c.s == kSustain) ok = ((long long)(start + i0) + 63 < c.ends_at);
                     if (ok) {
-                        o[i0 + lane] = (float)(c.env + (double)lane * c.dq);       // exact
+                        if (WPE == 1 || (k & (WPE - 1)) == sub)
+                            o[i0 + lane] = (float)(c.env + (double)lane * c.dq);   // exact
                         c.env = c.env + 64.0 * c.dq;
                         continue;
                     }
                 }
             }
             const double mine = adsr_chunk<TRIG>(c, p, amk, amk | rmk, 64, (long long)(start + i0), lane);
-            o[i0 + lane] = (float)mine;
+            if (WPE == 1 || (k & (WPE - 1)) == sub) o[i0 + lane] = (float)mine;
         }
     }
 #pragma unroll 1
@@ -372,9 +387,9 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
         const int64_t i0 = ch * 64;
         const int nvalid = (n - i0 < 64) ? (int)(n - i0) : 64;
         const double mine = adsr_chunk<TRIG>(c, p, am, am | rm, nvalid, (long long)(start + i0), lane);
-        if (lane < nvalid) o[i0 + lane] = (float)mine;
+        if (lane < nvalid && (WPE == 1 || (int)(ch & (WPE - 1)) == sub)) o[i0 + lane] = (float)mine;
     }
-    if (lane == 0) {
+    if (lane == 0 && sub == 0) {
         st[0] = (double)c.s;
         st[1] = c.env;
         st[2] = TRIG ? (double)c.ends_at : (double)last_gate[inst];
@@ -418,9 +433,15 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
         int rc = pgx_stream_fork();
         if (rc != PGX_OK) return rc;
     }
-    hipLaunchKernelGGL(k_adsr_walk<MODE == 1>, dim3((batch + 3) / 4), dim3(256), 0, pgx::stream(), out, out_stride,
-                       batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
-                       (const unsigned long long *)w.group_bits, (const float *)w.last_gate, state);
+    if (batch <= kWideWalkBatch)
+        hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 4>), dim3(batch), dim3(256), 0, pgx::stream(), out, out_stride,
+                           batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
+                           (const unsigned long long *)w.group_bits, (const float *)w.last_gate, state);
+    else
+        hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 1>), dim3((batch + 3) / 4), dim3(256), 0, pgx::stream(), out,
+                           out_stride, batch, start, n, w.nchunks, w.gwords, params,
+                           (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
+                           (const float *)w.last_gate, state);
     PGX_LAUNCH_CHECK("k_adsr_walk");
     if (detach_walk) return pgx_stream_select(0);
     return PGX_OK;

@@ -68,103 +68,135 @@ __device__ __forceinline__ void ladder_store(double *st, const LadderState &s);
 
 constexpr int kLadderChunk = 8;
 
-__device__ __forceinline__ void ladder_fetch(const LadderConsts &c, int64_t i, int64_t i1, float (&x)[kLadderChunk]) {
-#pragma unroll
-    for (int j = 0; j < kLadderChunk; ++j) x[j] = (i + j < i1) ? c.x[(i + j) * c.channels + c.ch] : 0.0f;
-}
-
 // Samples [i0, i1); output is written from `emit_from` on; when `snap` is given the state on entering
-// sample `emit_from` is stored there (i0 <= emit_from <= i1, and emit_from - i0 is a multiple of the
-// chunk or emit_from == i0... the test is per sample, so any value works).
+// sample `emit_from` is stored there (i0 <= emit_from <= i1).
 // Input is fetched a chunk ahead and output stored a chunk at a time: the recurrence is latency
 // bound, one memory round trip per sample would double its run time.
-__device__ __forceinline__ void ladder_advance(const LadderConsts &c, LadderState &s, int64_t i0, int64_t emit_from,
-                                               int64_t i1, double *snap = nullptr) {
+// STREAMS = false: scalar cutoff / resonance / drive -- the coefficient polynomials leave the sample loop (the
+// chain is one wave per SIMD, so every instruction counts, not only the dependent ones).  OS = 2: the usual
+// oversampling factor, unrolled; OS = 0: any factor.  UMODE: every lane of the wave has the same LadderMode, kept in
+// an SGPR so that the output tap is chosen by scalar branches.  Same operations in the same order either way.
+template <bool STREAMS, int OS, bool UMODE>
+__device__ __forceinline__ void ladder_advance_impl(const LadderConsts &c, LadderState &s, int64_t i0,
+                                                    int64_t emit_from, int64_t i1, double *snap, int mode_u) {
+    const int mode = UMODE ? mode_u : c.mode;
     const double state_decay = 0.95, input_threshold = 1e-5, resonance_multiplier = 1.8;
     const double two_pi = 2.0 * 3.141592653589793;
     const double min_cutoff = 5.0;
-    float xn[kLadderChunk];
-    if (i0 < i1) ladder_fetch(c, i0, i1, xn);
-    for (int64_t base = i0; base < i1; base += kLadderChunk) {
-        float xc[kLadderChunk], yc[kLadderChunk];
-#pragma unroll
-        for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
-        if (base + kLadderChunk < i1) ladder_fetch(c, base + kLadderChunk, i1, xn);
-#pragma unroll
-        for (int j = 0; j < kLadderChunk; ++j) {
-            const int64_t i = base + j;
-            yc[j] = 0.0f;
-            if (i >= i1) continue;
-            if (snap && i == emit_from) ladder_store(snap, s);
+    const int oversample = OS ? OS : c.oversample;
+    double alpha = 0.0, q_adjust = 0.0, k = 0.0, drive_scaled = 0.0;
+    auto coefficients = [&](int64_t i) {
+        double cutoff = (STREAMS && c.freq) ? (double)c.freq[i] : c.p_freq;
+        if (cutoff < min_cutoff) cutoff = min_cutoff;
+        if (cutoff > c.max_cutoff) cutoff = c.max_cutoff;
+        const double wc = cutoff * two_pi / (c.sr * (double)c.oversample);
+        const double wc2 = wc * wc;
+        const double wc3 = wc2 * wc;
+        const double wc4 = wc3 * wc;
+        alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
+        q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
+        double res = (STREAMS && c.resonance) ? (double)c.resonance[i] : c.p_res;
+        if (res < 0.0) res = 0.0;
+        if (res > 1.0) res = 1.0;
+        k = 4.0 * res * resonance_multiplier;
+        drive_scaled = ladder_drive_scale((STREAMS && c.drive) ? (double)c.drive[i] : c.p_drive, c.pbg);
+    };
+    if (!STREAMS) coefficients(0);
 
-            double cutoff = c.freq ? (double)c.freq[i] : c.p_freq;
-            if (cutoff < min_cutoff) cutoff = min_cutoff;
-            if (cutoff > c.max_cutoff) cutoff = c.max_cutoff;
-            const double wc = cutoff * two_pi / (c.sr * (double)c.oversample);
-            const double wc2 = wc * wc;
-            const double wc3 = wc2 * wc;
-            const double wc4 = wc3 * wc;
-            const double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
-            const double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
-
-            double res = c.resonance ? (double)c.resonance[i] : c.p_res;
-            if (res < 0.0) res = 0.0;
-            if (res > 1.0) res = 1.0;
-            const double k = 4.0 * res * resonance_multiplier;
-            const double drive_scaled = ladder_drive_scale(c.drive ? (double)c.drive[i] : c.p_drive, c.pbg);
-
-            const double input_sample = (double)xc[j] * drive_scaled;
-            const double input_abs = input_sample >= 0.0 ? input_sample : -input_sample;
-            if (input_abs < input_threshold) {
+    // one sample: the reference's operation order (ladder_pe.py:116-203)
+    auto sample = [&](int64_t i, float x) -> float {
+        if (STREAMS) coefficients(i);
+        const double input_sample = (double)x * drive_scaled;
+        const double input_abs = input_sample >= 0.0 ? input_sample : -input_sample;
+        if (input_abs < input_threshold) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    s.z0[q] *= state_decay;
-                    s.z1[q] *= state_decay;
+            for (int q = 0; q < 4; ++q) {
+                s.z0[q] *= state_decay;
+                s.z1[q] *= state_decay;
+            }
+            s.old_input *= state_decay;
+        }
+        double total = 0.0, interp = 0.0;
+#pragma unroll
+        for (int os = 0; os < oversample; ++os) {
+            const double in_interp = interp * s.old_input + (1.0 - interp) * input_sample;
+            const double u = pgx::pgx_tanh(in_interp - (s.z1[3] - c.pbg * in_interp) * k * q_adjust);
+            double ft, stage1, stage2, stage3, stage4, weighted;
+
+            ft = u * 0.76923077 + 0.23076923 * s.z0[0] - s.z1[0];
+            ft = ft * alpha + s.z1[0];
+            s.z1[0] = ft; s.z0[0] = u; stage1 = ft;
+
+            ft = stage1 * 0.76923077 + 0.23076923 * s.z0[1] - s.z1[1];
+            ft = ft * alpha + s.z1[1];
+            s.z1[1] = ft; s.z0[1] = stage1; stage2 = ft;
+
+            ft = stage2 * 0.76923077 + 0.23076923 * s.z0[2] - s.z1[2];
+            ft = ft * alpha + s.z1[2];
+            s.z1[2] = ft; s.z0[2] = stage2; stage3 = ft;
+
+            ft = stage3 * 0.76923077 + 0.23076923 * s.z0[3] - s.z1[3];
+            ft = ft * alpha + s.z1[3];
+            s.z1[3] = ft; s.z0[3] = stage3; stage4 = ft;
+
+            if (mode == 0) weighted = stage4;
+            else if (mode == 1) weighted = stage2;
+            else if (mode == 2) weighted = (stage2 + stage4) * 4.0 - stage3 * 8.0;
+            else if (mode == 3) weighted = (stage1 - stage2) * 2.0;
+            else if (mode == 4) weighted = u + stage4 - (stage1 + stage3) * 4.0 + stage2 * 6.0;
+            else weighted = u + stage2 - stage1 * 2.0;
+
+            total += weighted * c.oversample_recip;
+            interp += c.oversample_recip;
+        }
+        s.old_input = input_sample;
+        return (float)total;
+    };
+
+    // [a, b) in whole chunks (input fetched a chunk ahead, output stored a chunk at a time, no per-sample
+    // bounds tests) and a tail of single samples
+    auto run = [&](int64_t a, int64_t b, bool emit) {
+        int64_t base = a;
+        if (b - a >= kLadderChunk) {
+            float xn[kLadderChunk];
+#pragma unroll
+            for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + j) * c.channels + c.ch];
+            for (; base + kLadderChunk <= b; base += kLadderChunk) {
+                float xc[kLadderChunk], yc[kLadderChunk];
+#pragma unroll
+                for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
+                if (base + 2 * kLadderChunk <= b) {
+#pragma unroll
+                    for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + kLadderChunk + j) * c.channels + c.ch];
                 }
-                s.old_input *= state_decay;
-            }
-            double total = 0.0, interp = 0.0;
-            for (int os = 0; os < c.oversample; ++os) {
-                const double in_interp = interp * s.old_input + (1.0 - interp) * input_sample;
-                const double u = pgx::pgx_tanh(in_interp - (s.z1[3] - c.pbg * in_interp) * k * q_adjust);
-                double ft, stage1, stage2, stage3, stage4, weighted;
-
-                ft = u * 0.76923077 + 0.23076923 * s.z0[0] - s.z1[0];
-                ft = ft * alpha + s.z1[0];
-                s.z1[0] = ft; s.z0[0] = u; stage1 = ft;
-
-                ft = stage1 * 0.76923077 + 0.23076923 * s.z0[1] - s.z1[1];
-                ft = ft * alpha + s.z1[1];
-                s.z1[1] = ft; s.z0[1] = stage1; stage2 = ft;
-
-                ft = stage2 * 0.76923077 + 0.23076923 * s.z0[2] - s.z1[2];
-                ft = ft * alpha + s.z1[2];
-                s.z1[2] = ft; s.z0[2] = stage2; stage3 = ft;
-
-                ft = stage3 * 0.76923077 + 0.23076923 * s.z0[3] - s.z1[3];
-                ft = ft * alpha + s.z1[3];
-                s.z1[3] = ft; s.z0[3] = stage3; stage4 = ft;
-
-                if (c.mode == 0) weighted = stage4;
-                else if (c.mode == 1) weighted = stage2;
-                else if (c.mode == 2) weighted = (stage2 + stage4) * 4.0 - stage3 * 8.0;
-                else if (c.mode == 3) weighted = (stage1 - stage2) * 2.0;
-                else if (c.mode == 4) weighted = u + stage4 - (stage1 + stage3) * 4.0 + stage2 * 6.0;
-                else weighted = u + stage2 - stage1 * 2.0;
-
-                total += weighted * c.oversample_recip;
-                interp += c.oversample_recip;
-            }
-            s.old_input = input_sample;
-            yc[j] = (float)total;
-        }
 #pragma unroll
-        for (int j = 0; j < kLadderChunk; ++j) {
-            const int64_t i = base + j;
-            if (i >= emit_from && i < i1) c.o[i * c.channels + c.ch] = yc[j];
+                for (int j = 0; j < kLadderChunk; ++j) yc[j] = sample(base + j, xc[j]);
+                if (emit) {
+#pragma unroll
+                    for (int j = 0; j < kLadderChunk; ++j) c.o[(base + j) * c.channels + c.ch] = yc[j];
+                }
+            }
         }
+        for (; base < b; ++base) {
+            const float y = sample(base, c.x[base * c.channels + c.ch]);
+            if (emit) c.o[base * c.channels + c.ch] = y;
+        }
+    };
+    run(i0, emit_from, false);                                   // warm-up (nothing written)
+    if (snap) ladder_store(snap, s);                             // state on entering the first output sample
+    run(emit_from, i1, true);
+}
+
+__device__ __forceinline__ void ladder_advance(const LadderConsts &c, LadderState &s, int64_t i0, int64_t emit_from,
+                                               int64_t i1, double *snap = nullptr) {
+    const int mode_u = __builtin_amdgcn_readfirstlane(c.mode);
+    if (c.freq || c.resonance || c.drive) {                       // kernel arguments: uniform
+        ladder_advance_impl<true, 0, false>(c, s, i0, emit_from, i1, snap, 0);
+    } else if (__all(c.oversample == 2 && c.mode == mode_u)) {    // every active lane: a wave-uniform choice
+        ladder_advance_impl<false, 2, true>(c, s, i0, emit_from, i1, snap, mode_u);
+    } else {
+        ladder_advance_impl<false, 0, false>(c, s, i0, emit_from, i1, snap, 0);
     }
-    if (snap && emit_from == i1) ladder_store(snap, s);
 }
 
 __device__ __forceinline__ LadderState ladder_load(const double *st) {

@@ -7,7 +7,7 @@ from pygmu2_amd import device
 from oracle import pe_oracle as O
 
 lib = device.ensure_init()
-K, n, sr = 512, 48000, 48000.0
+K, n, sr = int(os.environ.get('PGX_ADSR_K', '512')), 48000, 48000.0
 rec = np.zeros(K, dtype=device.ADSR_PARAMS)
 a, d, r = O.adsr_slopes(0.01, 0.1, 0.7, 0.2, sr)
 rec[:] = (a, d, r, 0.7, 0)
