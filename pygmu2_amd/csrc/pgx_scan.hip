@@ -79,6 +79,24 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // sr
     return __hiloint2double(hi, lo);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_keep(double old, double v) {     // lanes without a source keep `old`
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// DPP shifts of a 2x2 map / a 2-vector; lanes without a source see the identity map / the zero vector, so a
+// scan step needs no lane test.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ M2 dpp_m2_identity(const M2 &m) {
+    return M2{dpp_f64_keep<CTRL, ROW_MASK>(1.0, m.a), dpp_f64_keep<CTRL, ROW_MASK>(0.0, m.b),
+              dpp_f64_keep<CTRL, ROW_MASK>(0.0, m.c), dpp_f64_keep<CTRL, ROW_MASK>(1.0, m.d)};
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ V2 dpp_v2_zero(const V2 &v) {
+    return V2{dpp_f64_keep<CTRL, ROW_MASK>(0.0, v.x), dpp_f64_keep<CTRL, ROW_MASK>(0.0, v.y)};
+}
+
 __device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -1073,15 +1091,18 @@ __device__ __forceinline__ V2 scan2_tile(BvShared &sh, const M2 &cm, const V2 &c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     M2 im = cm;
     V2 iv = cv;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        M2 om = shfl_up_m2(im, 1 << k);
-        V2 ov = shfl_up_v2(iv, 1 << k);
-        if (lane >= (1 << k)) {
-            iv = vadd(mv(im, ov), iv);
-            im = mm(im, om);
-        }
+    // inclusive scan of the maps over the wave on DPP (row shifts, then the row joins); (om, ov) = the map of the
+    // frames before this lane's, composed first
+#define PGX_S2_STEP(CTRL, MASK)                                   \
+    {                                                             \
+        const M2 om = dpp_m2_identity<CTRL, MASK>(im);            \
+        const V2 ov = dpp_v2_zero<CTRL, MASK>(iv);                \
+        iv = vadd(mv(im, ov), iv);                                \
+        im = mm(im, om);                                          \
     }
+    PGX_S2_STEP(0x111, 0xf) PGX_S2_STEP(0x112, 0xf) PGX_S2_STEP(0x114, 0xf) PGX_S2_STEP(0x118, 0xf)
+    PGX_S2_STEP(0x142, 0xa) PGX_S2_STEP(0x143, 0xc)
+#undef PGX_S2_STEP
     if (lane == 63) {
         sh.wm[wave] = im;
         sh.wv[wave] = iv;
@@ -1106,10 +1127,9 @@ __device__ __forceinline__ V2 scan2_tile(BvShared &sh, const M2 &cm, const V2 &c
         }
         carry = cn;
         // exclusive prefix within the wave applied to the wave carry-in
-        const M2 em = shfl_up_m2(im, 1);
-        const V2 ev = shfl_up_v2(iv, 1);
-        s = cw;
-        if (lane > 0) s = vadd(mv(em, cw), ev);
+        const M2 em = dpp_m2_identity<0x138, 0xf>(im);              // wave_shr:1
+        const V2 ev = dpp_v2_zero<0x138, 0xf>(iv);
+        s = vadd(mv(em, cw), ev);
     }
     __syncthreads();
     return s;
@@ -1605,12 +1625,6 @@ k_env_onepole(float *out, const double *det, int64_t n, int channels, double coe
     if (have_final) state[ch] = final_y;
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64_keep(double old, double v) {     // lanes without a source keep `old`
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 
 // attack != release (envelope_pe.py:259-271), time-parallel.  One sample's update
 //     e' = e + c(e) * (t - e),   c = attack if t > e else release
