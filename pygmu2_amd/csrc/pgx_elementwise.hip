@@ -121,19 +121,31 @@ __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride,
     int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
     for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
         float v[4];
-        int64_t prev_f = -1;
-        float prev_v = 0.0f;
+        // frame of element e + j without a 64-bit division per element (software on this hardware): mono is the
+        // identity, otherwise one division per thread and a running remainder
+        int64_t f = e;
+        int rem = 0;
+        if (channels != 1) {
+            f = e / channels;
+            rem = (int)(e - f * channels);
+        }
+        float cur = 0.0f;
+        bool have = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int64_t f = (e + j) / channels;
-            if (f != prev_f) {
+            if (!have) {
                 double t = (double)(start + f) / sr;
                 double ph = p.phase0 + p.w * t;
-                prev_v = (float)(p.amp * pgx::pgx_sin(ph));
-                if (has_gain) prev_v = prev_v * post_gain;
-                prev_f = f;
+                cur = (float)(p.amp * pgx::pgx_sin(ph));
+                if (has_gain) cur = cur * post_gain;
+                have = true;
             }
-            v[j] = prev_v;
+            v[j] = cur;
+            if (channels == 1 || ++rem == channels) {            // next element starts a new frame
+                rem = 0;
+                ++f;
+                have = false;
+            }
         }
         store4(o, e, n_elems, aligned, v);
     }
