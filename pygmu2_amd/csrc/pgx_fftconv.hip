@@ -52,7 +52,6 @@ __device__ __forceinline__ cplx twiddle(int64_t m, double inv_n) {
 template <int TILE>
 __device__ void lds_fft(cplx *buf, const cplx *tw, int lm, int stride) {
     const int tid = threadIdx.x;
-    const int M = 1 << lm;
     constexpr int U4 = TILE / 4 / kFBlock;                     // radix-4 butterflies per thread
     constexpr int U2 = TILE / 2 / kFBlock;                     // radix-2 butterflies per thread
     for (int lns = 0; lns < lm;) {

@@ -71,7 +71,7 @@ k_index_range(double *result, const float *delay, int64_t start, int64_t n) {
     smax[threadIdx.x] = hi;
     __syncthreads();
     for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
+        if ((int)threadIdx.x < s) {
             const double a = smin[threadIdx.x + s], b = smax[threadIdx.x + s];
             if (a != a || a < smin[threadIdx.x]) smin[threadIdx.x] = a;
             if (b != b || b > smax[threadIdx.x]) smax[threadIdx.x] = b;

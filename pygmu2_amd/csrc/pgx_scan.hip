@@ -69,9 +69,6 @@ __device__ __forceinline__ M2 m_identity() { return M2{1.0, 0.0, 0.0, 1.0}; }
 __device__ __forceinline__ V2 shfl_up_v2(const V2 &v, int d) {
     return V2{__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64)};
 }
-__device__ __forceinline__ M2 shfl_up_m2(const M2 &m, int d) {
-    return M2{__shfl_up(m.a, d, 64), __shfl_up(m.b, d, 64), __shfl_up(m.c, d, 64), __shfl_up(m.d, d, 64)};
-}
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);

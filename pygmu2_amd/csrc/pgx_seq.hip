@@ -117,8 +117,7 @@ __device__ __forceinline__ void ladder_advance_impl(const LadderConsts &c, Ladde
             s.old_input *= state_decay;
         }
         double total = 0.0, interp = 0.0;
-#pragma unroll
-        for (int os = 0; os < oversample; ++os) {
+        for (int os = 0; os < oversample; ++os) {                    // (a constant trip count when OS != 0)
             const double in_interp = interp * s.old_input + (1.0 - interp) * input_sample;
             const double u = pgx::pgx_tanh(in_interp - (s.z1[3] - c.pbg * in_interp) * k * q_adjust);
             double ft, stage1, stage2, stage3, stage4, weighted;
