@@ -216,77 +216,85 @@ __device__ __forceinline__ void adsr_step(AdsrCtx &c, const pgx_adsr_params &p, 
     c.have = false;
 }
 
-// General path for one chunk of `nvalid` samples: runs, literal steps, edges.  Inlined (a noinline
-// call would force the context through scratch memory); its call sites sit in non-unrolled loops so
-// there are only two copies of it per kernel.
-template <bool TRIG>
-__device__ __forceinline__ double adsr_chunk(AdsrCtx &cx, const pgx_adsr_params &p,
-                                                       unsigned long long amask, unsigned long long emask,
-                                                       int nvalid, long long now0, int lane) {
-    AdsrCtx c = cx;
-    double mine = 0.0;
-    int a = 0;
-    while (a < nvalid) {
-        if ((emask >> a) & 1ull) {                                 // gate edge / trigger on this sample
-            c.s = ((amask >> a) & 1ull) ? kAttack : kRelease;
-            c.have = false;
-            emask &= ~(1ull << a);
-        }
-        const unsigned long long later = emask & ~((2ull << a) - 1ull);
-        int limit = later ? (__ffsll((long long)later) - 1) : nvalid;
-        if (limit > nvalid) limit = nvalid;
-        const long long now = now0 + a;
-        if (!c.have) c.have = adsr_derive(c, p, TRIG, now);
-        if (c.have) {
-            // candidate levels of this run on the lanes; a lane is "regular" if one more step from its
-            // level is still exact.  The run extends up to the first lane that is not.
-            const int t = lane - a;
-            const double v = c.env + (double)t * c.dq;             // exact for every lane we will use
-            bool reg = (c.dir > 0) ? (v <= c.lim) : ((c.dir < 0) ? (v >= c.lim) : true);
-            if (TRIG && c.s == kSustain) reg = (now + t < c.ends_at);
-            const unsigned long long bad = __ballot(t >= 0 && t < limit - a && !reg);
-            const int take = bad ? (__ffsll((long long)bad) - 1 - a) : (limit - a);
-            if (take > 0) {
-                if (t >= 0 && t < take) mine = v;
-                c.env = c.env + (double)take * c.dq;               // exact: `take` regular steps
-                a += take;
-                if (bad) {
-                    // the sample that ended the run (no edge on it: edges sit at `limit`) takes its literal
-                    // step right here instead of costing another trip round the loop
-                    if (lane == a) mine = c.env;
-                    adsr_step(c, p, TRIG, now0 + a);
-                    a += 1;
-                }
-                continue;
-            }
-            c.have = false;
-        }
-        if (lane == a) mine = c.env;                               // literal step for one sample
-        adsr_step(c, p, TRIG, now);
-        a += 1;
+// How many consecutive samples, starting with the current one, take a regular step (>= 1 after a successful
+// adsr_derive).  Levels and increment are integer multiples of one ulp u with level/u < 2^53, so the quotient is
+// taken in float64 and repaired with one exact remainder (fma): no loop over candidates, no ballot.
+__device__ __forceinline__ int adsr_run_length(const AdsrCtx &c, bool triggered, long long now, int cap) {
+    if (c.dir == 0) {
+        if (triggered && c.s == kSustain) return (c.ends_at - now < (long long)cap) ? (int)(c.ends_at - now) : cap;
+        return cap;
     }
-    cx = c;
-    return mine;
+    const double a = (c.dir > 0) ? (c.lim - c.env) : (c.env - c.lim);      // exact, >= 0
+    const double b = fabs(c.dq);
+    double q = floor(a / b);
+    const double r = __builtin_fma(-q, b, a);                              // exact: |r| < 2b
+    if (r < 0.0) q -= 1.0;
+    else if (r >= b) q += 1.0;
+    if (q >= (double)cap) return cap;
+    return (int)q + 1;
 }
 
-// WPE = waves per envelope.  1: a bank of envelopes, one wave each.  4: a few envelopes (a rank's share of a
-// sharded mix): the four waves of a workgroup walk the SAME envelope redundantly -- the walk is scalar control
-// flow, identical in each -- and split the emitting (conversions + stores), which is what the fast path spends
-// its issue slots on: chunk k of a group is written by wave k mod 4.  No LDS, no barrier.
+// First sample >= p that carries a gate edge / trigger (or n).  The per-voice bitmap of 512-sample groups that
+// contain an edge is searched with bit operations; the eight chunk masks of the group found are fetched by eight
+// lanes at once, so an edge costs one memory round trip, not one per chunk on a dependent chain.
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int adsr_next_edge(const unsigned long long *mk, const unsigned long long *gb, int nchunks,
+                                              int gwords, int n, int p, bool &is_attack, int lane) {
+    const int ngroups = (nchunks + kGroupChunks - 1) / kGroupChunks;
+    int grp = (p >> 6) / kGroupChunks;
+    while (grp < ngroups) {
+        // next group at or after `grp` whose bit is set
+        int w = grp >> 6;
+        unsigned long long word = gb[w] & (~0ull << (grp & 63));
+        while (word == 0ull && ++w < gwords) word = gb[w];
+        if (word == 0ull) return n;
+        grp = w * 64 + (__ffsll((long long)word) - 1);
+        const int chunk = grp * kGroupChunks + lane;                       // lanes 0..7: one chunk each
+        unsigned long long am = 0ull, m = 0ull;
+        if (lane < kGroupChunks && chunk < nchunks) {
+            am = mk[(int64_t)chunk * 2];
+            m = am | mk[(int64_t)chunk * 2 + 1];
+            if (chunk == (p >> 6)) m &= ~0ull << (p & 63);
+            else if (chunk < (p >> 6)) m = 0ull;
+        }
+        const unsigned long long hit = __ballot(m != 0ull);
+        if (hit) {
+            const int src = __ffsll((long long)hit) - 1;
+            const unsigned long long mm = readlane_u64(m, src), aa = readlane_u64(am, src);
+            const int bit = __ffsll((long long)mm) - 1;
+            is_attack = ((aa >> bit) & 1ull) != 0ull;
+            const int at = (grp * kGroupChunks + src) * 64 + bit;
+            return at < n ? at : n;
+        }
+        ++grp;                                                             // its edges all lie before p
+    }
+    return n;
+}
+
+// k_adsr_walk, run by run: between two gate edges the level moves through a few dozen runs (one per binade and
+// phase), each an exact arithmetic progression whose length is known in closed form, so the walk is
+//   edge? -> derive the run -> its length -> emit `take` samples (all lanes) -> one literal step where it ends.
+// WPE = waves per envelope: 1 for a bank of envelopes; 4 for a few (a rank's share of a sharded mix): the four
+// waves of a workgroup walk the SAME envelope -- scalar control flow, identical in each -- and split the emitting.
 template <bool TRIG, int WPE>
 __global__ void __launch_bounds__(256)
 k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
             const pgx_adsr_params *params, const unsigned long long *masks, const unsigned long long *group_bits,
             const float *last_gate, double *state) {
     const int lane = threadIdx.x & 63;
-    // A dependent chain on one wave: when it shares a SIMD with throughput kernels of a forked block
+    // A dependent chain: when it shares a SIMD with throughput kernels of a forked block
     // (pgx_adsr_gated_periodic's detach_walk) it must win instruction arbitration, or it is the
     // block's critical path at a third of its speed.
     __builtin_amdgcn_s_setprio(3);
     // readfirstlane makes the indices provably wave-uniform (scalar loads)
     const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int inst = (WPE == 1) ? blockIdx.x * 4 + wave_id : blockIdx.x;
-    const int sub = (WPE == 1) ? 0 : wave_id;                    // which share of the chunks this wave writes
+    const int sub = (WPE == 1) ? 0 : wave_id;                    // which share of the samples this wave writes
     if (inst >= batch) return;
     const pgx_adsr_params p = params[inst];
     float *o = out + (int64_t)inst * out_stride;
@@ -304,90 +312,46 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
     c.lim = 0.0;
     if (WPE > 1) __syncthreads();           // every wave has read the state before wave 0 may overwrite it
 
-    // The walk is a dependent chain on a single wave, so nothing on the common path may wait for
-    // memory: "does group i contain an edge" is one bit of a per-voice bitmap, 64 groups (32 768
-    // samples) per word, fetched one word ahead.
-    const int64_t full_groups = n / (64 * kGroupChunks);
-    unsigned long long word = (full_groups > 0) ? gb[0] : 0ull, word_next = 0ull;
-    for (int64_t grp = 0; grp < full_groups; ++grp) {
-        if ((grp & 63) == 0) {
-            if (grp > 0) word = word_next;
-            if (((grp >> 6) + 1) < gwords) word_next = gb[(grp >> 6) + 1];
+    // positions inside the block are 32-bit (the entry points refuse longer blocks): 64-bit integer arithmetic and
+    // int64 <-> float64 conversions are multi-instruction sequences here, and this loop is instruction-bound
+    const int n32 = (int)n, nch32 = (int)nchunks, gw32 = (int)gwords;
+    bool edge_attack = false;
+    int next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, 0, edge_attack, lane);
+    int pos = 0;
+    while (pos < n32) {
+        if (pos == next_edge) {                                   // gate edge / trigger on this sample
+            c.s = edge_attack ? kAttack : kRelease;
+            c.have = false;
+            next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, pos + 1, edge_attack, lane);
         }
-        const int64_t ch = grp * kGroupChunks;
-        const int64_t base = ch * 64;
-        const bool has_edge = ((word >> (grp & 63)) & 1ull) != 0ull;
-        if (!has_edge) {
-            if (!c.have) c.have = adsr_derive(c, p, TRIG, (long long)(start + base));
-            if (c.have) {
-                // 512 samples stay inside the run iff the 512th level is still regular (monotone)
-                const double vlast = c.env + (double)(64 * kGroupChunks - 1) * c.dq;
-                bool ok = (c.dir > 0) ? (vlast <= c.lim) : ((c.dir < 0) ? (vlast >= c.lim) : true);
-                if (TRIG && c.s == kSustain) ok = ((long long)(start + base) + 64 * kGroupChunks - 1 < c.ends_at);
-                if (ok) {
-                    const double env = c.env, dq = c.dq;
-#pragma unroll
-                    for (int k = 0; k < kGroupChunks; ++k)
-                        if (WPE == 1 || (k & (WPE - 1)) == sub)
-                            o[base + k * 64 + lane] = (float)(env + (double)(k * 64 + lane) * dq);    // exact
-                    c.env = env + (double)(64 * kGroupChunks) * dq;
-                    continue;
+        const long long now = (long long)start + pos;
+        if (!c.have) c.have = adsr_derive(c, p, TRIG, now);
+        if (c.have) {
+            const int room = next_edge - pos;                     // >= 1: the run may reach up to the next edge
+            const int cnt = adsr_run_length(c, TRIG, now, room + 1);
+            const int take = cnt < room ? cnt : room;
+            const double env = c.env, dq = c.dq;
+            float *dst = o + pos;
+            for (int t = sub * 64 + lane; t < take; t += 64 * WPE)
+                dst[t] = (float)(env + (double)t * dq);            // exact progression
+            c.env = env + (double)take * dq;                       // exact: `take` regular steps
+            pos += take;
+            if (cnt <= room) {
+                // the run ended by itself (not at an edge): its next sample takes a literal step -- unless that
+                // sample is an edge, whose state change comes first
+                if (pos < n32 && pos != next_edge) {
+                    if (sub == 0 && lane == 0) o[pos] = (float)c.env;
+                    adsr_step(c, p, TRIG, (long long)start + pos);
+                    pos += 1;
+                } else {
+                    c.have = false;
                 }
             }
+            continue;
         }
-        // general path: fetch the group's 16 masks together (one latency), then walk its chunks
-        unsigned long long am[kGroupChunks], rm[kGroupChunks];
-#pragma unroll
-        for (int k = 0; k < kGroupChunks; ++k) am[k] = rm[k] = 0ull;
-        if (has_edge) {                       // groups that are slow only because a run ends have no edges
-#pragma unroll
-            for (int k = 0; k < kGroupChunks; ++k) {
-                am[k] = mk[(ch + k) * 2];
-                rm[k] = mk[(ch + k) * 2 + 1];
-            }
-        }
-#pragma unroll 1
-        for (int k = 0; k < kGroupChunks; ++k) {
-            // pick chunk k's masks with selects (a dynamically indexed register array would go to scratch);
-            // a group that is slow only because a run ends in it has none to pick
-            unsigned long long amk = 0ull, rmk = 0ull;
-            if (has_edge) {
-                amk = am[0];
-                rmk = rm[0];
-#pragma unroll
-                for (int j = 1; j < kGroupChunks; ++j) {
-                    amk = (k == j) ? am[j] : amk;
-                    rmk = (k == j) ? rm[j] : rmk;
-                }
-            }
-            const int64_t i0 = (ch + k) * 64;
-            if ((amk | rmk) == 0ull) {
-                // no edge in this chunk: the group was slow because a run ends somewhere in it -- most of
-                // its chunks still are plain 64-sample pieces of a run
-                if (!c.have) c.have = adsr_derive(c, p, TRIG, (long long)(start + i0));
-                if (c.have) {
-                    const double vlast = c.env + 63.0 * c.dq;
-                    bool ok = (c.dir > 0) ? (vlast <= c.lim) : ((c.dir < 0) ? (vlast >= c.lim) : true);
-                    if (TRIG && c.s == kSustain) ok = ((long long)(start + i0) + 63 < c.ends_at);
-                    if (ok) {
-                        if (WPE == 1 || (k & (WPE - 1)) == sub)
-                            o[i0 + lane] = (float)(c.env + (double)lane * c.dq);   // exact
-                        c.env = c.env + 64.0 * c.dq;
-                        continue;
-                    }
-                }
-            }
-            const double mine = adsr_chunk<TRIG>(c, p, amk, amk | rmk, 64, (long long)(start + i0), lane);
-            if (WPE == 1 || (k & (WPE - 1)) == sub) o[i0 + lane] = (float)mine;
-        }
-    }
-#pragma unroll 1
-    for (int64_t ch = full_groups * kGroupChunks; ch < nchunks; ++ch) {     // tail (last chunk may be partial)
-        const unsigned long long am = mk[ch * 2], rm = mk[ch * 2 + 1];
-        const int64_t i0 = ch * 64;
-        const int nvalid = (n - i0 < 64) ? (int)(n - i0) : 64;
-        const double mine = adsr_chunk<TRIG>(c, p, am, am | rm, nvalid, (long long)(start + i0), lane);
-        if (lane < nvalid && (WPE == 1 || (int)(ch & (WPE - 1)) == sub)) o[i0 + lane] = (float)mine;
+        if (sub == 0 && lane == 0) o[pos] = (float)c.env;          // literal step for one sample
+        adsr_step(c, p, TRIG, now);
+        pos += 1;
     }
     if (lane == 0 && sub == 0) {
         st[0] = (double)c.s;
@@ -462,6 +426,7 @@ int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t ga
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && gate && params && state && workspace, "pgx_adsr_gated: null pointer");
+    PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_gated: block too long");
     PGX_CHECK_ARG(batch == 1 || (out_stride >= n && gate_stride >= n), "pgx_adsr_gated: stride too small");
     return adsr_launch<0>(out, out_stride, gate, gate_stride, batch, 0, n, nullptr, params, state, workspace);
 }
@@ -472,6 +437,7 @@ int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t s
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && gates && params && state && workspace, "pgx_adsr_gated_periodic: null pointer");
+    PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_gated_periodic: block too long");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_adsr_gated_periodic: stride too small");
     return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, state, workspace,
                           detach_walk != 0);
@@ -482,6 +448,7 @@ int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && trig && params && state && workspace, "pgx_adsr_triggered: null pointer");
+    PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_triggered: block too long");
     PGX_CHECK_ARG(batch == 1 || (out_stride >= n && trig_stride >= n), "pgx_adsr_triggered: stride too small");
     return adsr_launch<1>(out, out_stride, trig, trig_stride, batch, start, n, nullptr, params, state, workspace);
 }
