@@ -11,17 +11,18 @@
 // env = E*u and |d| = (D + r)*u with integer E, D and 0 <= r < 1 (all exact power-of-two
 // scalings), round-to-nearest gives E' = E +/- Dq, Dq = D + [r > 1/2], as long as no tie
 // (r == 1/2) occurs and the sum does not leave the binade.  Inside such a "run" the level is the
-// exact progression env_t = env_0 + t*dq (dq = +/-Dq*u, every term representable), so 64 lanes
-// emit 64 consecutive samples at once, and "how long does the run last" is answered by comparing
-// the candidate levels with the last regular level (one ballot) -- no division anywhere.
+// exact progression env_t = env_0 + t*dq (dq = +/-Dq*u, every term representable), so the lanes
+// emit consecutive samples at once, and "how long does the run last" is (last regular level -
+// level) / dq: integers in units of u, divided in float64 and repaired with an exact remainder.
 // Binade crossings, ties, clamp crossings (>= 1, <= sustain, <= 0), zero levels and gate edges
 // take ONE literal reference step.  An ADSR cycle is a few dozen runs.
 //
 // Two kernels per render:
 //   k_adsr_edges  fully parallel over (voice, 64-sample chunk): evaluates / loads the control
-//                 stream and reduces it to two 64-bit edge masks per chunk (attack, release);
-//   k_adsr_walk   one wave per envelope walks its chunks: scalar mask loads, a 512-sample fast
-//                 path (one compare), coalesced float32 stores.
+//                 stream and reduces it to two 64-bit edge masks per chunk (attack, release) and a
+//                 per-voice bitmap of the 512-sample groups that contain an edge;
+//   k_adsr_walk   per envelope, run by run: next edge, derive the run, its length in closed form,
+//                 emit it with all lanes (coalesced float32 stores), one literal step where it ends.
 
 #include "pgx_common.h"
 
