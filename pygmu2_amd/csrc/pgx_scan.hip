@@ -1132,13 +1132,19 @@ __device__ __forceinline__ V2 scan2_tile(BvShared &sh, const M2 &cm, const V2 &c
     return s;
 }
 
-// carried state on entering segment `seg`: the maps of the earlier segments applied in order
+// carried state on entering segment `seg`: the maps of the earlier segments applied in order.  The maps are staged
+// through LDS with one coalesced load first: read one by one from HBM on the dependent chain, 43 of them cost
+// 10 us -- more than the segment itself.
 __device__ __forceinline__ V2 scan2_fold(const double *agg, int seg, V2 s) {
+    __shared__ double maps[kS2MaxSeg * 6];
+    for (int i = threadIdx.x; i < seg * 6; i += kBlock) maps[i] = agg[i];
+    __syncthreads();
     for (int j = 0; j < seg; ++j) {
-        const double *a = agg + (int64_t)j * 6;
+        const double *a = maps + j * 6;
         const M2 m{a[0], a[1], a[2], a[3]};
         s = vadd(mv(m, s), V2{a[4], a[5]});
     }
+    __syncthreads();
     return s;
 }
 
@@ -1148,10 +1154,12 @@ __device__ __forceinline__ void rbj(int mode, double f, double q, double A, doub
     const double nyq99 = (sr / 2.0) * 0.99;
     f = f < 1.0 ? 1.0 : (f > nyq99 ? nyq99 : f);              // np.clip(freq, 1.0, nyquist*0.99)
     q = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
-    double omega = ((2.0 * kPi) * f) / sr;
+    // Divisions: a Newton-refined reciprocal (<= 1 ulp) instead of the correctly rounded IEEE sequence -- seven of
+    // those were 40 % of this kernel's instructions, and the coefficients feed a result held to 1e-5
+    double omega = pgx::pgx_div_fast((2.0 * kPi) * f, sr);
     double sn, cs;
     pgx::pgx_sincos(omega, sn, cs);
-    double alpha = sn / (2.0 * q);
+    double alpha = pgx::pgx_div_fast(sn, 2.0 * q);
     double a0;
     switch (mode) {
     case 0:
@@ -1176,7 +1184,7 @@ __device__ __forceinline__ void rbj(int mode, double f, double q, double A, doub
         break;
     case 5:
         b0 = 1.0 + alpha * A; b1 = -2.0 * cs; b2 = 1.0 - alpha * A;
-        a0 = 1.0 + alpha / A; a1 = -2.0 * cs; a2 = 1.0 - alpha / A;
+        a0 = 1.0 + pgx::pgx_div_fast(alpha, A); a1 = -2.0 * cs; a2 = 1.0 - pgx::pgx_div_fast(alpha, A);
         break;
     case 6:
         b0 = A * (((A + 1.0) - (A - 1.0) * cs) + (2.0 * sqrtA) * alpha);
@@ -1195,7 +1203,8 @@ __device__ __forceinline__ void rbj(int mode, double f, double q, double A, doub
         a2 = ((A + 1.0) - (A - 1.0) * cs) - (2.0 * sqrtA) * alpha;
         break;
     }
-    b0 = b0 / a0; b1 = b1 / a0; b2 = b2 / a0; a1 = a1 / a0; a2 = a2 / a0;
+    const double inv_a0 = pgx::pgx_div_fast(1.0, a0);
+    b0 = b0 * inv_a0; b1 = b1 * inv_a0; b2 = b2 * inv_a0; a1 = a1 * inv_a0; a2 = a2 * inv_a0;
 }
 
 // State map per sample: (y1,y2) -> (y0,y1) with
@@ -1359,29 +1368,29 @@ struct SvCoef {
 
 // svfilter_pe.py:120-205, per-sample scalar arithmetic in the reference's order.
 __device__ __forceinline__ SvCoef svf_coef(int mode, double freq, double q, double a_lin, double sr) {
-    double f_norm = freq / sr;
+    double f_norm = pgx::pgx_div_fast(freq, sr);        // (divisions: see rbj)
     if (f_norm < 1e-6) f_norm = 1e-6;
     if (f_norm > 0.5) f_norm = 0.5;
     double res;
     if (mode == 4) {                                   // peaking ("bell")
         double qc = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
-        const double k_bell = 1.0 / (qc * a_lin);
+        const double k_bell = pgx::pgx_div_fast(1.0, qc * a_lin);
         res = 1.0 - 0.5 * k_bell;
     } else {
         double qc = q < 0.01 ? 0.01 : (q > 100.0 ? 100.0 : q);
-        res = 1.0 - 0.5 / qc;
+        res = 1.0 - pgx::pgx_div_fast(0.5, qc);
     }
     if (res < 0.0) res = 0.0;
     if (res > 0.999) res = 0.999;
     const double k = 2.0 - 2.0 * res;
     double sn, cs;
     pgx::pgx_sincos(kPi * f_norm, sn, cs);
-    double g = sn / cs;                                // tan(pi * f_norm)
+    double g = pgx::pgx_div_fast(sn, cs);              // tan(pi * f_norm)
     double shelf_a = 1.0;
     if (mode == 5) shelf_a = 1.0 / sqrt(a_lin);
     else if (mode == 6) shelf_a = sqrt(a_lin);
     g = g * shelf_a;
-    const double a1 = 1.0 / (1.0 + g * (g + k));
+    const double a1 = pgx::pgx_div_fast(1.0, 1.0 + g * (g + k));
     const double a2 = g * a1;
     const double a3 = g * a2;
     SvCoef c;
