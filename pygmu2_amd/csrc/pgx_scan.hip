@@ -1706,6 +1706,7 @@ k_env_newton(float *out, const float *in, const double *det, int64_t n, int chan
         const int64_t f0 = base + (int64_t)tid * T;
         const int live = (n - f0 >= T) ? T : (n - f0 > 0 ? (int)(n - f0) : 0);
         const bool has_next = base + kWindow < n;
+        const bool full = base + kWindow <= n;
         if (has_next) fetch(base + kWindow);                               // next window, in flight
 
         // Two barriers per round (pieces, then the "an entry level moved" flags); LDS is double-buffered by round
@@ -1714,19 +1715,28 @@ k_env_newton(float *out, const float *in, const double *det, int64_t n, int chan
         double y[T];
         for (int round = 0; round <= NW * 64 + 1; ++round) {
             double e = entry;
-            int attacks = 0, releases = 0;
+            int attacks = 0;
+            if (full) {                                  // every thread owns T live samples: no per-sample guard
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const bool on = j < live;
-                const bool attack = t[j] > e;
-                const double stepped = e + (attack ? attack_coeff : release_coeff) * (t[j] - e);
-                attacks += (on && attack) ? 1 : 0;
-                releases += (on && !attack) ? 1 : 0;
-                e = on ? stepped : e;
-                y[j] = e;
+                for (int j = 0; j < T; ++j) {
+                    const bool attack = t[j] > e;
+                    e = e + (attack ? attack_coeff : release_coeff) * (t[j] - e);
+                    attacks += attack ? 1 : 0;
+                    y[j] = e;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const bool on = j < live;
+                    const bool attack = t[j] > e;
+                    const double stepped = e + (attack ? attack_coeff : release_coeff) * (t[j] - e);
+                    attacks += (on && attack) ? 1 : 0;
+                    e = on ? stepped : e;
+                    y[j] = e;
+                }
             }
             // the affine piece this thread passed through: slope from the regime counts, offset from the exit
-            double a = s_pa[attacks] * s_pr[releases];
+            double a = s_pa[attacks] * s_pr[live - attacks];
             double b = __builtin_fma(-a, entry, e);
             // inclusive scan of the pieces over the wave (lanes without a source see the identity)
 #define PGX_ENV_STEP(CTRL, MASK)                                            \
