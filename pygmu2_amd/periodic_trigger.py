@@ -19,13 +19,12 @@ class PeriodicTrigger(TriggerSignal):
     def __init__(self, hz: float, phase: float = 0.0, amplitude: int = 1):
         if hz <= 0:
             raise ValueError("PeriodicTrigger hz must be > 0")
-        self._hz = float(hz)
-        self._phase = float(phase) % 1.0
-        self._amp = int(amplitude)
-        self._period = int(round(get_sample_rate() / self._hz))
-        if self._period <= 0:
+        rate, cycle = float(hz), float(phase) % 1.0
+        period = int(round(get_sample_rate() / rate))                 # samples between two events
+        if period <= 0:
             raise ValueError("PeriodicTrigger computed period <= 0; check sample rate / hz")
-        self._phase_samples = int(round(self._phase * self._period))
+        self._hz, self._phase, self._amp, self._period = rate, cycle, int(amplitude), period
+        self._phase_samples = int(round(cycle * period))              # the kernel fires where (n + this) % period == 0
 
     def inputs(self) -> list[ProcessingElement]:
         return []
