@@ -215,6 +215,49 @@ def bench_c1(pg, dist, steps, warmup):
     return dt, total
 
 
+def hello_sine_case(pg):
+    """examples/01_hello_sine.py:41-56, what BASELINE's config 0 cites: a C-major triad of three SinePEs
+    (amplitude 0.3) -> MixPE -> GainPE(0.3) -> CropPE(8 s), pulled in 1024-frame blocks at 44.1 kHz."""
+    pg.set_sample_rate(44100)
+    total = 8 * 44100
+    triad = [pg.SinePE(frequency=440.0 * 2.0 ** ((p - 69) / 12.0), amplitude=0.3) for p in (60, 64, 67)]
+    root = pg.CropPE(pg.GainPE(pg.MixPE(*triad), gain=0.3), 0, total)
+    r = pg.NullRenderer(sample_rate=44100)
+    r.set_source(root)
+    r.start()
+    from pygmu2_amd import device
+    best = 0.0
+    for rep in range(4):
+        device.synchronize()
+        t0 = time.perf_counter()
+        pos = 0
+        while pos < total:
+            n = min(1024, total - pos)
+            keep = root.render(pos, n)
+            pos += n
+        device.synchronize()
+        if rep:
+            best = max(best, total / (time.perf_counter() - t0) / 1e6)
+    r.stop()
+    return round(best, 3)
+
+
+def cpu_hello_sine(budget_s=4.0):
+    from oracle import pe_oracle as O
+    total, t_all, reps = 8 * 44100, 0.0, 0
+    freqs = [440.0 * 2.0 ** ((p - 69) / 12.0) for p in (60, 64, 67)]
+    while t_all < budget_s and reps < 50:
+        t0 = time.perf_counter()
+        pos = 0
+        while pos < total:
+            n = min(1024, total - pos)
+            O.gain_const(O.mix([O.sine_pure(pos, n, f, 0.3, 0.0, 44100, 1) for f in freqs]), 0.3)
+            pos += n
+        t_all += time.perf_counter() - t0
+        reps += 1
+    return round(total * reps / t_all / 1e6, 3)
+
+
 def cpu_c1(budget_s=5.0):
     from oracle import pe_oracle as O
     total, t_all, reps = 441_000, 0.0, 0
@@ -457,6 +500,7 @@ def main():
         if args.workload == "c2" and n_gpus == 1:
             dt1, f1 = bench_c1(pg, Dist(1), 5, 1)
             cases["c1_sine_gain_1024_blocks"] = {"value": round(f1 * 5 / dt1 / 1e6, 3), "unit": "Msamples/s"}
+            cases["c1_hello_sine_example_1024_blocks"] = {"value": hello_sine_case(pg), "unit": "Msamples/s"}
             dt3, f3 = bench_c3(pg, Dist(1), 10, 2)
             cases["c3_convolve_64k_taps"] = {"value": round(f3 * 10 / dt3 / 1e6, 3), "unit": "Msamples/s",
                                              "path": "float64 FFT overlap-save (pgx_convolve_fft)",
@@ -479,6 +523,7 @@ def main():
                 cases["autowah_biquad_1024_blocks"]["cpu_oracle_msamples_s"] = cpu_autowah("biquad")
             if "c1_sine_gain_1024_blocks" in cases:
                 cases["c1_sine_gain_1024_blocks"]["cpu_oracle_msamples_s"] = cpu_c1()
+                cases["c1_hello_sine_example_1024_blocks"]["cpu_oracle_msamples_s"] = cpu_hello_sine()
             if "c3_convolve_64k_taps" in cases:
                 cases["c3_convolve_64k_taps"]["cpu_oracle_msamples_s"] = cpu_c3()
         if cases:
