@@ -9,13 +9,14 @@
 // What makes it parallel anyway: while the level stays inside one binade [2^e, 2^(e+1)) every
 // addition of the constant slope d rounds to the same grid of spacing u = 2^(e-52).  Writing
 // env = E*u and |d| = (D + r)*u with integer E, D and 0 <= r < 1 (all exact power-of-two
-// scalings), round-to-nearest gives E' = E +/- Dq, Dq = D + [r > 1/2], as long as no tie
-// (r == 1/2) occurs and the sum does not leave the binade.  Inside such a "run" the level is the
+// scalings), round-to-nearest gives E' = E +/- Dq, Dq = D + [r > 1/2], as long as the sum does
+// not leave the binade; in the one binade where r == 1/2 (a tie on every step) round-half-even
+// moves an even E by the even one of D, D + 1.  Inside such a "run" the level is the
 // exact progression env_t = env_0 + t*dq (dq = +/-Dq*u, every term representable), so the lanes
 // emit consecutive samples at once, and "how long does the run last" is (last regular level -
 // level) / dq: integers in units of u, divided in float64 and repaired with an exact remainder.
-// Binade crossings, ties, clamp crossings (>= 1, <= sustain, <= 0), zero levels and gate edges
-// take ONE literal reference step.  An ADSR cycle is a few dozen runs.
+// Binade crossings, odd levels in a tie binade, clamp crossings (>= 1, <= sustain, <= 0), zero
+// levels and gate edges take ONE literal reference step.  An ADSR cycle is a few dozen runs.
 //
 // Two kernels per render:
 //   k_adsr_edges  fully parallel over (voice, 64-sample chunk): evaluates / loads the control
@@ -164,8 +165,18 @@ __device__ __forceinline__ bool adsr_derive(AdsrCtx &c, const pgx_adsr_params &p
     if (!(q < kTwo53)) return false;                               // |d| >= 2^(e+1): leaves the binade
     const double D = floor(q);
     const double r = q - D;
-    if (r == 0.5) return false;                                    // tie: round-half-even
-    const double Dq = D + (r > 0.5 ? 1.0 : 0.0);
+    double Dq;
+    if (r == 0.5) {
+        // Tie binade (the slope's lowest set bit sits exactly half an ulp down: every slope has one such binade,
+        // and a release spends e.g. 27 samples in it).  Round-half-even makes this regular too: from an EVEN level
+        // E the step lands on the even one of E -+ D, E -+ (D + 1), i.e. moves by D if D is even and by D + 1 if
+        // it is odd -- and lands on an even level again.  From an odd level one literal step gets there.
+        if (__double2loint(env) & 1) return false;                 // E = env / u is odd (lowest mantissa bit)
+        const double half = D * 0.5;
+        Dq = (floor(half) == half) ? D : D + 1.0;
+    } else {
+        Dq = D + (r > 0.5 ? 1.0 : 0.0);
+    }
     if (Dq == 0.0) {                                               // |d| < u/2: the level cannot move
         return !(c.s == kDecay && env <= p.sustain_level);
     }
