@@ -426,10 +426,12 @@ LadderPlan ladder_plan(int batch, int64_t n, int channels, int64_t settle) {
     LadderPlan p{false, n, 1};
     if (settle <= 0) return p;
     const int64_t chains = (int64_t)batch * channels;
-    int64_t seg_len = settle / 8 > 64 ? settle / 8 : 64;          // run time ~ settle + seg_len
-    const int64_t lane_budget = 1 << 18;                          // ~4 waves on every SIMD
-    const int64_t floor_len = pgx::ceil_div(n * chains, lane_budget);
-    if (seg_len < floor_len) seg_len = floor_len;
+    // A lane's run time ~ settle + seg_len, so short segments are good -- until there are more than two waves per
+    // CU: measured on C4 (64 chains x 48 000 frames, settle 1024), ms per block by lane count: 8 Ki 0.66, 16 Ki
+    // 0.58, 24 Ki 0.56, 32 Ki 0.555, 48 Ki 0.78, 64 Ki 0.83 (the unrolled sample loop is ~40 KB of code: more waves
+    // per CU at different places in it fall out of the instruction cache).  Never shorter than 32 samples.
+    int64_t seg_len = pgx::ceil_div(n * chains, (int64_t)32768);
+    if (seg_len < 32) seg_len = 32;
     if (n < 2 * (settle + seg_len)) return p;                     // nothing to win
     p.segmented = true;
     p.seg_len = seg_len;
