@@ -2,27 +2,33 @@
 """
 bench.py -- throughput of the MI355X render path on the BASELINE.json configurations.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4|c5|supersaw]
 
-Prints ONE JSON line (rank 0).  Metric: Msamples/s = output frames rendered per wall second
-x 1e-6, the metric of the reference's benchmarks/benchmark_pes.py:62-66.
+Prints ONE JSON line (rank 0).  Metric: Msamples/s = output frames rendered per wall second x 1e-6, the
+metric of the reference's benchmarks/benchmark_pes.py:62-66.
 
-Primary workload (BASELINE.json configs[1], "C2"): BiquadPE(SinePE(440), 1000 Hz, q .707,
-LOWPASS), 44.1 kHz mono, one step = one contiguous render(start, 1_000_000) through the
-public PE API on a started NullRenderer graph, inputs generated on the device (SinePE),
-outputs left in HBM.  K steps are timed between barrier+synchronize pairs.
-With --gpus N > 1 every rank renders its own replica of the chain (a single biquad chain is
-one sequence: "replicas only"); the sharded 512-voice mix with its RCCL reduction is
-reported alongside in the `voice_mix` object (strong scaling).
+Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process only spawns N fresh
+rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per GPU), relays rank 0's
+JSON line and exits non-zero if any rank did; it never touches the GPU itself.  Under a launcher that
+already set WORLD_SIZE (python -m torch.distributed.run ...) the process is one rank.  Ranks meet through
+the launcher's c10d store (128-byte communicator id), then talk RCCL through the library's own entry points
+(pgx_comm_init / pgx_allreduce_sum); the barrier and the max-over-ranks of the timed region are scalar
+all-reduces on the same communicator.  `--dry-run` exercises exactly this glue on CPU-only hosts (no
+library call, no measurement): every rank reports through the store and the line carries n_gpus /
+n_ranks_seen / the shard sizes.
 
-Extra objects in the same JSON line:
-  roofline      dominant kernel pair of C2 (k_biquad_const reduce+apply), algorithmic bytes
-                8 B/frame, timed live with HIP events on the library stream
-  roofline_scaled  the same entry point on 2^26 frames (past launch-latency / cache effects)
-  cpu_baseline  the CPU oracle (numpy sin + scipy lfilter, i.e. the reference's own
-                primitives in the reference's order) on the same workload, 1 thread
-  cases         other BASELINE configs measured in the same run (C1 sine->gain blocks,
-                C3 convolution) with their own CPU-oracle timings
+Primary workload (BASELINE.json configs[1], "C2"): BiquadPE(SinePE(440), 1000 Hz, q .707, LOWPASS), 44.1 kHz
+mono, one step = one contiguous render(start, 1_000_000) through the public PE API on a started
+NullRenderer graph, inputs generated on the device, outputs left in HBM.  With --gpus N every rank renders
+its own replica of the chain (a single biquad chain is one sequence: "replicas only").  The workloads that
+shard (c4, c5, supersaw: inputs of the root MixPE dealt i mod N over the ranks, one RCCL all-reduce of the
+partial mix per block) are selected with --workload and are reported inside the default line as well.
+
+Extra objects in the default line (rank 0, N = 1): roofline / roofline_scaled (the C2 filter kernel, HIP
+events), cpu_baseline (the CPU oracle on this host, 1 thread, host core count stated), value_with_d2h
+(the same C2 steps with every root Snippet read on the host: pinned buffer, async copy overlapped with the
+next step -- and with a sync per step), cases (the other BASELINE configs, each with its CPU figure), suite
+(benchmark_pes.py's own protocol: 44 100-frame renders, 5 + 50, sync and pipelined, CPU beside).
 """
 
 from __future__ import annotations
@@ -30,6 +36,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,67 +48,178 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+SHARDED = ("c4", "c5", "supersaw")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "supersaw"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle timings")
     ap.add_argument("--no-extras", action="store_true", help="primary workload only")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch glue only (CPU host): ranks rendezvous and report, nothing is rendered")
+    return ap.parse_args(argv)
 
 
-# ----------------------------------------------------------------------------- distributed glue
+# ----------------------------------------------------------------------------- launching N ranks
+def spawn_ranks(n: int) -> int:
+    """Parent of a `--gpus N` run: N child ranks of this same command line; relay rank 0's stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGX_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+    out0 = procs[0].stdout
+    failed = 0
+    try:
+        for line in iter(out0.readline, b""):            # rank 0's JSON line (and nothing else) goes to stdout
+            sys.stdout.write(line.decode("utf-8", "replace"))
+            sys.stdout.flush()
+        deadline = time.time() + 600
+        for p in procs:
+            try:
+                rc = p.wait(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                rc = -9
+            failed = failed or rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return 1 if failed else 0
+
+
+# ----------------------------------------------------------------------------- the ranks' control plane
 class Dist:
-    def __init__(self, n_gpus):
+    """World / rank from the launcher's environment.  world > 1: the c10d store the launcher provides
+    carries the communicator id (and, in a dry run, the whole report); RCCL carries everything else."""
+
+    def __init__(self, dry_run=False):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.enabled = self.world > 1
-        self.torch = None
+        self.dry_run = dry_run
+        self.store = None
+        self._barriers = 0
         if self.enabled:
-            import torch
-            import torch.distributed as dist
-            self.torch, self.dist = torch, dist
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend="nccl")      # RCCL on ROCm
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            from torch.distributed import rendezvous
+            self.store, _, _ = next(rendezvous("env://", rank=self.rank, world_size=self.world))
+
+    def connect(self):
+        """After device init: build the RCCL communicator (every rank).  Returns the ranks seen by an
+        all-reduce of ones on it."""
+        if not self.enabled:
+            return 1
+        if self.dry_run:
+            return int(self._store_sum("ranks_seen", 1))
+        from pygmu2_amd import comm
+        if self.rank == 0:
+            self.store.set("pgx_comm_id", comm.unique_id())
+        ident = self.store.get("pgx_comm_id")
+        comm.init(self.rank, self.world, bytes(ident))
+        return int(round(comm.reduce_scalar(1.0, "sum")))
+
+    def _store_sum(self, key, value):
+        self.store.add(key, int(value))
+        self.store.add(key + "_n", 1)
+        t0 = time.time()
+        while int(self.store.add(key + "_n", 0)) < self.world:
+            if time.time() - t0 > 300:
+                raise RuntimeError(f"rank {self.rank}: peers never arrived at {key}")
+            time.sleep(0.002)
+        return int(self.store.add(key, 0))
 
     def barrier(self):
-        if self.enabled:
-            self.dist.barrier()
+        if not self.enabled:
+            return
+        if self.dry_run:
+            self._barriers += 1
+            self._store_sum(f"barrier{self._barriers}", 0)
+            return
+        from pygmu2_amd import comm
+        comm.reduce_scalar(0.0, "sum")
 
     def max_over_ranks(self, value: float) -> float:
-        if not self.enabled:
+        if not self.enabled or self.dry_run:
             return value
-        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        from pygmu2_amd import comm
+        return comm.reduce_scalar(value, "max")
 
     def shutdown(self):
-        if self.enabled:
-            self.dist.destroy_process_group()
+        if not self.enabled:
+            return
+        if not self.dry_run:
+            from pygmu2_amd import comm
+            self.barrier()
+            comm.destroy()
+        # rank 0 may be hosting the store (bench.py's own spawner): it leaves last
+        if self.rank != 0:
+            self.store.add("pgx_done", 1)
+            return
+        t0 = time.time()
+        while int(self.store.add("pgx_done", 0)) < self.world - 1 and time.time() - t0 < 60:
+            time.sleep(0.005)
 
 
-def timed_steps(dist: Dist, step, steps: int, warmup: int):
+class _Solo:
+    """The rank-local stand-in used for the N = 1 side measurements of a default run."""
+    world, rank, enabled = 1, 0, False
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, v):
+        return v
+
+
+def timed_steps(dist, step, steps: int, warmup: int, finish=None):
     """W untimed + K timed calls of step(i); barrier + device sync on both sides; max over ranks."""
     from pygmu2_amd import device
     for i in range(warmup):
         step(i)
+    if finish:
+        finish()
     device.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
+    if finish:
+        finish()
     device.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
     return dist.max_over_ranks(dt)
 
 
-# ----------------------------------------------------------------------------- workloads
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"host_cores": os.cpu_count() or usable, "host_cores_usable": usable, "host_cpu": model}
+
+
+# ----------------------------------------------------------------------------- C2
 def c2_graph(pg):
     pg.set_sample_rate(44100)
     pe = pg.BiquadPE(pg.SinePE(frequency=440.0), frequency=1000.0, q=0.707, mode=pg.BiquadMode.LOWPASS)
@@ -122,6 +241,42 @@ def bench_c2(pg, dist, steps, warmup, frames=1_000_000):
     return dt, frames
 
 
+def bench_c2_with_d2h(pg, steps, warmup, frames=1_000_000):
+    """The same steps with the root Snippet handed to the caller as host data every step, as the reference's
+    loop does (benchmarks/benchmark_pes.py:176-185; SURVEY 8d "GPU timings include the final D2H of the root
+    Snippet and a stream sync").  pipelined: block k crosses PCIe (pinned buffer, copy stream) while block
+    k+1 renders, the caller reads k after issuing k+1; sync: render, copy, wait, every step."""
+    from pygmu2_amd import device
+    out = {}
+    for mode in ("pipelined", "sync"):
+        pe, r = c2_graph(pg)
+        state = {"prev": None, "sum": 0.0}
+
+        def step(i):
+            s = pe.render(i * frames, frames)
+            if mode == "sync":
+                state["sum"] += float(s.data[-1, 0])
+                return
+            s.prefetch()
+            prev, state["prev"] = state["prev"], s
+            if prev is not None:
+                state["sum"] += float(prev.data[-1, 0])
+
+        def finish():
+            prev, state["prev"] = state["prev"], None
+            if prev is not None:
+                state["sum"] += float(prev.data[-1, 0])
+
+        dt = timed_steps(_Solo(), step, steps, warmup, finish)
+        r.stop()
+        out[mode] = {"value": round(frames * steps / dt / 1e6, 3), "unit": "Msamples/s",
+                     "ms_per_step": round(dt / steps * 1e3, 6),
+                     "pcie_gb_s": round(4.0 * frames * steps / dt / 1e9, 2)}
+    out["note"] = ("C2 steps with the root Snippet's 4 MB read on the host each step (pinned block from "
+                   "pgx_host_malloc, pgx_d2h_begin / pgx_d2h_wait); never `value`")
+    return out
+
+
 def pmc_traffic(entry: str, frames: int):
     """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json), or None."""
     try:
@@ -129,6 +284,18 @@ def pmc_traffic(entry: str, frames: int):
             return json.load(f).get(entry, {}).get(str(frames))
     except (OSError, ValueError):
         return None
+
+
+def event_avg_ms(launch, launches, warm=3):
+    from pygmu2_amd import device
+    for _ in range(warm):
+        launch()
+    e0, e1 = device.Event(), device.Event()
+    e0.record()
+    for _ in range(launches):
+        launch()
+    e1.record()
+    return e1.elapsed_ms_since(e0) / launches
 
 
 def biquad_kernel_roofline(pg, frames, launches, settled=True):
@@ -157,14 +324,7 @@ def biquad_kernel_roofline(pg, frames, launches, settled=True):
         device.check(lib.pgx_biquad_const(out.ptr, 0, x.ptr, 0, 1, frames, 1, coef.ptr, tables.ptr if settle else None, settle, state.ptr,
                                           ws.ptr))
 
-    for _ in range(3):
-        launch()
-    e0, e1 = device.Event(), device.Event()
-    e0.record()
-    for _ in range(launches):
-        launch()
-    e1.record()
-    ms = e1.elapsed_ms_since(e0) / launches
+    ms = event_avg_ms(launch, launches)
     algo_bytes = 8.0 * frames                      # read f32 + write f32 per frame
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -187,12 +347,15 @@ def cpu_c2(frames, budget_s=12.0):
         t_all += time.perf_counter() - t0
         pos += frames
         reps += 1
-    return {"value": round(frames * reps / t_all / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-            "kind": "port",
-            "sample": f"{reps} x render of {frames} frames: oracle sine_pure + biquad_const "
-                      f"(numpy sin + scipy.signal.lfilter, float64), 1 thread, {t_all:.1f} s"}
+    out = {"value": round(frames * reps / t_all / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+           "kind": "port",
+           "sample": f"{reps} x render of {frames} frames: oracle sine_pure + biquad_const "
+                     f"(numpy sin + scipy.signal.lfilter, float64), 1 thread, {t_all:.1f} s"}
+    out.update(host_info())
+    return out
 
 
+# ----------------------------------------------------------------------------- C1 and the small-block cases
 def bench_c1(pg, dist, steps, warmup):
     """C1: GainPE(SinePE(440, ch=2), 0.5), 44.1 kHz, 431 blocks of 1024 (441 000 frames) per step."""
     pg.set_sample_rate(44100)
@@ -325,6 +488,7 @@ def cpu_autowah(kind, block=1024, seconds=8):
     return round(total / (time.perf_counter() - t0) / 1e6, 3)
 
 
+# ----------------------------------------------------------------------------- C3
 def c3_inputs(frames):
     x = (np.random.default_rng(0).standard_normal((frames, 2)) * 0.1).astype(np.float32)
     n = np.arange(65536)
@@ -332,9 +496,10 @@ def c3_inputs(frames):
     return x, h
 
 
-def bench_c3(pg, dist, steps, warmup, frames=96_000):
-    """C3: ConvolvePE(stereo ArrayPE, 65 536-tap FIR, fft_size=131072), 48 kHz; a step renders the
-    whole `frames`-long signal in one call on a fresh (history-cleared) stream position."""
+def bench_c3(pg, dist, steps, warmup, frames=96_000, block=None):
+    """C3: ConvolvePE(stereo ArrayPE, 65 536-tap FIR, fft_size=131072), 48 kHz; a step renders the whole
+    `frames`-long signal, in one call or in `block`-frame calls, from stream position 0 (the overlap
+    history is carried from block to block and across steps)."""
     pg.set_sample_rate(48000)
     x, h = c3_inputs(frames)
     pe = pg.ConvolvePE(pg.ArrayPE(x), pg.ArrayPE(h), fft_size=131072)
@@ -344,7 +509,14 @@ def bench_c3(pg, dist, steps, warmup, frames=96_000):
     keep = {}
 
     def step(i):
-        keep["s"] = pe.render(0, frames)
+        if block is None:
+            keep["s"] = pe.render(0, frames)
+            return
+        pos = 0
+        while pos < frames:
+            n = min(block, frames - pos)
+            keep["s"] = pe.render(pos, n)
+            pos += n
 
     dt = timed_steps(dist, step, steps, warmup)
     r.stop()
@@ -363,14 +535,7 @@ def conv_kernel_roofline(pg, frames, launches):
     def launch():
         device.check(lib.pgx_convolve(out.ptr, xd.ptr, frames, 2, hd.ptr, 65536, 1, 2, hist.ptr, ws.ptr))
 
-    for _ in range(2):
-        launch()
-    e0, e1 = device.Event(), device.Event()
-    e0.record()
-    for _ in range(launches):
-        launch()
-    e1.record()
-    ms = e1.elapsed_ms_since(e0) / launches
+    ms = event_avg_ms(launch, launches, warm=2)
     flops = 2.0 * 65536 * 2 * frames                # direct form: 2*L*C_out per frame
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -396,24 +561,12 @@ def conv_fft_roofline(pg, frames, launches):
     def launch():
         device.check(lib.pgx_convolve_fft(out.ptr, xd.ptr, frames, 2, spec.ptr, L, 1, 2, nfft, hist.ptr, ws.ptr))
 
-    for _ in range(2):
-        launch()
-    e0, e1 = device.Event(), device.Event()
-    e0.record()
-    for _ in range(launches):
-        launch()
-    e1.record()
-    ms = e1.elapsed_ms_since(e0) / launches
+    ms = event_avg_ms(launch, launches, warm=2)
     algo_bytes = 4.0 * (2 + 2) * frames              # 4(C_in + C_out) per frame; taps are read once
-    hop = nfft - (L - 1)
-    pairs = 2 * ((-(-frames // hop) + 1) // 2)
-    moved = 3.0 * 32.0 * nfft * pairs                # three passes, 16 B read + 16 B written per complex point
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "work_buffer_bytes_per_launch": moved,
-            "kernel": "k_fft_cols<fwd> + k_fft_rows + k_fft_cols<inv> + k_fft_hist (pgx_convolve_fft, "
-                      f"N={nfft}, float64)",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("pgx_convolve_fft", frames),
+            "kernel": f"pgx_convolve_fft (float64 four-step FFT overlap-save, N={nfft})",
             "frames_per_launch": frames, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms, 6)}
 
 
@@ -430,21 +583,142 @@ def cpu_c3(frames=96_000, budget_s=6.0):
     return round(frames * reps / t_all / 1e6, 3)
 
 
+# ----------------------------------------------------------------------------- sharded mixes (C4, C5, SuperSaw)
+def mix_entry(pg, dist, config, steps, warmup, with_cpu):
+    from pygmu2_amd.sharding import bench_voice_mix
+    voices = 64 if config == "c4" else 512
+    dt, frames, name, info = bench_voice_mix(pg, dist, steps, warmup, voices=voices, config=config)
+    per_voice = {"c4": 7, "c5": 1, "supersaw": 7}[config]
+    out = {"value": round(frames * steps / dt / 1e6, 3), "unit": "Msamples/s",
+           "ms_per_block": round(dt / steps * 1e3, 4), "scaling": "strong", "workload": name,
+           "steps": steps, "warmup": warmup, "n_ranks": dist.world if dist.enabled else 1,
+           "voices_on_this_rank": info["owned"],
+           "oscillator_msamples_s": round(per_voice * voices * frames * steps / dt / 1e6, 1),
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": round(4.0 * frames * steps / dt / 1e9, 4),
+                        "frac": round(4.0 * frames * steps / dt / 1e9 / HBM_PEAK_GBS, 7),
+                        "algorithmic_bytes_per_block": 4.0 * frames,
+                        "note": "SURVEY 8d: 4C B/frame of final mix; every oscillator / filter is an on-chip "
+                                "intermediate, so this path is compute / latency bound by construction"}}
+    if config == "c4":
+        # LadderPE: chains x oversampled steps per second (latency-bound, no bandwidth fraction)
+        out["chain_steps_per_s"] = round(voices * 2 * frames * steps / dt, 1)
+    if with_cpu:
+        out["cpu_baseline"] = cpu_mix(config, voices, frames)
+        out["over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    out["_dt"] = dt
+    return out
+
+
+def cpu_mix(config, voices, frames, sample=(0, 0.37, 0.71)):
+    """CPU oracle on a bounded sample of the same workload: three of the voices (first, 37 %, 71 % of the
+    index range) rendered for one block each; the block of all `voices` is their mean x voices (voices are
+    independent and the mix is one add per voice).  1 thread."""
+    from oracle import graph_eval
+    from oracle.golden_cases import S
+
+    def spec(i):
+        if config == "c5":
+            return S("GainPE",
+                     source=S("BiquadPE", source=S("BlitSawPE", frequency=27.5 * 2 ** (i / 48.0)),
+                              frequency=2000.0, q=0.707),
+                     gain=S("AdsrGatedPE", gate=S("PeriodicGate", frequency=2.0 + 0.01 * i, duty_cycle=0.5),
+                            attack_time=0.01, decay_time=0.1, sustain_level=0.7, release_time=0.2))
+        if config == "c4":
+            return S("LadderPE", source=S("SuperSawPE", frequency=55.0 * 2 ** (i / 12.0), voices=7,
+                                          detune_cents=20.0, seed=i),
+                     frequency=1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2)
+        return S("SuperSawPE", frequency=55.0 * 2 ** (i / 96.0), voices=7, detune_cents=20.0, seed=i)
+
+    picks = sorted({min(voices - 1, int(f * voices)) for f in sample})
+    t_all = 0.0
+    for i in picks:
+        g = graph_eval.Node(spec(i), 48000)
+        g.render(0, 4800)                               # warm (C library load, allocations)
+        t0 = time.perf_counter()
+        g.render(4800, frames)
+        t_all += time.perf_counter() - t0
+    per_voice = t_all / len(picks)
+    out = {"value": round(frames / (per_voice * voices) / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": f"voices {picks} of {voices}, one {frames}-frame block each = {t_all:.2f} s; whole mix = mean x "
+                     f"{voices}; oracle numpy/scipy + oracle/seq_kernels.c (gcc -O2) for the ladder and ADSR loops"}
+    if config == "c4":
+        out["chain_steps_per_s"] = round(2 * frames / per_voice, 1)
+    out.update(host_info())
+    return out
+
+
+# ----------------------------------------------------------------------------- the benchmark_pes.py protocol
+def suite_rows(pg, with_cpu):
+    """benchmarks/benchmark_pes.py:149-196 protocol on its own configs (:257-383) that north_star names:
+    5 warm-up + 50 timed contiguous renders of 44 100 frames through a started NullRenderer graph;
+    "sync" waits for the device after every render, "pipelined" once after the 50."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_suite as B
+    wanted = ["SinePE (440 Hz)", "BlitSawPE (440 Hz, auto M)", "SuperSawPE (7 voices)", "GainPE (constant)",
+              "MixPE (4 sources)", "BiquadPE (lowpass, fixed)", "BiquadPE (bandpass, fixed)",
+              "BiquadPE (lowpass, modulated freq)", "BiquadPE (bandpass, modulated Q)",
+              "SVFilterPE (lowpass, fixed)", "SVFilterPE (lowpass, modulated freq)", "EnvelopePE", "CompressorPE"]
+    rows = {}
+    for name, spec in B.CONFIGS:
+        if name not in wanted:
+            continue
+        s, p = B.device_rates(spec)
+        row = {"sync": round(s, 1), "pipelined": round(p, 1)}
+        if with_cpu and "SVFilterPE (lowpass, modulated" not in name:     # that oracle loop is plain Python
+            row["cpu"] = round(B.cpu_rate(spec, budget_s=1.5), 2)
+            row["pipelined_over_cpu"] = round(p / row["cpu"], 1)
+        rows[name] = row
+    return {"protocol": "benchmark_pes.py:149-196: 44 100-frame renders, 5 warm-up + 50 timed, Msamples/s; "
+                        "cpu = oracle on this host, 1 thread", "rows": rows}
+
+
+# ----------------------------------------------------------------------------- dry run (launch glue on CPU)
+def dry_run(args, dist):
+    import pygmu2_amd as pg
+    from pygmu2_amd.sharding import ShardedMixPE, mix_voice_factory
+    pg.set_sample_rate(48000)
+    owned = None
+    if args.workload in SHARDED:
+        make, voices = mix_voice_factory(args.workload)
+        root = ShardedMixPE([make(pg, i) for i in range(voices)], dist.rank, dist.world)
+        owned = len(root.owned)
+    seen = dist.connect()
+    total_owned = dist._store_sum("owned", owned or 0) if dist.enabled else (owned or 0)
+    dist.barrier()
+    if dist.rank == 0:
+        print(json.dumps({"metric": "Msamples/s rendered (benchmark_pes.py metric: output frames / wall second)",
+                          "value": None, "unit": "Msamples/s", "n_gpus": dist.world, "n_ranks_seen": seen,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "config": {"workload": args.workload, "voices_on_rank0": owned,
+                                     "voices_on_all_ranks": total_owned}}), flush=True)
+    dist.shutdown()
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse_args()
-    dist = Dist(args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # before anything touches the GPU
+    dist = Dist(dry_run=args.dry_run)
+    if args.dry_run:
+        dry_run(args, dist)
+        return
     if dist.enabled:
         os.environ.setdefault("PYGMU_DEVICE", str(dist.local_rank))
     import pygmu2_amd as pg
     from pygmu2_amd import device
     device.ensure_init()
+    ranks_seen = dist.connect()
 
     n_gpus = max(1, dist.world)
+    with_cpu = not args.no_cpu and n_gpus == 1
     result = {}
+    extra_primary = {}
     if args.workload == "c2":
         dt, frames = bench_c2(pg, dist, args.steps, args.warmup)
-        name, sr = "C2: BiquadPE(SinePE(440), lowpass 1 kHz, q 0.707), 44.1 kHz mono, render(start, 1_000_000) per step", 44100
+        name = "C2: BiquadPE(SinePE(440), lowpass 1 kHz, q 0.707), 44.1 kHz mono, render(start, 1_000_000) per step"
         units = frames * args.steps * n_gpus
     elif args.workload == "c1":
         dt, frames = bench_c1(pg, dist, args.steps, args.warmup)
@@ -454,69 +728,76 @@ def main():
         dt, frames = bench_c3(pg, dist, args.steps, args.warmup)
         name = "C3: ConvolvePE stereo x 65536-tap FIR, 48 kHz, 96 000 frames per step"
         units = frames * args.steps * n_gpus
-    elif args.workload == "c4":
-        from pygmu2_amd.sharding import bench_voice_mix
-        dt, frames, name = bench_voice_mix(pg, dist, args.steps, args.warmup, voices=64, config="c4")
-        units = frames * args.steps
     else:
-        from pygmu2_amd.sharding import bench_voice_mix
-        dt, frames, name = bench_voice_mix(pg, dist, args.steps, args.warmup)
+        entry = mix_entry(pg, dist, args.workload, args.steps, args.warmup, with_cpu and dist.rank == 0)
+        dt, frames, name = entry.pop("_dt"), 48_000, entry["workload"]
         units = frames * args.steps
+        extra_primary = {k: entry[k] for k in entry if k not in ("value", "unit", "workload", "steps", "warmup")}
 
     value = units / dt / 1e6
+    sharded = args.workload in SHARDED
     result.update({
         "metric": "Msamples/s rendered (benchmark_pes.py metric: output frames / wall second)",
-        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "n_ranks_seen": ranks_seen,
+        "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True,
-        "scaling": "strong" if args.workload in ("c4", "c5") else "weak", "vs_baseline": None, "dtype": "f64",
+        "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": name, "frames_per_step": frames,
-                   "parallelism": ("voices sharded over ranks, RCCL all-reduce of the partial mixes"
-                                   if args.workload in ("c4", "c5") else
+                   "parallelism": (f"inputs of the root MixPE dealt i mod {n_gpus} over the ranks, one RCCL all-reduce "
+                                   "of the partial mix per block (pgx_allreduce_sum)" if sharded else
                                    ("single chain" if n_gpus == 1 else f"{n_gpus} independent replicas (replicas only)"))},
     })
+    if sharded:
+        result["mix"] = extra_primary
+        if "roofline" in extra_primary:
+            result["roofline"] = extra_primary["roofline"]
+        if "cpu_baseline" in extra_primary:
+            result["cpu_baseline"] = extra_primary["cpu_baseline"]
 
-    if args.workload not in ("c4", "c5") and not args.no_extras:
-        # collective: every rank takes part.  512-voice mix sharded over the ranks (strong scaling).
-        from pygmu2_amd.sharding import bench_voice_mix
-        vdt, vframes, vname = bench_voice_mix(pg, dist, 10, 2)
-        result["voice_mix"] = {"value": round(vframes * 10 / vdt / 1e6, 3), "unit": "Msamples/s",
-                               "voice_msamples_s": round(512 * vframes * 10 / vdt / 1e6, 1),
-                               "ms_per_block": round(vdt / 10 * 1e3, 4), "scaling": "strong",
-                               "workload": vname, "steps": 10, "warmup": 2}
-        # north_star's scaling case: 512 SuperSaw voices (3584 oscillators) -- throughput-bound, so it is the
-        # sharded workload that can scale with the GPU count (the C5 voices above are latency-bound chains)
-        sdt, sframes, sname = bench_voice_mix(pg, dist, 6, 2, config="supersaw")
-        result["supersaw_mix"] = {"value": round(sframes * 6 / sdt / 1e6, 3), "unit": "Msamples/s",
-                                  "oscillator_msamples_s": round(3584 * sframes * 6 / sdt / 1e6, 1),
-                                  "ms_per_block": round(sdt / 6 * 1e3, 4), "scaling": "strong",
-                                  "workload": sname, "steps": 6, "warmup": 2}
+    if not sharded and not args.no_extras:
+        # collectives: every rank takes part.  The sharded mixes ride along in the default line.
+        result["voice_mix"] = mix_entry(pg, dist, "c5", 10, 2, with_cpu and dist.rank == 0)
+        result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 6, 2, with_cpu and dist.rank == 0)
+        result["voice_mix"].pop("_dt"), result["supersaw_mix"].pop("_dt")
 
-    if dist.rank == 0 and not args.no_extras:
+    if dist.rank == 0 and not args.no_extras and not sharded:
+        solo = _Solo()
         result["device"] = device.device_name()
         result["roofline"] = biquad_kernel_roofline(pg, 1_000_000, 200)
         result["roofline_scaled"] = biquad_kernel_roofline(pg, 1 << 26, 10)
         cases = {}
         if args.workload == "c2" and n_gpus == 1:
-            dt1, f1 = bench_c1(pg, Dist(1), 5, 1)
+            result["value_with_d2h"] = bench_c2_with_d2h(pg, 40, 5)
+            dt1, f1 = bench_c1(pg, solo, 5, 1)
             cases["c1_sine_gain_1024_blocks"] = {"value": round(f1 * 5 / dt1 / 1e6, 3), "unit": "Msamples/s"}
             cases["c1_hello_sine_example_1024_blocks"] = {"value": hello_sine_case(pg), "unit": "Msamples/s"}
-            dt3, f3 = bench_c3(pg, Dist(1), 10, 2)
+            dt3, f3 = bench_c3(pg, solo, 10, 2)
             cases["c3_convolve_64k_taps"] = {"value": round(f3 * 10 / dt3 / 1e6, 3), "unit": "Msamples/s",
                                              "path": "float64 FFT overlap-save (pgx_convolve_fft)",
                                              "roofline": conv_fft_roofline(pg, 96_000, 20),
                                              # the dense FIR x block product on the matrix cores, same filter:
                                              # what ConvolvePE uses below convolve_pe.FFT_MIN_TAPS taps
                                              "direct_form_mfma": conv_kernel_roofline(pg, 96_000, 10)}
-        if args.workload == "c2" and n_gpus == 1:
-            from pygmu2_amd.sharding import bench_voice_mix
-            d4, f4, _ = bench_voice_mix(pg, Dist(1), 5, 1, voices=64, config="c4")
-            cases["c4_supersaw_ladder_mix_64"] = {"value": round(f4 * 5 / d4 / 1e6, 3), "unit": "Msamples/s",
-                                                  "ms_per_block": round(d4 / 5 * 1e3, 4)}
+            dtw, fw = bench_c3(pg, solo, 5, 1, frames=1_440_000)
+            cases["c3_convolve_64k_taps_1440000_whole"] = {
+                "value": round(fw * 5 / dtw / 1e6, 3), "unit": "Msamples/s",
+                "roofline": conv_fft_roofline(pg, 1_440_000, 5)}
+            dtb, fb = bench_c3(pg, solo, 3, 1, frames=1_440_000, block=65_537)
+            cases["c3_convolve_64k_taps_1440000_blocks_65537"] = {
+                "value": round(fb * 3 / dtb / 1e6, 3), "unit": "Msamples/s",
+                "roofline": conv_fft_roofline(pg, 65_537, 20)}
+            cases["c4_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4", 5, 1, with_cpu)
+            cases["c4_supersaw_ladder_mix_64"].pop("_dt")
             cases["autowah_biquad_1024_blocks"] = {"value": autowah_case(pg, "biquad"), "unit": "Msamples/s"}
             cases["autowah_svf_1024_blocks"] = {"value": autowah_case(pg, "svf"), "unit": "Msamples/s"}
-        if not args.no_cpu and n_gpus == 1:
+            result["suite"] = suite_rows(pg, with_cpu)
+        if with_cpu:
             result["cpu_baseline"] = cpu_c2(1_000_000)
+            if "value_with_d2h" in result:
+                for mode in ("pipelined", "sync"):
+                    result["value_with_d2h"][mode]["over_cpu"] = round(
+                        result["value_with_d2h"][mode]["value"] / result["cpu_baseline"]["value"], 1)
             if "autowah_biquad_1024_blocks" in cases:
                 # the oracle's varying biquad is the C restatement of the numba kernel; its SVF coefficient
                 # loop is plain Python (slow), so only the biquad graph gets a CPU figure
@@ -525,7 +806,10 @@ def main():
                 cases["c1_sine_gain_1024_blocks"]["cpu_oracle_msamples_s"] = cpu_c1()
                 cases["c1_hello_sine_example_1024_blocks"]["cpu_oracle_msamples_s"] = cpu_hello_sine()
             if "c3_convolve_64k_taps" in cases:
-                cases["c3_convolve_64k_taps"]["cpu_oracle_msamples_s"] = cpu_c3()
+                c3cpu = cpu_c3()
+                for k in cases:
+                    if k.startswith("c3_"):
+                        cases[k]["cpu_oracle_msamples_s"] = c3cpu
         if cases:
             result["cases"] = cases
 

@@ -70,6 +70,18 @@ int pgx_memcpy_h2d(void *dst, const void *src_host, size_t bytes);  /* synchrono
 int pgx_memcpy_d2h(void *dst_host, const void *src, size_t bytes);  /* synchronous */
 int pgx_memcpy_d2d(void *dst, const void *src, size_t bytes);
 
+/* Root Snippets leaving the device (the caller of render() reads `.data`: benchmark_pes.py:176-185 hands host
+ * arrays to its caller).  Pinned host blocks are pooled like device blocks.
+ *   pgx_d2h_begin   asynchronous copy on the library's copy stream, ordered behind everything enqueued on
+ *                   the library stream so far -- the next block renders while this one crosses PCIe
+ *   pgx_d2h_wait    the host blocks until that copy has landed
+ *   pgx_d2h_fence   the library stream waits for it instead (before `src` is recycled unread) */
+int pgx_host_malloc(void **hptr, size_t bytes);
+int pgx_host_free(void *hptr);
+int pgx_d2h_begin(void *dst_host, const void *src, size_t bytes, int64_t *ticket);
+int pgx_d2h_wait(int64_t ticket);
+int pgx_d2h_fence(int64_t ticket);
+
 int pgx_event_create(void **event);
 int pgx_event_destroy(void *event);
 int pgx_event_record(void *event);              /* on the library stream */
@@ -442,6 +454,29 @@ int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, in
 int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, const void *spectrum,
                      int64_t fir_len, int fir_channels, int out_channels, int64_t fft_size,
                      float *hist, void *workspace);
+
+/* ------------------------------------------------------------------ multi-GPU exchange (RCCL over xGMI)
+ * The one exchange step of the path: the partial mixes of a MixPE whose inputs are dealt i mod world over
+ * the ranks are summed (mix_pe.py:91-94 is the sum being distributed).  One process
+ * per GPU.  librccl is loaded on demand by these entry points only.
+ *   pgx_comm_unique_id   rank 0 creates the 128-byte rendezvous id; the host hands it to every rank
+ *                        (any channel: a file, MPI, torch.distributed's store ...)
+ *   pgx_comm_init        collective: every rank calls it with the same id, after pgx_init(device)
+ *   pgx_allreduce_sum    out[i] = sum over ranks of in[i] (float32, n elements; out may equal in).  Runs on
+ *                        the library's collective stream, ordered behind everything enqueued on the library
+ *                        stream so far; asynchronous.  `in` and `out` must stay allocated until the ticket
+ *                        has been waited for.
+ *   pgx_allreduce_wait   orders the library stream behind the collective of `ticket` (stream-level wait:
+ *                        the host does not block), after which `out` may be read and `in` released
+ *   pgx_allreduce_scalar_host   synchronous sum (op 0) / max (op 1) of one host double over the ranks */
+size_t pgx_comm_unique_id_bytes(void);
+int pgx_comm_unique_id(void *id_host, size_t len);
+int pgx_comm_init(int rank, int world, const void *id_host, size_t len);
+int pgx_comm_info(int *rank, int *world);        /* world == 0: no communicator */
+int pgx_comm_destroy(void);
+int pgx_allreduce_sum(float *out, const float *in, size_t n, int64_t *ticket);
+int pgx_allreduce_wait(int64_t ticket);
+int pgx_allreduce_scalar_host(double *value_host, int op);
 
 #ifdef __cplusplus
 }

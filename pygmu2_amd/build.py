@@ -29,6 +29,7 @@ SOURCES = [
     "pgx_lookup.hip",
     "pgx_dynamics.hip",
     "pgx_fftconv.hip",
+    "pgx_comm.hip",
 ]
 
 # -ffp-contract=off: the parity contract is "same float64 operation order as the reference's
@@ -47,26 +48,58 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _deps_common():
+    return [os.path.join(CSRC, "pgx_common.h"), os.path.join(ROOT, "include", "pygmu_hip.h"),
+            os.path.abspath(__file__)]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES]
-    deps += [os.path.join(CSRC, "pgx_common.h"), os.path.join(ROOT, "include", "pygmu_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def needs_build() -> bool:
+    return _stale(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + _deps_common())
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP source into pygmu2_amd/libpygmu_hip.so; returns its path."""
+    """Compile every HIP source (one object per translation unit, in parallel, only the stale ones) and
+    link pygmu2_amd/libpygmu_hip.so; returns its path."""
     if not force and not needs_build():
         return LIB_PATH
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(CSRC, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
     extra = os.environ.get("PGX_EXTRA_FLAGS", "").split()       # experiments: -DPGX_... switches
-    cmd = [_hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                                "-o", LIB_PATH] + srcs
+    tag = os.path.join(obj_dir, "flags.txt")
+    flag_text = " ".join(FLAGS + extra)
+    if not os.path.exists(tag) or open(tag).read() != flag_text:
+        force = True
+    compile_flags = [f for f in FLAGS if f != "-shared"] + extra
+    jobs, objs = [], []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(obj_dir, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + _deps_common()):
+            jobs.append([_hipcc()] + compile_flags + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                                                      "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print("[pygmu2_amd.build]", " ".join(cmd[-4:]), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, jobs))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
-        print("[pygmu2_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print("[pygmu2_amd.build] link", LIB_PATH, flush=True)
+    subprocess.check_call(link)
+    with open(tag, "w") as f:
+        f.write(flag_text)
     return LIB_PATH
 
 

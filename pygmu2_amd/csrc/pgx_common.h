@@ -17,7 +17,9 @@ int fail(int code, const std::string &msg);
 
 // Library stream (created by pgx_init).  Returns nullptr before init.
 hipStream_t stream();
+hipStream_t main_stream();   // the stream `stream()` returns outside a fork
 bool initialised();
+int device_index();
 
 }  // namespace pgx
 

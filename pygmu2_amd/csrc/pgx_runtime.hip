@@ -34,6 +34,13 @@ struct Runtime {
     std::map<size_t, std::vector<void *>> free_lists;   // size class -> blocks
     std::unordered_map<void *, size_t> live;             // ptr -> size class
     size_t bytes_cached = 0;
+    // pinned host blocks + the device->host copy stream (root Snippets leaving the device)
+    std::map<size_t, std::vector<void *>> host_free;
+    std::unordered_map<void *, size_t> host_live;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_copy_in = nullptr;
+    hipEvent_t copy_done[64] = {};
+    int64_t copies_issued = 0;
 };
 
 Runtime &rt() {
@@ -59,7 +66,9 @@ int fail(int code, const std::string &msg) {
 }
 
 hipStream_t stream() { return rt().current; }
+hipStream_t main_stream() { return rt().stream; }
 bool initialised() { return rt().ready; }
+int device_index() { return rt().device; }
 
 }  // namespace pgx
 
@@ -105,6 +114,10 @@ int pgx_init(int device) {
     }
     PGX_HIP(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
     PGX_HIP(hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming));
+    PGX_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    PGX_HIP(hipEventCreateWithFlags(&r.ev_copy_in, hipEventDisableTiming));
+    for (auto &e : r.copy_done) PGX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    r.copies_issued = 0;
     r.current = r.stream;
     r.forked = false;
     r.device = device;
@@ -128,12 +141,21 @@ int pgx_pool_trim(void) {
 int pgx_shutdown(void) {
     Runtime &r = rt();
     if (!r.ready) return PGX_OK;
+    pgx_comm_destroy();
     pgx_pool_trim();
     std::lock_guard<std::mutex> lock(r.mu);
-    for (auto &kv : r.live) (void)hipFree(kv.first);
+    for (auto &kv : r.live) (void)hipFree(kv.first);   // parked blocks are still listed in `live`
     r.live.clear();
-    for (void *p : r.parked) (void)hipFree(p);
     r.parked.clear();
+    (void)hipStreamSynchronize(r.copy);
+    for (auto &kv : r.host_free)
+        for (void *p : kv.second) (void)hipHostFree(p);
+    r.host_free.clear();
+    for (auto &kv : r.host_live) (void)hipHostFree(kv.first);
+    r.host_live.clear();
+    (void)hipStreamDestroy(r.copy);
+    (void)hipEventDestroy(r.ev_copy_in);
+    for (auto &e : r.copy_done) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(r.stream);
     (void)hipStreamDestroy(r.side);
     (void)hipEventDestroy(r.ev_fork);
@@ -286,6 +308,83 @@ int pgx_memcpy_d2d(void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PGX_OK;
     PGX_CHECK_ARG(dst != nullptr && src != nullptr, "pgx_memcpy_d2d: null pointer");
     PGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().current));
+    return PGX_OK;
+}
+
+int pgx_host_malloc(void **hptr, size_t bytes) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(hptr != nullptr, "pgx_host_malloc: null output");
+    Runtime &r = rt();
+    const size_t cls = size_class(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lock(r.mu);
+        auto it = r.host_free.find(cls);
+        if (it != r.host_free.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            r.host_live[p] = cls;
+            *hptr = p;
+            return PGX_OK;
+        }
+    }
+    void *p = nullptr;
+    PGX_HIP(hipHostMalloc(&p, cls, hipHostMallocDefault));
+    {
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.host_live[p] = cls;
+    }
+    *hptr = p;
+    return PGX_OK;
+}
+
+int pgx_host_free(void *hptr) {
+    if (hptr == nullptr) return PGX_OK;
+    Runtime &r = rt();
+    if (!r.ready) return PGX_OK;
+    std::lock_guard<std::mutex> lock(r.mu);
+    auto it = r.host_live.find(hptr);
+    if (it == r.host_live.end()) return pgx::fail(PGX_ERR_INVALID, "pgx_host_free: unknown pointer");
+    // a copy still in flight into this block stays ordered before any later one: the copy stream is in-order
+    r.host_free[it->second].push_back(hptr);
+    r.host_live.erase(it);
+    return PGX_OK;
+}
+
+int pgx_d2h_begin(void *dst_host, const void *src, size_t bytes, int64_t *ticket) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(ticket != nullptr && (bytes == 0 || (dst_host != nullptr && src != nullptr)),
+                  "pgx_d2h_begin: null argument");
+    Runtime &r = rt();
+    PGX_HIP(hipEventRecord(r.ev_copy_in, r.current));            // the payload is complete at this point
+    PGX_HIP(hipStreamWaitEvent(r.copy, r.ev_copy_in, 0));
+    if (bytes) PGX_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, r.copy));
+    const int64_t t = ++r.copies_issued;
+    PGX_HIP(hipEventRecord(r.copy_done[t % 64], r.copy));
+    *ticket = t;
+    return PGX_OK;
+}
+
+namespace {
+// the event that marks `ticket` done: its own while the slot has not been recycled, else a later one
+hipEvent_t copy_event(Runtime &r, int64_t ticket) {
+    const int64_t t = ticket > r.copies_issued - 64 ? ticket : r.copies_issued - 63;
+    return r.copy_done[t % 64];
+}
+}  // namespace
+
+int pgx_d2h_wait(int64_t ticket) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(ticket >= 1 && ticket <= r.copies_issued, "pgx_d2h_wait: unknown ticket");
+    PGX_HIP(hipEventSynchronize(copy_event(r, ticket)));
+    return PGX_OK;
+}
+
+int pgx_d2h_fence(int64_t ticket) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(ticket >= 1 && ticket <= r.copies_issued, "pgx_d2h_fence: unknown ticket");
+    PGX_HIP(hipStreamWaitEvent(r.current, copy_event(r, ticket), 0));
     return PGX_OK;
 }
 

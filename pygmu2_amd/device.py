@@ -53,6 +53,11 @@ _SIGNATURES = [
     ("pgx_memcpy_h2d", _I, [_P, _P, _Z]),
     ("pgx_memcpy_d2h", _I, [_P, _P, _Z]),
     ("pgx_memcpy_d2d", _I, [_P, _P, _Z]),
+    ("pgx_host_malloc", _I, [C.POINTER(_P), _Z]),
+    ("pgx_host_free", _I, [_P]),
+    ("pgx_d2h_begin", _I, [_P, _P, _Z, C.POINTER(_L)]),
+    ("pgx_d2h_wait", _I, [_L]),
+    ("pgx_d2h_fence", _I, [_L]),
     ("pgx_event_create", _I, [C.POINTER(_P)]),
     ("pgx_event_destroy", _I, [_P]),
     ("pgx_event_record", _I, [_P]),
@@ -114,6 +119,14 @@ _SIGNATURES = [
     ("pgx_adsr_triggered", _I, [_P, _L, _P, _L, _I, _L, _L, _P, _P, _P]),
     ("pgx_convolve_workspace_bytes", _Z, [_L, _L, _I]),
     ("pgx_convolve", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P]),
+    ("pgx_comm_unique_id_bytes", _Z, []),
+    ("pgx_comm_unique_id", _I, [_P, _Z]),
+    ("pgx_comm_init", _I, [_I, _I, _P, _Z]),
+    ("pgx_comm_info", _I, [C.POINTER(_I), C.POINTER(_I)]),
+    ("pgx_comm_destroy", _I, []),
+    ("pgx_allreduce_sum", _I, [_P, _P, _Z, C.POINTER(_L)]),
+    ("pgx_allreduce_wait", _I, [_L]),
+    ("pgx_allreduce_scalar_host", _I, [C.POINTER(_D), _I]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -270,6 +283,16 @@ class DeviceBuffer:
             check(ensure_init().pgx_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes), "pgx_memcpy_d2h")
         return out
 
+    def begin_to_host(self):
+        """Start an asynchronous copy into a pinned host block: (numpy view of the block, ticket).  The view
+        holds valid data once `wait_to_host(ticket)` has returned; the block returns to the library's pinned
+        pool when the last view of it dies."""
+        lib = ensure_init()
+        block = PinnedBlock(self.nbytes, self.shape, self.dtype)
+        ticket = C.c_int64(0)
+        check(lib.pgx_d2h_begin(block.ptr, self.ptr, self.nbytes, C.byref(ticket)), "pgx_d2h_begin")
+        return np.asarray(block), ticket.value
+
     def zero_(self) -> None:
         if self.nbytes:
             check(ensure_init().pgx_memset(self.ptr, 0, self.nbytes), "pgx_memset")
@@ -305,6 +328,37 @@ class DeviceBuffer:
 
     def __repr__(self):
         return f"DeviceBuffer(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr or 0:x})"
+
+
+class PinnedBlock:
+    """A pinned (page-locked) host block from the library's pool, exposed to numpy through
+    __array_interface__ (numpy keeps this object alive as the array's base)."""
+
+    __slots__ = ("ptr", "nbytes", "__array_interface__")
+
+    def __init__(self, nbytes: int, shape, dtype):
+        p = C.c_void_p(0)
+        check(ensure_init().pgx_host_malloc(C.byref(p), max(int(nbytes), 1)), "pgx_host_malloc")
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dtype).str,
+                                    "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.pgx_host_free(self.ptr)
+        except Exception:
+            pass
+        self.ptr = 0
+
+
+def wait_to_host(ticket: int) -> None:
+    check(_lib.pgx_d2h_wait(ticket), "pgx_d2h_wait")
+
+
+def fence_to_host(ticket: int) -> None:
+    check(_lib.pgx_d2h_fence(ticket), "pgx_d2h_fence")
 
 
 def upload_struct(dtype: np.dtype, **fields) -> DeviceBuffer:

@@ -5,9 +5,10 @@ Voices / PE sub-graphs feeding a MixPE share nothing (a stateful PE may have onl
 sink, renderer.py:379-384) and MixPE is a plain sum (mix_pe.py:91-94), so the K inputs
 are dealt round-robin over the G ranks (input i -> rank i mod G), every rank renders and
 mixes its own shard entirely in its own HBM, and ONE all-reduce(sum) per rendered block
-combines the partial mixes: RCCL over xGMI when the payload lives on the GPU
-(torch.distributed backend "nccl"), gloo for host payloads (CPU tests).  One process per
-GPU; launch with torchrun / torch.distributed.run.
+combines the partial mixes: RCCL over xGMI through the library's own entry points
+(pgx_allreduce_sum, include/pygmu_hip.h; communicator set up by pygmu2_amd.comm), or gloo on host
+payloads for the CPU tests of the multi-rank logic.  One process per GPU; any launcher that
+sets RANK / LOCAL_RANK / WORLD_SIZE will do (torchrun, bench.py's own spawner).
 
 The all-reduce adds the partial mixes in an order that differs from the reference's
 left-to-right float32 sum, so sharded output matches the unsharded one to ~1e-7 of peak
@@ -53,14 +54,46 @@ class _Silence(ProcessingElement):
         return Snippet.from_zeros(start, duration, self._channels)
 
 
-class TorchReducer:
-    """all-reduce(sum) of a Snippet payload through torch.distributed (nccl == RCCL on ROCm).
+class RcclReducer:
+    """all-reduce(sum) of a Snippet payload on RCCL through the C ABI (pgx_allreduce_sum): the product path.
 
-    Device payloads are reduced in place, zero-copy (__cuda_array_interface__), without blocking the host:
-    the collective is ordered behind the library stream with stream waits, and the returned Snippet carries
-    a `ready` hook that orders the library stream behind the collective only when its payload is used.
-    Rendering the next block therefore overlaps the previous block's all-reduce over xGMI.
+    Out of place into a fresh buffer: the local payload may be storage somebody else keeps (a CachePE memo,
+    a row view of a read-ahead window, a pass-through Snippet), so it is only read.  Every rank issues the
+    same collective whatever its local payload was (a rank that owns nothing uploads its zeros).  The host
+    does not block: the collective is ordered behind the library stream, and the returned Snippet carries a
+    `ready` hook that orders the library stream behind the collective only when the payload is used or
+    dropped -- rendering the next block overlaps this block's all-reduce over xGMI.  The local payload is
+    kept alive by that hook until then.
     """
+
+    def __init__(self):
+        from . import comm, device
+        if not comm.initialised():
+            raise RuntimeError("no RCCL communicator: call pygmu2_amd.comm.init(...) on every rank first")
+        self._device = device
+        self._lib = device.ensure_init()
+        self.rank, self.world = comm.info()
+
+    def all_reduce(self, snippet: Snippet) -> Snippet:
+        import ctypes as C
+        dev, lib = self._device, self._lib
+        src = snippet.dev
+        out = dev.DeviceBuffer(src.shape, np.float32)
+        ticket = C.c_int64(0)
+        dev.check(lib.pgx_allreduce_sum(out.ptr, src.ptr, src.nbytes // 4, C.byref(ticket)), "pgx_allreduce_sum")
+        hold = [snippet]
+
+        def ready():
+            dev.check(lib.pgx_allreduce_wait(ticket.value), "pgx_allreduce_wait")
+            hold.clear()                                # the local payload may return to the pool now
+        return Snippet(snippet.start, out, ready=ready)
+
+
+class TorchReducer:
+    """all-reduce(sum) through an initialised torch.distributed group: gloo on host payloads (the CPU tests
+    of the multi-rank logic), or -- PYGMU_REDUCER=torch -- torch's own RCCL binding on device payloads.
+    The path is chosen from the group's backend, never from where this rank's payload happens to live, so
+    that every rank issues the same collective."""
 
     def __init__(self):
         import torch
@@ -70,6 +103,7 @@ class TorchReducer:
             raise RuntimeError("torch.distributed is not initialised")
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.on_device = "nccl" in str(dist.get_backend())
         self._lib_stream = None
         self._comm_stream = None
 
@@ -83,8 +117,11 @@ class TorchReducer:
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         torch, dist = self.torch, self.dist
-        if snippet.on_device:
-            buf = snippet.dev
+        if self.on_device:
+            from . import device as _dev
+            src = snippet.dev                           # a host payload (zeros of an idle rank) is uploaded
+            buf = _dev.DeviceBuffer(src.shape, np.float32)
+            _dev.check(_dev.ensure_init().pgx_memcpy_d2d(buf.ptr, src.ptr, src.nbytes), "pgx_memcpy_d2d")
             lib_stream, comm = self._streams()
             t = torch.as_tensor(buf, device="cuda")     # zero-copy via __cuda_array_interface__
             comm.wait_stream(lib_stream)                # the collective starts after the local mix is complete
@@ -98,6 +135,20 @@ class TorchReducer:
         t = torch.from_numpy(np.ascontiguousarray(snippet.data).copy())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return Snippet(snippet.start, t.numpy())
+
+
+def default_reducer():
+    """The C-ABI RCCL communicator when one exists (pygmu2_amd.comm.init); otherwise an initialised
+    torch.distributed group (gloo: CPU tests)."""
+    import os
+    from . import comm
+    if os.environ.get("PYGMU_REDUCER", "") != "torch":
+        try:
+            if comm.initialised():
+                return RcclReducer()
+        except RuntimeError:                            # library not built: only the host-side tests get here
+            pass
+    return TorchReducer()
 
 
 class ShardedMixPE(ProcessingElement):
@@ -151,7 +202,7 @@ class ShardedMixPE(ProcessingElement):
         if self._world == 1:
             return part
         if self._reducer is None:
-            self._reducer = TorchReducer()
+            self._reducer = default_reducer()
         return self._reducer.all_reduce(part)
 
 
@@ -174,10 +225,16 @@ def supersaw_voice(pg, i: int):
     return pg.SuperSawPE(55.0 * 2 ** (i / 96.0), voices=7, detune_cents=20.0, seed=i)
 
 
+def mix_voice_factory(config: str):
+    """(voice constructor, voice count) of the three sharded bench workloads."""
+    return {"c5": (c5_voice, 512), "c4": (c4_voice, 64), "supersaw": (supersaw_voice, 512)}[config]
+
+
 def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c5"):
-    """Sharded MixPE of BASELINE config 5 (512 voices) or 4 (64 SuperSaw->Ladder instances):
-    inputs i = rank (mod world) on each GPU, one RCCL all-reduce of the (block, 1) partial mix
-    per rendered block.  Strong scaling."""
+    """Sharded MixPE of BASELINE config 5 (512 voices), config 4 (64 SuperSaw->Ladder instances) or the
+    512-voice SuperSaw mix: inputs i = rank (mod world) on each GPU, one RCCL all-reduce of the (block, 1)
+    partial mix per rendered block.  Strong scaling.  `dist` offers world / rank / enabled / barrier() /
+    max_over_ranks(); the communicator (pygmu2_amd.comm) is already up when world > 1."""
     import time
 
     from . import device
@@ -185,7 +242,7 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     pg.set_sample_rate(48000)
     world = dist.world if dist.enabled else 1
     rank = dist.rank if dist.enabled else 0
-    make = {"c5": c5_voice, "c4": c4_voice, "supersaw": supersaw_voice}[config]
+    make = mix_voice_factory(config)[0]
     root = ShardedMixPE([make(pg, i) for i in range(voices)], rank, world)
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
@@ -195,16 +252,12 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
         keep["s"] = root.render(i * block, block)
     keep["s"].dev
     device.synchronize()
-    if dist.enabled:
-        dist.torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         keep["s"] = root.render((warmup + i) * block, block)
     keep["s"].dev                      # order the library stream behind the last block's all-reduce ...
     device.synchronize()               # ... and wait for it: every block is rendered AND reduced
-    if dist.enabled:
-        dist.torch.cuda.synchronize()
     dist.barrier()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
     r.stop()
@@ -217,4 +270,4 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     else:
         name = (f"C4: {voices} x LadderPE(SuperSawPE 7 voices)->MixPE, 48 kHz mono, {block}-frame blocks, "
                 f"instances sharded i mod {world}")
-    return dt, block, name
+    return dt, block, name, {"owned": len(root.owned)}

@@ -22,11 +22,12 @@ from .device import DeviceBuffer
 
 
 class Snippet:
-    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready")
+    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready", "_copy")
 
     def __init__(self, start: int, data, ready=None):
         self._start = int(start)
         self._ready = ready
+        self._copy = None
         if isinstance(data, DeviceBuffer):
             if data.dtype != np.float32 or len(data.shape) != 2:
                 raise ValueError("device payload must be float32 of shape (frames, channels)")
@@ -69,15 +70,34 @@ class Snippet:
     def __del__(self):
         try:
             self._resolve()
+            if self._copy is not None:          # a prefetch nobody read: the payload must outlive the copy
+                from .device import fence_to_host
+                fence_to_host(self._copy)
         except Exception:
             pass
+
+    def prefetch(self) -> "Snippet":
+        """Start moving the payload to the host (pinned block, the library's copy stream) without waiting:
+        `.data` will block only for what is left of the copy.  For callers that read every block
+        (benchmark_pes.py:176-185): render block k+1, then read block k."""
+        if self._host is None and self._copy is None and self._shape[0]:
+            self._resolve()
+            self._host, self._copy = self._dev.begin_to_host()
+        return self
 
     @property
     def data(self) -> np.ndarray:
         """Host view (frames, channels) float32; treat as immutable."""
-        self._resolve()
-        if self._host is None:
-            self._host = self._dev.to_host()
+        if self._copy is None:
+            if self._host is not None:
+                return self._host
+            self.prefetch()
+            if self._copy is None:              # zero frames
+                self._host = np.zeros(self._shape, dtype=np.float32)
+                return self._host
+        from .device import wait_to_host
+        ticket, self._copy = self._copy, None
+        wait_to_host(ticket)
         return self._host
 
     @property

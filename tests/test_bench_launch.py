@@ -1,0 +1,49 @@
+"""CPU: `bench.py --gpus N` creates N ranks by itself (no launcher), every rank joins the rendezvous, the
+shards cover the workload, and the parent fails when a rank does.  --dry-run stops short of the device."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True,
+                          text=True, timeout=timeout, cwd=ROOT)
+
+
+@pytest.mark.parametrize("n,workload,voices", [(2, "supersaw", 512), (3, "c5", 512), (2, "c4", 64)])
+def test_gpus_n_spawns_n_ranks(n, workload, voices):
+    p = _run(["--gpus", str(n), "--workload", workload, "--dry-run"])
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # exactly one JSON line: rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["n_ranks_seen"] == n
+    assert d["config"]["voices_on_all_ranks"] == voices
+    assert d["config"]["voices_on_rank0"] == len(range(0, voices, n))
+
+
+def test_single_rank_needs_no_rendezvous():
+    p = _run(["--dry-run", "--workload", "c5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1
+
+
+def test_parent_reports_a_failed_rank():
+    # without --dry-run the ranks need the device: here (no GPU) every rank fails loudly, and so must the parent
+    from pygmu2_amd import device
+    if device.device_available():
+        pytest.skip("needs a host without a GPU")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"], timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

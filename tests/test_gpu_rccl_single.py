@@ -1,6 +1,7 @@
-"""GPU: the RCCL leg of ShardedMixPE on a 1-rank "nccl" group -- proves the zero-copy hand-off of a
-library DeviceBuffer to torch.distributed (via __cuda_array_interface__), the stream ordering
-between the library stream and torch's stream, and that bench.py's multi-GPU glue runs."""
+"""GPU: the RCCL leg of ShardedMixPE on 1-rank communicators -- the library's own entry points
+(pgx_comm_init / pgx_allreduce_sum / pgx_allreduce_wait: the product path, no torch in the process), the
+deferred wait and buffer lifetimes of the pipelined use, the alternative torch.distributed binding, and
+bench.py's launch glue under torch.distributed.run."""
 
 import os
 import socket
@@ -25,6 +26,7 @@ from pygmu2_amd.sharding import ShardedMixPE, TorchReducer, c5_voice
 pg.set_sample_rate(48000)
 voices = [c5_voice(pg, i) for i in range(6)]
 red = TorchReducer()
+assert red.on_device
 root = ShardedMixPE(voices, 0, 1)
 root._world = 2                      # force the reduction path; with one rank the sum is the identity
 root._reducer = red
@@ -62,6 +64,78 @@ print("RCCL_SINGLE_OK")
 '''
 
 
+ABI_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PGX_ROOT"])
+import pygmu2_amd as pg
+from pygmu2_amd import comm, device
+from pygmu2_amd.sharding import ShardedMixPE, RcclReducer, default_reducer, c5_voice
+device.ensure_init()
+assert not comm.initialised()
+comm.init(0, 1, comm.unique_id())
+assert comm.info() == (0, 1)
+assert comm.reduce_scalar(3.5, "sum") == 3.5 and comm.reduce_scalar(-2.0, "max") == -2.0
+pg.set_sample_rate(48000)
+root = ShardedMixPE([c5_voice(pg, i) for i in range(6)], 0, 1)
+root._world = 2                      # force the reduction path; with one rank the sum is the identity
+r = pg.NullRenderer(48000); r.set_source(root); r.start()
+a = [root.render(i * 4096, 4096).data for i in range(3)]
+r.stop()
+assert isinstance(root._reducer, RcclReducer)
+plain = pg.MixPE(*[c5_voice(pg, i) for i in range(6)])
+r = pg.NullRenderer(48000); r.set_source(plain); r.start()
+b = [plain.render(i * 4096, 4096).data for i in range(3)]
+r.stop()
+for x, y in zip(a, b):
+    assert np.array_equal(x, y), float(np.max(np.abs(x - y)))
+# pipelined: blocks dropped unread while their all-reduce may still be in flight; 200 blocks also walk the
+# ticket ring (64 event slots) several times
+root2 = ShardedMixPE([c5_voice(pg, i) for i in range(6)], 0, 1)
+root2._world = 2
+r = pg.NullRenderer(48000); r.set_source(root2); r.start()
+keep = None
+for i in range(200):
+    keep = root2.render(i * 512, 512)
+assert keep._ready is not None       # nothing has forced the last reduce yet
+tail = keep.data
+assert keep._ready is None
+r.stop()
+r = pg.NullRenderer(48000); r.set_source(plain); r.start()
+want = np.concatenate([plain.render(i * 512, 512).data for i in range(200)])[-512:]
+r.stop()
+assert np.max(np.abs(tail - want)) <= 1e-6 * max(1e-3, float(np.max(np.abs(want))))
+# an idle rank (owns nothing) and a one-voice rank issue the same collective; the local payload is left alone
+cached = pg.CachePE(pg.SinePE(frequency=300.0))
+solo = ShardedMixPE([cached, pg.SinePE(frequency=500.0)], 0, 2, reducer=RcclReducer())
+first = solo.render(0, 256).data.copy()
+again = solo.render(0, 256).data
+assert np.array_equal(first, again) and np.array_equal(first, pg.SinePE(frequency=300.0).render(0, 256).data)
+idle = ShardedMixPE([pg.SinePE(frequency=300.0), pg.SinePE(frequency=500.0)], 2, 3, reducer=RcclReducer())
+assert not np.any(idle.render(0, 128).data)
+comm.destroy()
+assert not comm.initialised()
+assert "torch" not in sys.modules
+print("RCCL_ABI_OK")
+'''
+
+
+def _worker(tmp_path, text, token, **env_extra):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGX_ROOT=ROOT,
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    script = tmp_path / "w.py"
+    script.write_text(text)
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and token in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_rccl_allreduce_through_the_c_abi(tmp_path):
+    _worker(tmp_path, ABI_WORKER, "RCCL_ABI_OK")
+
+
 def test_rccl_allreduce_on_library_buffers(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -88,4 +162,14 @@ def test_bench_distributed_glue_single_rank(tmp_path):
     import json
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "voice_mix" in d and "roofline" in d
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["value"] > 0 and "voice_mix" in d and "roofline" in d
+
+
+def test_bench_sharded_workload_line(tmp_path):
+    """--workload supersaw as the primary line (what a scaling run reports), one rank."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "supersaw", "--steps", "2",
+                        "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    import json
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["value"] > 0 and d["mix"]["voices_on_this_rank"] == 512

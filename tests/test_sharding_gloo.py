@@ -43,7 +43,7 @@ def test_world_one_is_plain_local_mix():
         ShardedMixPE(voices[:1], 0, 1)
 
 
-@pytest.mark.parametrize("world,n_voices", [(2, 6), (3, 4)])
+@pytest.mark.parametrize("world,n_voices", [(2, 6), (3, 4), (3, 2)])     # (3, 2): rank 2 owns nothing
 def test_sharded_mix_matches_full_mix_gloo(tmp_path, world, n_voices):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=os.path.dirname(HERE))
