@@ -61,6 +61,7 @@ int pgx_stream_sync(void);
 int pgx_stream_fork(void);
 int pgx_stream_select(int side);
 int pgx_stream_join(void);
+int pgx_stream_is_forked(void);           /* 1 between fork and join */
 
 int pgx_malloc(void **dptr, size_t bytes);      /* pooled (size-class free lists)           */
 int pgx_free(void *dptr);                       /* returns the block to the pool            */
@@ -258,8 +259,8 @@ int pgx_index_range(double *result_dev, const float *delay, int64_t start, int64
 int pgx_piecewise(float *out, int64_t start, int64_t n, int channels, const int64_t *times,
                   const double *values, int count, int transition, int hold_first, int hold_last);
 /* WavWriterPE / WavReaderPE sample conversion on the device (half the PCIe bytes of float32):
- * libsndfile's PCM_16 rules (the reference's default subtype, wav_writer_pe.py:67):
- * s = lrintf(x * 32767) wrapped to 16 bits; x = s / 32768. */
+ * libsndfile's PCM_16 rules as python-soundfile configures them (clipping on; the reference's default
+ * subtype, wav_writer_pe.py:67): s = x * 32768 saturated to [-32768, 32767], else lrintf; x = s / 32768. */
 int pgx_f32_to_pcm16(int16_t *out, const float *in, int64_t n_elems);
 int pgx_pcm16_to_f32(float *out, const int16_t *in, int64_t n_elems);
 
@@ -342,6 +343,14 @@ size_t pgx_blitsaw_workspace_bytes(int batch, int64_t n, int streams /* any of f
 int pgx_supersaw_sum(float *out, int64_t out_stride, int batch, int nvoices, int64_t n,
                      int channels, const float *voices, const double *amp_scalar /* [batch] */,
                      const float *amp, int64_t amp_stride);
+
+/* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
+ * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the
+ * [batch*nvoices][frames] intermediate (one workgroup per instance, one wave per oscillator; nvoices <= 16).
+ * params / state are [batch*nvoices] as for pgx_blitsaw, laid out [instance][voice]. */
+int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                      double sample_rate, const pgx_blitsaw_params *params, double *state /* [batch*nvoices][2] */,
+                      const double *amp_scalar /* [batch] */);
 
 /* ------------------------------------------------------------------ LadderPE
  * _ladder_process_numba (ladder_pe.py:31-203), the reference's float64 operation order.

@@ -1,7 +1,12 @@
 """
-CompressorPE, LimiterPE, ExpanderPE: CachePE(source) feeding an EnvelopePE and a DynamicsPE
-(compressor_pe.py:21-325).  No kernels of their own: the envelope follower and the gain computer are
-pgx_envelope and pgx_dynamics.
+CompressorPE, LimiterPE, ExpanderPE: level detector + gain computer around one cached source.
+
+Behaviour (reference: compressor_pe.py:21-325): each of the three is a fixed wiring -- the source is
+rendered once per block (CachePE) and goes both to an EnvelopePE (side chain) and to a DynamicsPE that
+applies the gain the envelope calls for.  What differs is the recipe: the compressor detects RMS by default
+and compresses above the threshold with automatic make-up gain; the limiter is a compressor pinned to ratio
+100, hard knee, peak detection, look-ahead and no make-up; the expander gates below the threshold with a
+peak detector.  No kernels of their own: samples come from pgx_envelope and pgx_dynamics.
 """
 
 from __future__ import annotations
@@ -14,22 +19,27 @@ from .processing_element import ProcessingElement
 from .snippet import Snippet
 
 
-class _DynamicsProcessorPE(ProcessingElement):
-    def __init__(self, cached_source, envelope_pe, dynamics_pe, *, threshold, attack, release, knee, stereo_link):
-        self._source = cached_source
-        self._envelope_pe = envelope_pe
-        self._dynamics_pe = dynamics_pe
-        self._threshold = threshold
-        self._attack = attack
-        self._release = release
-        self._knee = knee
-        self._stereo_link = stereo_link
+def _setting(name):
+    """Read-only view of one entry of the processor's settings."""
+    return property(lambda self: self._settings[name])
 
-    threshold = property(lambda self: self._threshold)
-    attack = property(lambda self: self._attack)
-    release = property(lambda self: self._release)
-    knee = property(lambda self: self._knee)
-    stereo_link = property(lambda self: self._stereo_link)
+
+class _SideChainProcessor(ProcessingElement):
+    """source -> CachePE -> { EnvelopePE , DynamicsPE(audio, envelope) }; the DynamicsPE is the output."""
+
+    def _wire(self, source, *, detector: dict, computer: dict, settings: dict) -> None:
+        tap = CachePE(source)
+        follower = EnvelopePE(tap, **detector)
+        self._source = tap
+        self._envelope_pe = follower
+        self._dynamics_pe = DynamicsPE(tap, follower, **computer)
+        self._settings = dict(settings)
+
+    threshold = _setting("threshold")
+    attack = _setting("attack")
+    release = _setting("release")
+    knee = _setting("knee")
+    stereo_link = _setting("stereo_link")
 
     def inputs(self) -> list[ProcessingElement]:
         return [self._dynamics_pe]
@@ -47,62 +57,64 @@ class _DynamicsProcessorPE(ProcessingElement):
         return self._dynamics_pe.render(start, duration)
 
 
-class CompressorPE(_DynamicsProcessorPE):
+class CompressorPE(_SideChainProcessor):
     AUTO = "auto"
 
     def __init__(self, source: ProcessingElement, threshold: float = -20.0, ratio: float = 4.0,
                  attack: float = 0.01, release: float = 0.1, knee: float = 6.0,
                  makeup_gain: float | str = "auto", lookahead: float = 0.0,
                  detection: DetectionMode = DetectionMode.RMS, stereo_link: bool = True):
-        cached = CachePE(source)
-        envelope_pe = EnvelopePE(cached, attack=attack, release=release, lookahead=lookahead, mode=detection)
-        dynamics_pe = DynamicsPE(cached, envelope_pe, threshold=threshold, ratio=ratio, knee=knee,
-                                 makeup_gain=makeup_gain, mode=DynamicsMode.COMPRESS, stereo_link=stereo_link)
-        super().__init__(cached, envelope_pe, dynamics_pe, threshold=threshold, attack=attack, release=release,
-                         knee=knee, stereo_link=stereo_link)
-        self._ratio = ratio
-        self._makeup_gain = makeup_gain
-        self._lookahead = lookahead
-        self._detection = detection
+        self._wire(source,
+                   detector=dict(attack=attack, release=release, lookahead=lookahead, mode=detection),
+                   computer=dict(threshold=threshold, ratio=ratio, knee=knee, makeup_gain=makeup_gain,
+                                 mode=DynamicsMode.COMPRESS, stereo_link=stereo_link),
+                   settings=dict(threshold=threshold, ratio=ratio, attack=attack, release=release, knee=knee,
+                                 makeup_request=makeup_gain, lookahead=lookahead, detection=detection,
+                                 stereo_link=stereo_link))
 
-    ratio = property(lambda self: self._ratio)
-    makeup_gain = property(lambda self: self._dynamics_pe.makeup_gain)
-    lookahead = property(lambda self: self._lookahead)
-    detection = property(lambda self: self._detection)
+    ratio = _setting("ratio")
+    lookahead = _setting("lookahead")
+    detection = _setting("detection")
+
+    @property
+    def makeup_gain(self):
+        return self._dynamics_pe.makeup_gain             # the resolved value when "auto" was asked for
 
     def __repr__(self) -> str:
-        makeup_str = "auto" if self._makeup_gain == self.AUTO else f"{self.makeup_gain:.1f}"
-        return (f"CompressorPE(threshold={self._threshold}, ratio={self._ratio}, attack={self._attack}, "
-                f"release={self._release}, knee={self._knee}, makeup={makeup_str}, lookahead={self._lookahead})")
+        s = self._settings
+        makeup = "auto" if s["makeup_request"] == self.AUTO else f"{self.makeup_gain:.1f}"
+        return (f"CompressorPE(threshold={s['threshold']}, ratio={s['ratio']}, attack={s['attack']}, "
+                f"release={s['release']}, knee={s['knee']}, makeup={makeup}, lookahead={s['lookahead']})")
 
 
 class LimiterPE(CompressorPE):
     def __init__(self, source: ProcessingElement, ceiling: float = -1.0, attack: float = 0.0005,
                  release: float = 0.05, lookahead: float = 0.005, stereo_link: bool = True):
-        super().__init__(source, threshold=ceiling, ratio=100.0, attack=attack, release=release, knee=0.0,
-                         makeup_gain=0.0, lookahead=lookahead, detection=DetectionMode.PEAK,
-                         stereo_link=stereo_link)
-        self._ceiling = ceiling
+        CompressorPE.__init__(self, source, threshold=ceiling, ratio=100.0, attack=attack, release=release,
+                              knee=0.0, makeup_gain=0.0, lookahead=lookahead, detection=DetectionMode.PEAK,
+                              stereo_link=stereo_link)
+        self._settings["ceiling"] = ceiling
 
-    ceiling = property(lambda self: self._ceiling)
+    ceiling = _setting("ceiling")
 
     def __repr__(self) -> str:
-        return f"LimiterPE(ceiling={self._ceiling}, release={self._release}, lookahead={self._lookahead})"
+        s = self._settings
+        return f"LimiterPE(ceiling={s['ceiling']}, release={s['release']}, lookahead={s['lookahead']})"
 
 
-class ExpanderPE(_DynamicsProcessorPE):
+class ExpanderPE(_SideChainProcessor):
     def __init__(self, source: ProcessingElement, threshold: float = -40.0, attack: float = 0.001,
                  release: float = 0.05, gate_range: float = -80.0, knee: float = 0.0, stereo_link: bool = True):
-        cached = CachePE(source)
-        envelope_pe = EnvelopePE(cached, attack=attack, release=release, mode=DetectionMode.PEAK)
-        dynamics_pe = DynamicsPE(cached, envelope_pe, threshold=threshold, ratio=1.0, knee=knee, makeup_gain=0.0,
-                                 mode=DynamicsMode.GATE, stereo_link=stereo_link, gate_range=gate_range)
-        super().__init__(cached, envelope_pe, dynamics_pe, threshold=threshold, attack=attack, release=release,
-                         knee=knee, stereo_link=stereo_link)
-        self._range = gate_range
+        self._wire(source,
+                   detector=dict(attack=attack, release=release, mode=DetectionMode.PEAK),
+                   computer=dict(threshold=threshold, ratio=1.0, knee=knee, makeup_gain=0.0,
+                                 mode=DynamicsMode.GATE, stereo_link=stereo_link, gate_range=gate_range),
+                   settings=dict(threshold=threshold, attack=attack, release=release, knee=knee,
+                                 gate_range=gate_range, stereo_link=stereo_link))
 
-    gate_range = property(lambda self: self._range)
+    gate_range = _setting("gate_range")
 
     def __repr__(self) -> str:
-        return (f"ExpanderPE(threshold={self._threshold}, attack={self._attack}, release={self._release}, "
-                f"range={self._range})")
+        s = self._settings
+        return (f"ExpanderPE(threshold={s['threshold']}, attack={s['attack']}, release={s['release']}, "
+                f"range={s['gate_range']})")

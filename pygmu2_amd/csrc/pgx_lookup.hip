@@ -137,17 +137,23 @@ k_piecewise(float *out, int64_t start, int64_t n, int channels, const int64_t *t
 }
 
 // ------------------------------------------------------------------------------------------------
-// WAV sample formats: libsndfile's float <-> PCM16 conversions (src/pcm.c f2les_array / les2f_array,
-// normalisation on, clipping off): lrintf(x * 32767) truncated to 16 bits; x = s / 32768.
+// WAV sample formats: what the reference's writer does to a float32 sample on its way into a PCM_16 file.
+// wav_writer_pe.py:67 opens the file through python-soundfile, whose SoundFile.__init__ switches libsndfile to
+// clipping conversions (SFC_SET_CLIPPING = SF_TRUE); pcm_write_f2les then uses f2s_clip_array (src/pcm.c):
+// scaled = x * 0x8000 in float arithmetic; scaled >= 0x7FFF -> 0x7FFF; scaled <= -0x8000 -> -0x8000; otherwise
+// lrintf(scaled) in the default rounding mode (half to even).  Reading (s2f_array): x = s / 0x8000.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_f32_to_pcm16(int16_t *out, const float *in, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const float scaled = in[i] * 32767.0f;
-        float r = rintf(scaled);                           // round half to even
-        r = r != r ? 0.0f : (r > 9.0e18f ? 9.0e18f : (r < -9.0e18f ? -9.0e18f : r));
-        out[i] = (int16_t)(uint16_t)(uint64_t)(int64_t)r;  // wrap, like the C conversion chain
+        const float scaled = in[i] * 32768.0f;
+        int v;
+        if (scaled >= 32767.0f) v = 32767;
+        else if (scaled <= -32768.0f) v = -32768;
+        else if (scaled != scaled) v = 0;                  // NaN: lrintf's result is unspecified; write silence
+        else v = (int)rintf(scaled);                       // round half to even
+        out[i] = (int16_t)v;
     }
 }
 

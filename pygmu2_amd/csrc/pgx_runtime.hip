@@ -196,6 +196,8 @@ int pgx_stream_fork(void) {
     return PGX_OK;
 }
 
+int pgx_stream_is_forked(void) { return rt().ready && rt().forked ? 1 : 0; }
+
 int pgx_stream_select(int side) {
     PGX_REQUIRE_INIT();
     Runtime &r = rt();

@@ -974,6 +974,114 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// A bank of SuperSawPEs, voices summed on chip (super_saw_pe.py:304-316 on top of blit_saw_pe.py:150-264).
+// One 512-thread workgroup per SuperSaw instance.  A 4096-frame tile is rendered voice after voice exactly as
+// k_blitsaw<false, 8, 0> renders it (same wave values, same folds: the float32 samples of every oscillator are
+// that kernel's, bit for bit); instead of being stored, each voice is added, in voice order, to a float64
+// accumulator the thread keeps for its 8 frames -- k_supersaw_sum's arithmetic -- and the tile leaves the chip
+// once, as float32(acc * amplitude).  The [instances x voices][frames] intermediate never exists.
+// The per-voice carries (phase sum, integrator level) live in LDS between tiles.  Scalar parameters only.
+constexpr int kSsMaxVoices = 16;
+struct SsShared {
+    SawShared scan;
+    double carry_sum[kSsMaxVoices];
+    double carry_y[kSsMaxVoices];
+};
+__global__ void __launch_bounds__(kSawWideWaves * 64)
+k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels, double sr,
+                const pgx_blitsaw_params *params, double *state, const double *amp_scalar) {
+    constexpr int NW = kSawWideWaves;
+    constexpr int kTile = NW * 64 * kSawT;
+    __shared__ SsShared sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int inst = blockIdx.x;
+    const pgx_blitsaw_params *pv = params + (int64_t)inst * nv;
+    double *sv = state + (int64_t)inst * nv * 2;
+    float *ob = out + (int64_t)inst * out_stride;
+    const double g = amp_scalar[inst];
+    if (tid < nv) {
+        sh.carry_sum[tid] = 0.0;
+        sh.carry_y[tid] = sv[tid * 2 + 1];
+    }
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += kTile) {
+        const int64_t f0 = base + (int64_t)tid * kSawT;
+        double acc[kSawT];
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) acc[j] = 0.0;
+#pragma unroll 1
+        for (int v = 0; v < nv; ++v) {
+            const pgx_blitsaw_params p = pv[v];
+            const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
+            const double phase0 = sv[v * 2 + 0];            // rewritten only after the last tile
+            const double leak = p.leak;
+            double lamp[6], lam_wave, lam_lane = 1.0;
+            {
+                double l = leak;
+#pragma unroll
+                for (int s = 1; s < kSawT; s <<= 1) l = l * l;      // leak^T
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    lamp[k] = l;
+                    if (lane & (1 << k)) lam_lane = lam_lane * l;
+                    l = l * l;
+                }
+                lam_wave = l;
+            }
+            double carry_sum = sh.carry_sum[v], carry_y = sh.carry_y[v];
+            double loc[kSawT];
+            double run = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) {
+                run = run + ((f0 + j < n) ? k0.inc : 0.0);
+                loc[j] = run;
+            }
+            const double chunk_base = block_excl_sum_wide<NW>(run, sh.scan.sum, carry_sum);
+            double xb[kSawT];
+            double final_phase = 0.0, final_y = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) {
+                const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));
+                const double theta = kPi * ph;
+                const double m_theta = k0.m * theta;
+                const double sin_num = pgx::pgx_sin(m_theta);
+                const double sin_den = pgx::pgx_sin(theta);
+                const double blit = (fabs(sin_den) < 1e-9) ? (k0.m / k0.P)
+                                                           : pgx::pgx_div_fast(sin_num, k0.P * sin_den);
+                xb[j] = (f0 + j < n) ? (blit - k0.invP) : 0.0;
+                if (f0 + j == n - 1) final_phase = ph;
+            }
+            double e = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
+            double y = block_scan_scalar_affine_wide<NW>(e, lamp, lam_wave, lam_lane, sh.scan.aff, carry_y);
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) {
+                double z = leak * y;
+                y = z + xb[j];
+                acc[j] += (double)(float)((y * 2.0) * p.amp);
+                if (f0 + j == n - 1) final_y = y;
+            }
+            if (f0 <= n - 1 && n - 1 < f0 + kSawT) {         // the thread that renders the last frame
+                sv[v * 2 + 0] = final_phase;
+                sv[v * 2 + 1] = final_y;
+            }
+            if (tid == 0) {                                 // every thread holds the same carries
+                sh.carry_sum[v] = carry_sum;
+                sh.carry_y[v] = carry_y;
+            }
+            // the next voice's first LDS access is behind block_excl_sum_wide's barrier
+        }
+        float yf[kSawT];
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) yf[j] = (float)(acc[j] * g);
+        store_frames_tiled<kSawT>(ob, f0, n, channels, yf);
+        __syncthreads();                                    // carries written by thread 0 (a bank of one voice
+                                                            // has no other barrier before they are read again)
+    }
+}
+
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
 struct SawPlan {
     int nseg, tiles_per_seg;
@@ -1958,6 +2066,21 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     else PGX_SAW_LAUNCH(false, kWaves, 0, dim3(batch));
 #undef PGX_SAW_LAUNCH
     PGX_LAUNCH_CHECK("k_blitsaw");
+    return PGX_OK;
+}
+
+int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                      double sample_rate, const pgx_blitsaw_params *params, double *state,
+                      const double *amp_scalar) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && state && amp_scalar && channels >= 1 && sample_rate > 0,
+                  "pgx_supersaw_bank: bad argument");
+    PGX_CHECK_ARG(nvoices >= 1 && nvoices <= 16, "pgx_supersaw_bank: 1..16 voices per instance");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_bank: out_stride too small");
+    hipLaunchKernelGGL(k_supersaw_bank, dim3(batch), dim3(kSawWideWaves * 64), 0, pgx::stream(), out, out_stride,
+                       nvoices, n, channels, sample_rate, params, state, amp_scalar);
+    PGX_LAUNCH_CHECK("k_supersaw_bank");
     return PGX_OK;
 }
 

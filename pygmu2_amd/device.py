@@ -46,6 +46,7 @@ _SIGNATURES = [
     ("pgx_stream_fork", _I, []),
     ("pgx_stream_select", _I, [_I]),
     ("pgx_stream_join", _I, []),
+    ("pgx_stream_is_forked", _I, []),
     ("pgx_malloc", _I, [C.POINTER(_P), _Z]),
     ("pgx_free", _I, [_P]),
     ("pgx_pool_trim", _I, []),
@@ -108,6 +109,7 @@ _SIGNATURES = [
     ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P, _P]),
     ("pgx_blitsaw_workspace_bytes", _Z, [_I, _L, _I]),
     ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
+    ("pgx_supersaw_bank", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P]),
     ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P, _L, _P]),
     ("pgx_ladder_workspace_bytes", _Z, [_I, _L, _I, _L]),
     ("pgx_comb", _I, [_P, _P, _L, _I, _D, _D, _D, _P, _P, _D, _L, _P, _L, _P, _P, _P]),

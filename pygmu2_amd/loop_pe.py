@@ -18,25 +18,44 @@ def _subtree_pure(pe: ProcessingElement) -> bool:
     return pe.is_pure() and all(_subtree_pure(i) for i in pe.inputs())
 
 
+def _first_known(*candidates):
+    for c in candidates:
+        if c is not None:
+            return c
+    return None
+
+
 class LoopPE(ProcessingElement):
+    """Behaviour: frames [region_first, region_last) of the source repeat from output time 0 -- for ever, or
+    `count` times and then silence.  A boundary the caller leaves open falls back to the source's extent
+    (the start further to 0; an open end over an endless source is an error).  An optional crossfade, given
+    in seconds and never longer than half the region, blends the end of each pass into its beginning."""
+
     def __init__(self, source: ProcessingElement, loop_start: int | None = None, loop_end: int | None = None,
                  count: int | None = None, crossfade_seconds: float | None = None):
         if crossfade_seconds is not None and crossfade_seconds < 0:
             raise ValueError(f"crossfade_seconds must be non-negative, got {crossfade_seconds}")
         self._source = source
-        self._loop_start = loop_start
-        self._loop_end = loop_end
+        self._loop_start, self._loop_end = loop_start, loop_end
         self._count = count
         self._crossfade_seconds = crossfade_seconds
-        self._resolved_start: int | None = None
-        self._resolved_end: int | None = None
-        self._loop_length: int | None = None
-        self._crossfade = 0
         self._loop_snippet: Snippet | None = None         # kept only under a pure sub-graph
-        self._sample_rate = self._source.sample_rate        # loop_pe.py:64
-        self._resolve_loop_boundaries()
-        if self._sample_rate is not None:
-            self._resolve_crossfade()
+        self._sample_rate = source.sample_rate            # the loop lives at its source's rate
+
+        span = source.extent()
+        first = _first_known(loop_start, span.start, 0)
+        last = _first_known(loop_end, span.end)
+        if last is None:
+            raise ValueError("Cannot loop source with infinite extent without explicit loop_end")
+        if last - first <= 0:
+            raise ValueError(f"Loop length must be positive, got {last - first}")
+        self._region = (first, last)
+        self._loop_length = last - first
+
+        wanted = 0
+        if crossfade_seconds is not None and self._sample_rate is not None:
+            wanted = int(round(crossfade_seconds * self.sample_rate))
+        self._crossfade = min(wanted, self._loop_length // 2)
 
     source = property(lambda self: self._source)
     loop_start = property(lambda self: self._loop_start)
@@ -54,61 +73,37 @@ class LoopPE(ProcessingElement):
     def channel_count(self) -> int | None:
         return self._source.channel_count()
 
+    def _played_frames(self) -> int | None:
+        return None if self._count is None else self._count * self._loop_length
+
     def _compute_extent(self) -> Extent:
-        if self._loop_length is None or self._count is None:
-            return Extent(0, None)
-        return Extent(0, self._count * self._loop_length)
+        return Extent(0, self._played_frames())
 
-    def _resolve_loop_boundaries(self) -> None:      # loop_pe.py:122-148
-        ext = self._source.extent()
-        if self._resolved_start is None:
-            if self._loop_start is not None:
-                self._resolved_start = self._loop_start
-            elif ext.start is not None:
-                self._resolved_start = ext.start
-            else:
-                self._resolved_start = 0
-        if self._resolved_end is None:
-            if self._loop_end is not None:
-                self._resolved_end = self._loop_end
-            elif ext.end is not None:
-                self._resolved_end = ext.end
-            else:
-                raise ValueError("Cannot loop source with infinite extent without explicit loop_end")
-        self._loop_length = self._resolved_end - self._resolved_start
-        if self._loop_length <= 0:
-            raise ValueError(f"Loop length must be positive, got {self._loop_length}")
-
-    def _resolve_crossfade(self) -> None:             # loop_pe.py:150-157
-        if self._crossfade_seconds is not None:
-            self._crossfade = int(round(self._crossfade_seconds * self.sample_rate))
-        else:
-            self._crossfade = 0
-        if self._loop_length is not None:
-            self._crossfade = min(self._crossfade, self._loop_length // 2)
-
-    def _on_start(self) -> None:
+    def _drop_region(self) -> None:
         self._loop_snippet = None
 
-    _on_stop = _on_start
+    _on_start = _on_stop = _drop_region
 
     def _render(self, start: int, duration: int) -> Snippet:
-        channels = self._source.channel_count() or 1
-        total = -1 if self._count is None else self._count * self._loop_length
-        if total >= 0 and (start >= total or min(duration, total - start) <= 0):
-            return Snippet(start, new_output(duration, channels, zero=True))      # no source pull (loop_pe.py:176-187)
-        loop = self._loop_snippet
-        if loop is None:
-            loop = self._source.render(self._resolved_start, self._loop_length)
+        played = self._played_frames()
+        if played is not None and start >= played:
+            # past the last pass: silence, and the source is not pulled at all
+            return Snippet(start, new_output(duration, self._source.channel_count() or 1, zero=True))
+        region = self._loop_snippet
+        if region is None:
+            region = self._source.render(self._region[0], self._loop_length)
             if _subtree_pure(self._source):
-                self._loop_snippet = loop
-        out = new_output(duration, loop.channels)
-        check(lib().pgx_loop(out.ptr, loop.dev.ptr, start, duration, loop.channels, self._loop_length, total,
-                             self._crossfade), "pgx_loop")
+                self._loop_snippet = region               # a pure source renders the same region every time
+        out = new_output(duration, region.channels)
+        check(lib().pgx_loop(out.ptr, region.dev.ptr, start, duration, region.channels, self._loop_length,
+                             -1 if played is None else played, self._crossfade), "pgx_loop")
         return Snippet(start, out)
 
     def __repr__(self) -> str:
-        count_str = f", count={self._count}" if self._count is not None else ""
-        xfade_str = f", crossfade_seconds={self._crossfade_seconds}" if self._crossfade_seconds else ""
-        return (f"LoopPE(source={self._source.__class__.__name__}, loop_start={self._loop_start}, "
-                f"loop_end={self._loop_end}{count_str}{xfade_str})")
+        parts = [f"source={type(self._source).__name__}", f"loop_start={self._loop_start}",
+                 f"loop_end={self._loop_end}"]
+        if self._count is not None:
+            parts.append(f"count={self._count}")
+        if self._crossfade_seconds:
+            parts.append(f"crossfade_seconds={self._crossfade_seconds}")
+        return "LoopPE(" + ", ".join(parts) + ")"

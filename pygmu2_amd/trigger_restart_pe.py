@@ -17,10 +17,15 @@ from .trigger_signal import TriggerSignal
 
 
 class TriggerRestartPE(ProcessingElement):
+    """Behaviour: every positive trigger sample re-bases the source's clock -- the source is reset and then
+    rendered from its own time 0 at that frame; until the next trigger it simply keeps running on that
+    clock, across block boundaries.  Before the first trigger ever seen the output is silence.  Channels and
+    state follow the source, the extent follows the trigger."""
+
     def __init__(self, trigger: TriggerSignal, src: ProcessingElement):
         self._trigger = trigger
         self._src = src
-        self._t0_abs: int | None = None
+        self._origin: int | None = None          # absolute frame of the latest restart; None = none yet
 
     def inputs(self) -> list[ProcessingElement]:
         return [self._trigger, self._src]
@@ -39,34 +44,32 @@ class TriggerRestartPE(ProcessingElement):
     def _compute_extent(self) -> Extent:
         return self._trigger.extent()
 
-    def _reset_state(self) -> None:
-        self._t0_abs = None
+    def _forget_origin(self) -> None:
+        self._origin = None
 
-    _on_start = _reset_state
-    _on_stop = _reset_state
+    _reset_state = _on_start = _on_stop = _forget_origin
 
     def _render(self, start: int, duration: int) -> Snippet:
-        n = duration
-        ch = self.channel_count() or 1
-        out = new_output(n, ch, zero=True)
-        trig = self._trigger.render(start, duration).data[:, 0]
-        events = np.nonzero(trig > 0)[0]
-
-        def place(row: int, snip: Snippet) -> None:
-            if snip.duration:
-                check(lib().pgx_memcpy_d2d(out.offset_ptr(row * ch), snip.dev.ptr, snip.duration * ch * 4),
-                      "pgx_memcpy_d2d")
-
-        prefix_end = int(events[0]) if events.size else n
-        if prefix_end > 0 and self._t0_abs is not None:
-            place(0, self._src.render(start - self._t0_abs, prefix_end))
-        for i, k in enumerate(events.tolist()):
-            k_end = int(events[i + 1]) if i + 1 < events.size else n
-            if k_end <= k:
-                continue
-            self._src.reset_state()
-            self._t0_abs = start + k
-            place(k, self._src.render(0, k_end - k))
+        channels = self.channel_count() or 1
+        out = new_output(duration, channels, zero=True)
+        fired = np.flatnonzero(self._trigger.render(start, duration).data[:, 0] > 0)
+        # the block splits into stretches: [0, first trigger) on the running clock, then one per trigger
+        cuts = np.concatenate(([0], fired, [duration])).astype(np.int64)
+        for idx in range(len(cuts) - 1):
+            row, length = int(cuts[idx]), int(cuts[idx + 1] - cuts[idx])
+            restarts = idx > 0
+            if length <= 0:
+                continue                          # a trigger on frame 0 leaves an empty lead-in
+            if restarts:
+                self._src.reset_state()
+                self._origin = start + row
+                piece = self._src.render(0, length)
+            elif self._origin is not None:
+                piece = self._src.render(start - self._origin, length)
+            else:
+                continue                          # nothing has started the source yet: silence
+            check(lib().pgx_memcpy_d2d(out.offset_ptr(row * channels), piece.dev.ptr, length * channels * 4),
+                  "pgx_memcpy_d2d")
         return Snippet(start, out)
 
     def __repr__(self) -> str:

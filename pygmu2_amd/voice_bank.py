@@ -36,6 +36,7 @@ from .snippet import Snippet
 from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
+FUSED_SUPERSAW_MIN = 128     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
 
 def _is_pe(x) -> bool:
@@ -133,6 +134,13 @@ class _SuperSawNode(_Node):
         L = lib()
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
+        if self.k >= FUSED_SUPERSAW_MIN and self.nv <= 16:
+            # enough instances to fill the chip with one wave per oscillator: voices summed on chip
+            out = DeviceBuffer((self.k, n, self.ch), np.float32)
+            check(L.pgx_supersaw_bank(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
+                                      self.params.ptr, self.state.ptr, self.amp.ptr), "pgx_supersaw_bank")
+            self.last_end = start + n
+            return out
         voices = DeviceBuffer((self.k * self.nv, n), np.float32)
         ws = blitsaw_workspace(self, self.k * self.nv, n, False)
         check(L.pgx_blitsaw(voices.ptr, n, self.k * self.nv, n, 1, self.sr, self.params.ptr,
@@ -405,11 +413,12 @@ class VoiceBank:
             gain = root.children["gain"]
             if isinstance(gain, _AdsrGatedNode) and gain.fused_gate():
                 # edge search first (parallel, short), then the walk detached on the side stream
-                g = gain.render(start, duration, detach=True)
                 try:
+                    g = gain.render(start, duration, detach=True)
                     x = root.children["source"].render(start, duration)
                 finally:
-                    check(L.pgx_stream_join(), "pgx_stream_join")
+                    if L.pgx_stream_is_forked():        # the fork happens inside the detached render
+                        check(L.pgx_stream_join(), "pgx_stream_join")
             else:
                 check(L.pgx_stream_fork(), "pgx_stream_fork")
                 try:

@@ -146,3 +146,33 @@ def test_wide_blitsaw_workgroups_reproduce_the_bank_kernel_bit_for_bit():
         assert np.array_equal(seg.to_host()[2], bank.to_host()[pick + 1]), n
     assert np.array_equal(state_seg.to_host()[1], state_one.to_host()[0])
     assert np.array_equal(state_bank.to_host()[pick], state_one.to_host()[0])
+
+
+@pytest.mark.parametrize("voices,channels", [(7, 1), (3, 2), (1, 1), (16, 1)])
+def test_supersaw_bank_summed_on_chip_is_the_two_launch_path_bit_for_bit(voices, channels, monkeypatch):
+    """pgx_supersaw_bank (voices accumulated inside the oscillator kernel, no intermediate) against
+    pgx_blitsaw + pgx_supersaw_sum and against per-voice rendering: identical float32 samples, identical
+    carried state (a second and a third block, a gap that resets, an unaligned tail)."""
+    from pygmu2_amd import voice_bank
+    pg.set_sample_rate(48000)
+    n_inst = 130
+
+    def make():
+        return pg.MixPE(*[pg.SuperSawPE(55.0 * 2 ** (i / 24.0), amplitude=0.5 + 0.001 * i, voices=voices,
+                                        detune_cents=20.0, seed=i, channels=channels,
+                                        mix_mode=("center_heavy", "linear", "equal")[i % 3]) for i in range(n_inst)])
+
+    blocks = [(0, 5000), (5000, 4096), (9096, 8191), (40000, 777)]
+    fused = make()
+    got_fused = _render_blocks(fused, 48000, blocks)
+    assert fused._bank and fused._bank.root.k == n_inst
+    monkeypatch.setattr(voice_bank, "FUSED_SUPERSAW_MIN", 10 ** 9)
+    two = make()
+    got_two = _render_blocks(two, 48000, blocks)
+    for a, b in zip(got_fused, got_two):
+        assert a.shape == b.shape and np.array_equal(a, b), float(np.max(np.abs(a - b)))
+    plain = make()
+    plain._bank = False
+    got_plain = _render_blocks(plain, 48000, blocks[:2])
+    for a, b in zip(got_fused, got_plain):
+        assert np.array_equal(a, b), float(np.max(np.abs(a - b)))

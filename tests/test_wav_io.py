@@ -12,11 +12,14 @@ from pygmu2_amd import wav_io
 
 
 def test_pcm16_conversion_known_answers():
-    x = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 0.25, 1.5 / 32767, 2.5 / 32767, 1.00004, -1.00004, 3.0e-5],
-                 dtype=np.float32)
+    # libsndfile f2s_clip_array (what python-soundfile selects): x * 32768, saturate, lrintf half-to-even
+    x = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 0.25, 1.5 / 32768, 2.5 / 32768, 1.00004, -1.00004, 3.0e-5,
+                  0.99997, 32766.5 / 32768, 3.0, -3.0, 1e30, -1e30, np.nan], dtype=np.float32)
     got = O.float_to_pcm16(x)
-    #                 0   full  -full  16383.5->16384 (even)       1.5->2  2.5->2  wraps
-    assert got.tolist() == [0, 32767, -32767, 16384, -16384, 8192, 2, 2, -32768, -32768, 1]
+    #                0  clip   -full   exact   exact  exact 1.5->2 2.5->2 clip   clip    0.98->1
+    assert got.tolist() == [0, 32767, -32768, 16384, -16384, 8192, 2, 2, 32767, -32768, 1,
+                            32767, 32766, 32767, -32768, 32767, -32768, 0]
+    #                       32766.017->clip? no: 0.99997*32768 = 32767.02 -> >= 32767 -> 32767; 32766.5 -> 32766 (even)
     back = O.pcm16_to_float(np.array([0, 32767, -32768, 1], dtype=np.int16))
     assert back.dtype == np.float32
     assert back.tolist() == [0.0, 32767 / 32768, -1.0, 1 / 32768]

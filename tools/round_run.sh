@@ -1,5 +1,6 @@
 set -o pipefail
-timeout -k 10 900 python -m pytest tests -q -m gpu -x > gpurun_out/r1_tests.log 2>&1 && tail -2 gpurun_out/r1_tests.log \
-&& timeout -k 10 600 python bench.py > gpurun_out/r1_bench.json 2> gpurun_out/r1_bench.err && cut -c1-600 gpurun_out/r1_bench.json \
-&& timeout -k 10 400 python tools/bench_suite.py cpu > gpurun_out/r1_suite.md 2>&1 \
-&& bash tools/kernel_trace.sh r1_bench_trace bench.py --steps 50 --warmup 5 > /dev/null 2>&1; echo trace rc=$?; head -30 gpurun_out/r1_bench_trace.md
+# usage (GPU box): bash tools/round_run.sh <tag>   -- GPU test suite, bench line, kernel trace of the bench
+tag=${1:-r2}
+timeout -k 10 1000 python -m pytest tests -q -m gpu -x > gpurun_out/${tag}_tests.log 2>&1; rc=$?; tail -5 gpurun_out/${tag}_tests.log; [ $rc -eq 0 ] \
+&& timeout -k 10 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err && cut -c1-400 gpurun_out/${tag}_bench.json \
+&& bash tools/kernel_trace.sh ${tag}_bench_trace bench.py --steps 50 --warmup 5 --no-cpu > /dev/null 2>&1; echo trace rc=$?; head -40 gpurun_out/${tag}_bench_trace.md
