@@ -610,10 +610,10 @@ def mix_entry(pg, dist, config, steps, warmup, with_cpu):
     return out
 
 
-def cpu_mix(config, voices, frames, sample=(0, 0.37, 0.71)):
-    """CPU oracle on a bounded sample of the same workload: three of the voices (first, 37 %, 71 % of the
-    index range) rendered for one block each; the block of all `voices` is their mean x voices (voices are
-    independent and the mix is one add per voice).  1 thread."""
+def cpu_mix(config, voices, frames, budget_s=4.0, max_picks=24):
+    """CPU oracle on a bounded sample of the same workload: voices spread evenly over the index range (the
+    cost grows with the oscillator frequency), one block each, until `budget_s` seconds are spent; the block of
+    all `voices` is their mean x voices (voices are independent and the mix is one add per voice).  1 thread."""
     from oracle import graph_eval
     from oracle.golden_cases import S
 
@@ -630,18 +630,24 @@ def cpu_mix(config, voices, frames, sample=(0, 0.37, 0.71)):
                      frequency=1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2)
         return S("SuperSawPE", frequency=55.0 * 2 ** (i / 96.0), voices=7, detune_cents=20.0, seed=i)
 
-    picks = sorted({min(voices - 1, int(f * voices)) for f in sample})
-    t_all = 0.0
-    for i in picks:
+    order = [int((k * 0.6180339887 % 1.0) * voices) for k in range(max_picks)]      # low-discrepancy spread
+    picks, t_all = [], 0.0
+    for i in order:
+        if i in picks:
+            continue
         g = graph_eval.Node(spec(i), 48000)
         g.render(0, 4800)                               # warm (C library load, allocations)
         t0 = time.perf_counter()
         g.render(4800, frames)
         t_all += time.perf_counter() - t0
+        picks.append(i)
+        if t_all >= budget_s:
+            break
     per_voice = t_all / len(picks)
     out = {"value": round(frames / (per_voice * voices) / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": f"voices {picks} of {voices}, one {frames}-frame block each = {t_all:.2f} s; whole mix = mean x "
-                     f"{voices}; oracle numpy/scipy + oracle/seq_kernels.c (gcc -O2) for the ladder and ADSR loops"}
+           "sample": f"{len(picks)} of the {voices} voices (indices spread over the range), one {frames}-frame block "
+                     f"each = {t_all:.2f} s; whole mix = mean x {voices}; oracle numpy/scipy + oracle/seq_kernels.c "
+                     f"(gcc -O2) for the ladder and ADSR loops"}
     if config == "c4":
         out["chain_steps_per_s"] = round(2 * frames / per_voice, 1)
     out.update(host_info())
@@ -664,14 +670,18 @@ def suite_rows(pg, with_cpu):
     for name, spec in B.CONFIGS:
         if name not in wanted:
             continue
-        s, p = B.device_rates(spec)
-        row = {"sync": round(s, 1), "pipelined": round(p, 1)}
+        rates = B.device_rates(spec)
+        row = {k: round(v, 1) for k, v in rates.items()}
         if with_cpu and "SVFilterPE (lowpass, modulated" not in name:     # that oracle loop is plain Python
             row["cpu"] = round(B.cpu_rate(spec, budget_s=1.5), 2)
-            row["pipelined_over_cpu"] = round(p / row["cpu"], 1)
+            row["pipelined_over_cpu"] = round(rates["pipelined"] / row["cpu"], 1)
+            row["sync_over_cpu"] = round(rates["sync"] / row["cpu"], 1)
         rows[name] = row
-    return {"protocol": "benchmark_pes.py:149-196: 44 100-frame renders, 5 warm-up + 50 timed, Msamples/s; "
-                        "cpu = oracle on this host, 1 thread", "rows": rows}
+    return {"protocol": "benchmark_pes.py:149-196: 44 100-frame renders, 5 warm-up + 50 timed contiguous renders "
+                        "(started away from the warm-up: every timed frame is rendered inside the timed region), "
+                        "Msamples/s; sync = device wait after every render, pipelined = one wait after the 50, "
+                        "block_by_block = pipelined with read-ahead / look-ahead off; cpu = oracle on this host, "
+                        "1 thread", "rows": rows}
 
 
 # ----------------------------------------------------------------------------- dry run (launch glue on CPU)

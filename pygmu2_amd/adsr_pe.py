@@ -33,6 +33,9 @@ def _slopes(attack_time, decay_time, sustain_level, release_time):
 
 
 class _AdsrBase(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py
+    _STATE_FIELDS = ("_state",)
+
     def _init_common(self, control, attack_time, decay_time, sustain_level, release_time):
         self._control = control
         self._attack_time = float(attack_time)

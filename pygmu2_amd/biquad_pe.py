@@ -115,6 +115,9 @@ def settle_frames(a1: float, a2: float, limit: int = 1 << 16) -> int:
 
 
 class BiquadPE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py: block-partition invariant, state listed below
+    _STATE_FIELDS = ("_state", "_state_channels")
+
     def __init__(self, source: ProcessingElement, frequency, q,
                  mode: BiquadMode = BiquadMode.LOWPASS, gain_db: float = 0.0):
         self._source = source

@@ -20,6 +20,9 @@ from .snippet import Snippet
 
 
 class BlitSawPE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py
+    _STATE_FIELDS = ("_state", "_last_render_end")
+
     def __init__(self, frequency, amplitude=1.0, initial_phase: float = 0.0, m=None,
                  leak: float = 0.999, channels: int = 1):
         self._frequency = frequency

@@ -16,6 +16,9 @@ from .snippet import Snippet
 
 
 class CombPE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py
+    _STATE_FIELDS = ("_ring", "_state", "_buffer_len")
+
     _MAX_FEEDBACK = 0.995
 
     def __init__(self, source: ProcessingElement, frequency, feedback=0.0,

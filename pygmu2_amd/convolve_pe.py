@@ -43,6 +43,9 @@ def _next_pow2(n: int) -> int:
 
 
 class ConvolvePE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py: overlap history carried sample-exactly
+    _STATE_FIELDS = ("_hist", "_last_render_end")
+
     def __init__(self, src: ProcessingElement, fir: ProcessingElement, *, fft_size: int | None = None):
         self._src = src
         self._fir = fir

@@ -260,6 +260,67 @@ __device__ __forceinline__ double block_scan_scalar_affine_wide(double e, const 
     return lam_lane * cw + ex;
 }
 
+// block_excl_sum_wide when every thread contributes the SAME value (a scalar-frequency oscillator on a tile
+// whose frames are all live): every wave's total is the same number, so the folds need no exchange and no
+// barrier.  Same operations in the same order as the exchanging form, hence the same bits.
+template <int NW>
+__device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &sum_carry) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = o + inc;
+    }
+    const double t = readlane_f64(inc, 63);
+    double tot = 0.0, w_local = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        if (w < (wave & (kWaves - 1))) w_local = w_local + t;
+        tot = tot + t;
+    }
+    double base = sum_carry, mine_base = sum_carry;
+#pragma unroll
+    for (int g = 0; g < NW / kWaves; ++g) {
+        if (g == wave / kWaves) mine_base = base;
+        base = base + tot;
+    }
+    sum_carry = base;
+    double ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0.0;
+    return mine_base + (w_local + ex);
+}
+
+// block_scan_scalar_affine_wide with ONE barrier: `lds` holds two images of NW doubles used alternately
+// (`parity` flips on every call), so the readers of one image are separated from its next writer by the
+// barrier of the call in between.
+template <int NW>
+__device__ __forceinline__ double block_scan_scalar_affine_wide1(double e, const double (&lamp)[6], double lam_wave,
+                                                                 double lam_lane, double *lds, int parity,
+                                                                 double &carry) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *img = lds + (parity & 1) * NW;
+    double inc = e;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double o = __shfl_up(inc, 1 << k, 64);
+        if (lane >= (1 << k)) inc = lamp[k] * o + inc;
+    }
+    if (lane == 63) img[wave] = inc;
+    __syncthreads();
+    double cw = carry, cn = carry;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        double t = img[w];
+        if (w < wave) cw = lam_wave * cw + t;
+        cn = lam_wave * cn + t;
+    }
+    carry = cn;
+    double ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0.0;
+    return lam_lane * cw + ex;
+}
+
 // ================================================================================================
 // BiquadPE, constant coefficients
 // ================================================================================================
@@ -783,7 +844,7 @@ constexpr double kPi = 3.141592653589793;
 constexpr int kSawWideWaves = 8;                  // 512-thread form for a handful of oscillators (203 VGPRs: 2 waves per SIMD)
 struct SawShared {
     double sum[kSawWideWaves];
-    double aff[kSawWideWaves];
+    double aff[2 * kSawWideWaves];        // two images: block_scan_scalar_affine_wide1
 };
 
 // Per-sample constants of the Dirichlet kernel derived from the frequency (blit_saw_pe.py:166-173,196).
@@ -906,7 +967,8 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     }
     const int64_t seg_begin = SEG ? (int64_t)first_tile * kTile : 0;
     const int64_t seg_end = SEG ? ((seg_begin + (int64_t)tiles_per_seg * kTile < n) ? seg_begin + (int64_t)tiles_per_seg * kTile : n) : n;
-    for (int64_t base = seg_begin; base < seg_end; base += kTile) {
+    int parity = 0;
+    for (int64_t base = seg_begin; base < seg_end; base += kTile, ++parity) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
         SawConst kc[kSawT];
         // ---- phase increment and inclusive local cumsum (blit_saw_pe.py:188-191) ----
@@ -924,7 +986,10 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             run = run + (live ? kc[j].inc : 0.0);
             loc[j] = run;
         }
-        const double chunk_base = block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
+        // scalar frequency, every frame of the tile live: all threads add the same increments, no exchange
+        const double chunk_base = (!STREAMS && base + kTile <= n)
+                                      ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
+                                      : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
 
         // ---- Dirichlet kernel (blit_saw_pe.py:194-217) ----
         double xb[kSawT];
@@ -949,10 +1014,9 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         double e = 0.0;
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
-        double y = block_scan_scalar_affine_wide<NW>(e, lamp, lam_wave, lam_lane, sh.aff, carry_y);
+        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lam_lane, sh.aff, parity, carry_y);
         if (SEG == 1) {                      // the wave responses the scan just folded are still in LDS
-            if (tid < NW) wsi[2 + (base / kTile) * NW + tid] = sh.aff[tid];
-            __syncthreads();
+            if (tid < NW) wsi[2 + (base / kTile) * NW + tid] = sh.aff[(parity & 1) * NW + tid];
             continue;
         }
 
@@ -983,17 +1047,21 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 // once, as float32(acc * amplitude).  The [instances x voices][frames] intermediate never exists.
 // The per-voice carries (phase sum, integrator level) live in LDS between tiles.  Scalar parameters only.
 constexpr int kSsMaxVoices = 16;
+template <int NW>
 struct SsShared {
-    SawShared scan;
+    double sum[NW];
+    double aff[2 * NW];
     double carry_sum[kSsMaxVoices];
     double carry_y[kSsMaxVoices];
 };
-__global__ void __launch_bounds__(kSawWideWaves * 64)
+// NW = 4: 2048-frame tiles, two workgroups per CU (512 instances fill the chip in one round and one workgroup's
+// barrier waits overlap the other's arithmetic); NW = 8: 4096-frame tiles for fewer instances.  Same bits.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
 k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels, double sr,
                 const pgx_blitsaw_params *params, double *state, const double *amp_scalar) {
-    constexpr int NW = kSawWideWaves;
     constexpr int kTile = NW * 64 * kSawT;
-    __shared__ SsShared sh;
+    __shared__ SsShared<NW> sh;
     const int tid = threadIdx.x, lane = tid & 63;
     const int inst = blockIdx.x;
     const pgx_blitsaw_params *pv = params + (int64_t)inst * nv;
@@ -1005,13 +1073,15 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         sh.carry_y[tid] = sv[tid * 2 + 1];
     }
     __syncthreads();
+    int parity = 0;
     for (int64_t base = 0; base < n; base += kTile) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
+        const bool full = base + kTile <= n;                // uniform: every frame of the tile is live
         double acc[kSawT];
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) acc[j] = 0.0;
 #pragma unroll 1
-        for (int v = 0; v < nv; ++v) {
+        for (int v = 0; v < nv; ++v, ++parity) {
             const pgx_blitsaw_params p = pv[v];
             const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
             const double phase0 = sv[v * 2 + 0];            // rewritten only after the last tile
@@ -1037,7 +1107,8 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 run = run + ((f0 + j < n) ? k0.inc : 0.0);
                 loc[j] = run;
             }
-            const double chunk_base = block_excl_sum_wide<NW>(run, sh.scan.sum, carry_sum);
+            const double chunk_base = full ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
+                                           : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
             double xb[kSawT];
             double final_phase = 0.0, final_y = 0.0;
 #pragma unroll
@@ -1055,7 +1126,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             double e = 0.0;
 #pragma unroll
             for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
-            double y = block_scan_scalar_affine_wide<NW>(e, lamp, lam_wave, lam_lane, sh.scan.aff, carry_y);
+            double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lam_lane, sh.aff, parity, carry_y);
 #pragma unroll
             for (int j = 0; j < kSawT; ++j) {
                 double z = leak * y;
@@ -1071,14 +1142,13 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 sh.carry_sum[v] = carry_sum;
                 sh.carry_y[v] = carry_y;
             }
-            // the next voice's first LDS access is behind block_excl_sum_wide's barrier
         }
         float yf[kSawT];
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) yf[j] = (float)(acc[j] * g);
         store_frames_tiled<kSawT>(ob, f0, n, channels, yf);
-        __syncthreads();                                    // carries written by thread 0 (a bank of one voice
-                                                            // has no other barrier before they are read again)
+        if (nv == 1) __syncthreads();                       // with more voices the carries written above are
+                                                            // read again only after the other voices' barriers
     }
 }
 
@@ -2078,8 +2148,12 @@ int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, in
                   "pgx_supersaw_bank: bad argument");
     PGX_CHECK_ARG(nvoices >= 1 && nvoices <= 16, "pgx_supersaw_bank: 1..16 voices per instance");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_bank: out_stride too small");
-    hipLaunchKernelGGL(k_supersaw_bank, dim3(batch), dim3(kSawWideWaves * 64), 0, pgx::stream(), out, out_stride,
-                       nvoices, n, channels, sample_rate, params, state, amp_scalar);
+    if (batch >= 512)
+        hipLaunchKernelGGL(k_supersaw_bank<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
+                           nvoices, n, channels, sample_rate, params, state, amp_scalar);
+    else
+        hipLaunchKernelGGL(k_supersaw_bank<8>, dim3(batch), dim3(8 * 64), 0, pgx::stream(), out, out_stride,
+                           nvoices, n, channels, sample_rate, params, state, amp_scalar);
     PGX_LAUNCH_CHECK("k_supersaw_bank");
     return PGX_OK;
 }

@@ -28,6 +28,12 @@ class DetectionMode(Enum):
 
 
 class EnvelopePE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py; the RMS detector is block-local (see the condition)
+    _STATE_FIELDS = ("_state", "_state_channels")
+
+    def _look_ahead_condition(self) -> bool:
+        return self._mode == DetectionMode.PEAK
+
     def __init__(self, source: ProcessingElement, attack: float = 0.01, release: float = 0.1,
                  lookahead: float = 0.0, mode: DetectionMode = DetectionMode.PEAK):
         self._source = source

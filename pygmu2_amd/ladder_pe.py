@@ -82,6 +82,9 @@ def ladder_settle_frames(cutoff: float, resonance: float, sample_rate: float, ov
 
 
 class LadderPE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py
+    _STATE_FIELDS = ("_state", "_state_channels")
+
     _DEFAULT_OVERSAMPLE = 2
     _RESONANCE_MULTIPLIER = 1.8
     _MIN_CUTOFF_FREQ = 5.0

@@ -1,0 +1,211 @@
+"""
+Look-ahead for small-block streaming of STATEFUL sub-graphs.
+
+The reference's block loops (benchmarks/profile_biquad_vs_svfilter.py:75-87, audio_renderer.py:171-179,
+utils.py:60-62) pull 1024-frame blocks.  A filter graph at that size is a chain of dependent launches, each
+little more than its latency: six of them cost about 25 us per block however fast each kernel is.  The
+filters, oscillators and envelopes here produce the same samples however a stream is cut into blocks (their
+state is carried sample-exactly), so when a sub-graph is pulled sequentially in small blocks its top PE
+renders up to `AHEAD_BLOCKS` blocks (about `AHEAD_FRAMES` frames) in one go and hands the caller row views
+of that resident window -- the same samples, 1/64 of the launches.
+
+What that must not change is what the caller can observe between blocks.  Before a window is rendered the
+state of every stateful PE under it is snapshot (device blobs copied device-to-device, host-side fields by
+value).  While the caller keeps pulling the next block, blocks are served from the window.  Anything else --
+a seek, a pull of a PE inside the sub-graph, reset_state / on_start / on_stop anywhere in it -- first
+`settle`s the window: the snapshot is restored and the part of the window the caller has actually consumed
+is rendered again (output discarded), which leaves every state exactly where block-by-block rendering
+would have left it; then the request takes the normal path.
+
+A PE takes part when its class says so: `_LOOK_AHEAD_SAFE = True` promises block-partition invariance and
+lists the mutable fields in `_STATE_FIELDS` (DeviceBuffers are copied, everything else is taken by value);
+pure PEs qualify through read_ahead's allow-list.  `_look_ahead_condition()` may veto per instance.  One PE
+that does not qualify anywhere below keeps the whole sub-graph on the block-by-block path.
+Disable with PYGMU_LOOK_AHEAD=0.
+"""
+
+from __future__ import annotations
+
+import os
+import threading
+
+import numpy as np
+
+from . import read_ahead as _read_ahead
+
+SMALL_BLOCK = 65536         # pulls up to this many frames are served from a look-ahead window
+AHEAD_BLOCKS = 64           # at most this many blocks per window ...
+AHEAD_FRAMES = 1 << 19      # ... and about this many frames (44 100-frame pulls: 11 blocks per window)
+
+_tls = threading.local()
+_ENABLED = os.environ.get("PYGMU_LOOK_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")
+
+
+def enabled() -> bool:
+    return _ENABLED
+
+
+def set_enabled(flag: bool) -> None:
+    global _ENABLED
+    _ENABLED = bool(flag)
+
+
+def _busy() -> bool:
+    return getattr(_tls, "busy", False)
+
+
+def _subtree(pe, seen, out):
+    if id(pe) in seen:
+        return
+    seen.add(id(pe))
+    out.append(pe)
+    for child in pe.inputs():
+        _subtree(child, seen, out)
+
+
+def _node_ok(pe) -> bool:
+    stateful_ok = bool(getattr(pe, "_LOOK_AHEAD_SAFE", False))
+    pure_ok = bool(getattr(pe, "_READ_AHEAD_SAFE", False)) and pe.is_pure()
+    if not (stateful_ok or pure_ok):
+        return False
+    if pure_ok and not stateful_ok:
+        cond = getattr(pe, "_read_ahead_condition", None)
+        if cond is not None and not cond():
+            return False
+    cond = getattr(pe, "_look_ahead_condition", None)
+    return True if cond is None else bool(cond())
+
+
+def capable(pe) -> bool:
+    """The sub-graph under `pe` carries state and every PE in it qualifies (cached on the instance)."""
+    cached = pe.__dict__.get("_la_ok")
+    if cached is None:
+        nodes = []
+        _subtree(pe, set(), nodes)
+        cached = (all(_node_ok(n) for n in nodes)
+                  and any(getattr(n, "_STATE_FIELDS", None) is not None for n in nodes)
+                  and not _read_ahead.eligible(pe))
+        pe.__dict__["_la_ok"] = cached
+    return cached
+
+
+# ------------------------------------------------------------------------------------ snapshots
+def _copy_value(value):
+    from .device import DeviceBuffer, check, ensure_init
+    if isinstance(value, DeviceBuffer):
+        twin = DeviceBuffer(value.shape, value.dtype)
+        if value.nbytes:
+            check(ensure_init().pgx_memcpy_d2d(twin.ptr, value.ptr, value.nbytes), "pgx_memcpy_d2d")
+        return twin
+    if isinstance(value, np.ndarray):
+        return value.copy()
+    if isinstance(value, (list, dict, set)):
+        return type(value)(value)
+    return value                      # numbers, None, tuples, enums: immutable
+
+
+def take_snapshot(nodes):
+    snap = []
+    for pe in nodes:
+        fields = getattr(pe, "_STATE_FIELDS", None)
+        if fields:
+            snap.append((pe, {name: _copy_value(getattr(pe, name)) for name in fields}))
+    return snap
+
+
+def restore_snapshot(snap) -> None:
+    """Single use: the saved copies themselves become the PEs' state."""
+    for pe, fields in snap:
+        for name, value in fields.items():
+            setattr(pe, name, value)
+
+
+# ------------------------------------------------------------------------------------ windows
+class _Window:
+    __slots__ = ("first", "end", "buf", "served", "snap", "nodes")
+
+
+def render(pe, start: int, duration: int):
+    """Serve (start, duration) from the PE's window, or open one when the pull continues the previous
+    one.  None: the request takes the normal path (any window has been settled by then)."""
+    if not _ENABLED or _busy():
+        return None
+    d = pe.__dict__
+    owner = d.get("_la_owner")
+    if owner is not None:                             # pulled directly while inside somebody's window
+        settle(owner)
+    win = d.get("_la_win")
+    if win is not None:
+        if start == win.served and start + duration <= win.end:
+            win.served = start + duration
+            from .snippet import Snippet
+            return Snippet.window_rows(start, win.buf, start - win.first, duration)
+        settle(pe)
+    if duration > SMALL_BLOCK or not capable(pe):
+        return None
+    sequential = d.get("_la_last") == start
+    d["_la_last"] = start + duration
+    if not sequential:
+        return None
+    from .snippet import Snippet
+    nodes = []
+    _subtree(pe, set(), nodes)
+    for n in nodes:                                   # a window below (opened while this PE was pulled one
+        if n is not pe and n.__dict__.get("_la_win") is not None:      # level down) is closed first
+            settle(n)
+    snap = take_snapshot(nodes)
+    _tls.busy = True
+    try:
+        big = pe._render(start, duration * max(2, min(AHEAD_BLOCKS, AHEAD_FRAMES // duration)))
+    finally:
+        _tls.busy = False
+    if not big.on_device:                             # host-side graph: nothing to gain, nothing was assumed
+        restore_snapshot(snap)
+        _tls.busy = True
+        try:
+            return pe._render(start, duration)
+        finally:
+            _tls.busy = False
+    win = _Window()
+    win.first, win.end, win.buf = start, start + big.duration, big.dev
+    win.served, win.snap, win.nodes = start + duration, snap, nodes
+    d["_la_win"] = win
+    for n in nodes:
+        if n is not pe:
+            n.__dict__["_la_owner"] = pe
+    return Snippet.window_rows(start, win.buf, 0, duration)
+
+
+def settle(owner) -> None:
+    """Close `owner`'s window: every state under it goes to where the consumed part of the window ends."""
+    win = owner.__dict__.pop("_la_win", None)
+    if win is None:
+        return
+    for n in win.nodes:
+        if n.__dict__.get("_la_owner") is owner:
+            del n.__dict__["_la_owner"]
+    if win.served >= win.end:
+        return                                        # consumed to the last frame: the states are already there
+    restore_snapshot(win.snap)
+    if win.served > win.first:
+        was = _busy()
+        _tls.busy = True
+        try:
+            owner._render(win.first, win.served - win.first)
+        finally:
+            _tls.busy = was
+
+
+def before_direct_access(pe) -> None:
+    """Called (outside a look-ahead render) when a PE inside somebody's window is pulled or reset itself."""
+    if _busy():
+        return
+    owner = pe.__dict__.get("_la_owner")
+    if owner is not None:
+        settle(owner)
+    if pe.__dict__.get("_la_win") is not None:
+        settle(pe)
+
+
+def forget(pe) -> None:
+    pe.__dict__.pop("_la_last", None)

@@ -68,6 +68,9 @@ class MixPE(ProcessingElement):
         # the skip rule below looks at the requested window; with bounded inputs a larger window changes it
         return all(pe.extent().start is None and pe.extent().end is None for pe in self._inputs)
 
+    def _look_ahead_condition(self) -> bool:
+        return not self._voice_bank()      # a bank keeps its voices' states in its own nodes: not snapshot
+
     def _render(self, start: int, duration: int) -> Snippet:
         bank = self._voice_bank()
         if bank:

@@ -24,6 +24,8 @@ from .snippet import Snippet
 
 class PeriodicGate(GateSignal):
     _READ_AHEAD_SAFE = True
+    _LOOK_AHEAD_SAFE = True            # PE-driven parameters: carried phase
+    _STATE_FIELDS = ("_state", "_last_render_end")
 
     _TRUSTED_DOMAIN = True          # the kernel emits exactly 0.0f or 1.0f
 

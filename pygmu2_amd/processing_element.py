@@ -21,11 +21,16 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import device as _dev
+from . import look_ahead as _look_ahead
 from . import read_ahead as _read_ahead
 from .config import get_sample_rate, handle_error
 from .diagnostics import is_enabled, pull_count_enabled, record_pull, record_timing, timing_enabled
 from .extent import Extent
 from .snippet import Snippet
+
+
+_RA_LIMIT = _read_ahead.SMALL_BLOCK
+_LA_LIMIT = _look_ahead.SMALL_BLOCK
 
 
 class ProcessingElement(ABC):
@@ -78,10 +83,24 @@ class ProcessingElement(ABC):
             return out
         # pure sub-graphs, sequential small pulls (the verdict of read_ahead.eligible is cached on the instance:
         # a PE that is not eligible skips the call altogether)
-        if duration <= _read_ahead.SMALL_BLOCK and self.__dict__.get("_ra_ok", True):
-            ahead = _read_ahead.render(self, start, duration)
-            if ahead is not None:
-                return ahead
+        if duration <= _RA_LIMIT:
+            d = self.__dict__
+            win = d.get("_ra_win")                       # resident window of a pure sub-graph: (first, end, buffer)
+            if win is not None and win[0] <= start and start + duration <= win[1]:
+                d["_ra_last"] = start + duration
+                return Snippet.window_rows(start, win[2], start - win[0], duration)
+            if d.get("_ra_ok", True):
+                ahead = _read_ahead.render(self, start, duration)
+                if ahead is not None:
+                    return ahead
+            # stateful sub-graphs pulled in small sequential blocks (look_ahead.py); a PE inside somebody's
+            # window, or holding one, always goes through it so that the window is settled first
+            if (duration <= _LA_LIMIT and d.get("_la_ok", True)) or "_la_win" in d or "_la_owner" in d:
+                ahead = _look_ahead.render(self, start, duration)
+                if ahead is not None:
+                    return ahead
+        elif "_la_win" in self.__dict__ or "_la_owner" in self.__dict__:
+            _look_ahead.before_direct_access(self)
         return self._render(start, duration)
 
     @abstractmethod
@@ -117,18 +136,23 @@ class ProcessingElement(ABC):
 
     # ------------------------------------------------------------------ lifecycle
     def on_start(self) -> None:
+        _look_ahead.before_direct_access(self)
+        _look_ahead.forget(self)
         _read_ahead.forget(self)
         hook = getattr(self, "_on_start", None)
         if hook is not None:
             hook()
 
     def on_stop(self) -> None:
+        _look_ahead.before_direct_access(self)
+        _look_ahead.forget(self)
         _read_ahead.forget(self)
         hook = getattr(self, "_on_stop", None)
         if hook is not None:
             hook()
 
     def reset_state(self) -> None:
+        _look_ahead.before_direct_access(self)
         hook = getattr(self, "_reset_state", None)
         if hook is not None:
             hook()

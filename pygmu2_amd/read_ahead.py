@@ -22,8 +22,9 @@ from __future__ import annotations
 import os
 import threading
 
-SMALL_BLOCK = 4096          # requests up to this many frames are considered "small"
-AHEAD_BLOCKS = 64           # how many blocks one refill renders
+SMALL_BLOCK = 65536         # requests up to this many frames are served from a resident window
+AHEAD_BLOCKS = 64           # at most this many blocks per refill ...
+AHEAD_FRAMES = 1 << 19      # ... and about this many frames (a 44 100-frame pull refills 11 blocks at a time)
 
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_READ_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")
@@ -51,35 +52,41 @@ def eligible(pe) -> bool:
     return cached
 
 
+def ahead_blocks(duration: int) -> int:
+    return max(2, min(AHEAD_BLOCKS, AHEAD_FRAMES // max(1, duration)))
+
+
 def render(pe, start: int, duration: int):
     """Serve (start, duration) from the PE's resident window, refilling it when the pull is
-    sequential.  Returns None when the request should take the normal path."""
+    sequential.  Returns None when the request should take the normal path.
+
+    Instance state: `_ra_win` = (first frame, end frame, DeviceBuffer) of the resident window (device
+    windows only; ProcessingElement.render serves hits from it directly), `_ra_last` = where the previous
+    pull ended."""
     if not _ENABLED or duration > SMALL_BLOCK or getattr(_tls, "busy", False) or not eligible(pe):
         return None
     from .snippet import Snippet
-    st = pe.__dict__.get("_ra_state")
-    if st is not None:
-        w_start, w_snip, last_end = st
-        if start >= w_start and start + duration <= w_start + w_snip.duration and w_snip.on_device:
-            pe.__dict__["_ra_state"] = (w_start, w_snip, start + duration)
-            return Snippet(start, w_snip.dev.rows(start - w_start, duration))
-        sequential = (last_end == start)
-    else:
-        sequential = False
+    d = pe.__dict__
+    win = d.get("_ra_win")
+    if win is not None and win[0] <= start and start + duration <= win[1]:
+        d["_ra_last"] = start + duration
+        return Snippet.window_rows(start, win[2], start - win[0], duration)
+    sequential = d.get("_ra_last") == start
+    d["_ra_last"] = start + duration
     if not sequential:
-        # first pull / random access: render normally, remember where it ended
-        pe.__dict__["_ra_state"] = (start, Snippet.from_zeros(start, 0, 1), start + duration)
-        return None
+        return None             # first pull / random access: render normally, remember where it ended
     _tls.busy = True
     try:
-        big = pe._render(start, duration * AHEAD_BLOCKS)
+        big = pe._render(start, duration * ahead_blocks(duration))
     finally:
         _tls.busy = False
-    pe.__dict__["_ra_state"] = (start, big, start + duration)
     if not big.on_device:
+        d.pop("_ra_win", None)
         return Snippet(start, big.data[:duration])
-    return Snippet(start, big.dev.rows(0, duration))
+    d["_ra_win"] = (start, start + big.duration, big.dev)
+    return Snippet.window_rows(start, big.dev, 0, duration)
 
 
 def forget(pe) -> None:
-    pe.__dict__.pop("_ra_state", None)
+    pe.__dict__.pop("_ra_win", None)
+    pe.__dict__.pop("_ra_last", None)

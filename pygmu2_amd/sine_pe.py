@@ -21,6 +21,8 @@ from .snippet import Snippet
 
 class SinePE(ProcessingElement):
     _READ_AHEAD_SAFE = True
+    _LOOK_AHEAD_SAFE = True            # stateful path: the carried phase is sample-exact
+    _STATE_FIELDS = ("_state",)
 
     def __init__(self, frequency=440.0, amplitude=1.0, phase=0.0, channels: int = 1):
         self._frequency = frequency

@@ -22,12 +22,13 @@ from .device import DeviceBuffer
 
 
 class Snippet:
-    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready", "_copy")
+    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready", "_copy", "_base")
 
     def __init__(self, start: int, data, ready=None):
         self._start = int(start)
         self._ready = ready
         self._copy = None
+        self._base = None
         if isinstance(data, DeviceBuffer):
             if data.dtype != np.float32 or len(data.shape) != 2:
                 raise ValueError("device payload must be float32 of shape (frames, channels)")
@@ -45,6 +46,20 @@ class Snippet:
         self._host = data
         self._dev = None
         self._shape = data.shape
+
+    @classmethod
+    def window_rows(cls, start: int, window: DeviceBuffer, first_row: int, rows: int) -> "Snippet":
+        """`rows` frames of a resident (frames, channels) window, starting at `first_row`: what read-ahead hands
+        out per small block.  The DeviceBuffer view is only built if somebody asks for `.dev` / `.data`."""
+        self = object.__new__(cls)
+        self._start = start
+        self._ready = None
+        self._copy = None
+        self._host = None
+        self._dev = None
+        self._base = (window, first_row)
+        self._shape = (rows, window.shape[1])
+        return self
 
     @property
     def start(self) -> int:
@@ -81,8 +96,7 @@ class Snippet:
         `.data` will block only for what is left of the copy.  For callers that read every block
         (benchmark_pes.py:176-185): render block k+1, then read block k."""
         if self._host is None and self._copy is None and self._shape[0]:
-            self._resolve()
-            self._host, self._copy = self._dev.begin_to_host()
+            self._host, self._copy = self.dev.begin_to_host()
         return self
 
     @property
@@ -105,12 +119,16 @@ class Snippet:
         """Device payload (uploads a host-built snippet once)."""
         self._resolve()
         if self._dev is None:
-            self._dev = DeviceBuffer.from_host(np.ascontiguousarray(self._host))
+            if self._base is not None:
+                window, first_row = self._base
+                self._dev = window.rows(first_row, self._shape[0])
+            else:
+                self._dev = DeviceBuffer.from_host(np.ascontiguousarray(self._host))
         return self._dev
 
     @property
     def on_device(self) -> bool:
-        return self._dev is not None
+        return self._dev is not None or self._base is not None
 
     @classmethod
     def from_zeros(cls, start: int, duration: int, channels: int = 1) -> "Snippet":

@@ -24,6 +24,9 @@ from .snippet import Snippet
 
 
 class SuperSawPE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py
+    _STATE_FIELDS = ("_state", "_last_render_end")
+
     MIX_EQUAL = "equal"
     MIX_CENTER_HEAVY = "center_heavy"
     MIX_LINEAR = "linear"

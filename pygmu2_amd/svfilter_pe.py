@@ -73,6 +73,9 @@ def svf_coefficients(mode: BiquadMode, freq: float, q: float, gain_db: float, sa
 
 
 class SVFilterPE(ProcessingElement):
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py
+    _STATE_FIELDS = ("_state", "_state_channels")
+
     def __init__(self, source: ProcessingElement, frequency, q,
                  mode: BiquadMode = BiquadMode.LOWPASS, gain_db: float = 0.0):
         if mode == BiquadMode.ALLPASS:

@@ -26,6 +26,11 @@ from .snippet import Snippet
 
 
 class TransformPE(ProcessingElement):
+    _READ_AHEAD_SAFE = True            # named element-wise chains only (see the condition)
+
+    def _read_ahead_condition(self) -> bool:
+        return self._lowered is not None
+
     def __init__(self, source: ProcessingElement, func: Callable[[np.ndarray], np.ndarray],
                  name: str | None = None):
         self._source = source

@@ -1,0 +1,178 @@
+"""GPU: look-ahead of stateful sub-graphs (pygmu2_amd/look_ahead.py).  Whatever the caller does between blocks --
+keep streaming, seek, change the block size, reset or pull a PE inside the graph, stop and restart -- samples
+and carried states are the ones block-by-block rendering produces (within the filters' partition tolerance;
+exactly for the bit-exact PEs), and both agree with the CPU oracle."""
+
+import numpy as np
+import pytest
+
+import pygmu2_amd as pg
+from pygmu2_amd import look_ahead, transforms as tf
+
+pytestmark = pytest.mark.gpu
+
+SR = 44100
+
+
+def autowah(kind="biquad"):
+    src = pg.SinePE(frequency=220.0, amplitude=0.8)
+    env = pg.EnvelopePE(src, attack=0.005, release=0.05, mode=pg.DetectionMode.PEAK)
+    ctl = pg.TransformPE(env, func=tf.Chain(tf.Clip(0.0, 1.0), tf.Sqrt(), tf.Affine(2900.0, 100.0)), name="ctl")
+    flt = (pg.BiquadPE if kind == "biquad" else pg.SVFilterPE)(src, frequency=ctl, q=10.0, mode=pg.BiquadMode.LOWPASS)
+    root = pg.CropPE(pg.GainPE(flt, gain=1.0), 0, 8 * SR)
+    return root, {"filter": flt, "env": env}
+
+
+def c2():
+    flt = pg.BiquadPE(pg.SinePE(frequency=440.0), frequency=1000.0, q=0.707)
+    return flt, {"filter": flt}
+
+
+def voice():
+    osc = pg.BlitSawPE(110.0)
+    flt = pg.BiquadPE(osc, frequency=2000.0, q=0.707)
+    env = pg.AdsrGatedPE(pg.PeriodicGate(7.0, 0.5), 0.01, 0.02, 0.7, 0.03)
+    root = pg.GainPE(flt, gain=env)
+    return root, {"filter": flt, "osc": osc, "env": env}
+
+
+def comb_ladder():
+    osc = pg.SuperSawPE(98.0, voices=3, seed=5)
+    lad = pg.LadderPE(osc, frequency=1200.0, resonance=0.3, oversample=2)
+    comb = pg.CombPE(lad, frequency=440.0, feedback=0.6)
+    return comb, {"filter": lad, "osc": osc, "comb": comb}
+
+
+def conv():
+    h = (np.random.default_rng(1).standard_normal(300) * np.exp(-np.arange(300) / 60.0)).astype(np.float32)
+    c = pg.ConvolvePE(pg.SinePE(330.0, channels=2), pg.ArrayPE(h))
+    return c, {"filter": c}
+
+
+GRAPHS = {"autowah_biquad": lambda: autowah("biquad"), "autowah_svf": lambda: autowah("svf"), "c2": c2,
+          "voice": voice, "comb_ladder": comb_ladder, "conv": conv}
+TOL = {"conv": 5e-6}          # the float32 MFMA accumulation groups its taps by block
+
+
+def run(make, script, ahead):
+    """script: ("r", start, n) render | ("reset", name) | ("inner", name, start, n) | ("restart",)."""
+    look_ahead.set_enabled(ahead)
+    try:
+        pg.set_sample_rate(SR)
+        root, named = make()
+        r = pg.NullRenderer(SR)
+        r.set_source(root)
+        r.start()
+        out = []
+        for step in script:
+            if step[0] == "r":
+                out.append(root.render(step[1], step[2]).data.copy())
+            elif step[0] == "reset":
+                named[step[1]].reset_state()
+            elif step[0] == "inner":
+                out.append(named[step[1]].render(step[2], step[3]).data.copy())
+            elif step[0] == "restart":
+                r.stop()
+                r.start()
+        r.stop()
+        return out, root
+    finally:
+        look_ahead.set_enabled(True)
+
+
+def close(a, b, tol=2e-6):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape, i
+        peak = max(float(np.max(np.abs(y))), 1e-3)
+        err = float(np.max(np.abs(x.astype(np.float64) - y)))
+        assert err <= tol * peak, (i, err, peak)
+
+
+STREAM = [("r", i * 1024, 1024) for i in range(150)]
+SCRIPTS = {
+    "stream": STREAM,
+    "seek_back_and_forth": STREAM[:10] + [("r", 3000, 512), ("r", 3512, 512), ("r", 4024, 512), ("r", 100000, 777),
+                                           ("r", 100777, 777), ("r", 101554, 777), ("r", 0, 64)],
+    "ragged_blocks": [("r", s, n) for s, n in zip(np.cumsum([0] + [17, 23, 19, 41, 7, 93] * 40)[:-1],
+                                                  [17, 23, 19, 41, 7, 93] * 40)],
+    "reset_inside": STREAM[:7] + [("reset", "filter")] + [("r", (7 + i) * 1024, 1024) for i in range(70)],
+    "inner_pull": STREAM[:5] + [("inner", "filter", 5 * 1024, 300)] + [("r", 5 * 1024 + 300 + i * 1024, 1024)
+                                                                     for i in range(5)],
+    "restart": STREAM[:9] + [("restart",)] + STREAM[:9],
+    "block_44100": [("r", i * 44100, 44100) for i in range(14)] + [("r", 5, 44100)],
+}
+
+
+@pytest.mark.parametrize("script", sorted(SCRIPTS))
+@pytest.mark.parametrize("graph", sorted(GRAPHS))
+def test_look_ahead_is_invisible(graph, script):
+    if graph == "conv" and script == "inner_pull":
+        pytest.skip("the ConvolvePE is the root of that graph")
+    steps = SCRIPTS[script]
+    got, root = run(GRAPHS[graph], steps, ahead=True)
+    assert look_ahead.capable(root), "the graph was expected to take the look-ahead path"
+    want, _ = run(GRAPHS[graph], steps, ahead=False)
+    close(got, want, TOL.get(graph, 2e-6))
+
+
+def test_streams_really_come_from_windows_and_states_roll_back():
+    pg.set_sample_rate(SR)
+    flt, _ = c2()
+    r = pg.NullRenderer(SR)
+    r.set_source(flt)
+    r.start()
+    for i in range(5):
+        flt.render(i * 1024, 1024)
+    win = flt.__dict__.get("_la_win")
+    assert win is not None and win.first == 1024 and win.end == 1024 + 64 * 1024 and win.served == 5 * 1024
+    ahead_state = flt._state.to_host().copy()             # the state 64 blocks ahead
+    look_ahead.settle(flt)
+    assert "_la_win" not in flt.__dict__
+    settled = flt._state.to_host().copy()
+    r.stop()
+    ref, _ = c2()
+    look_ahead.set_enabled(False)
+    try:
+        r2 = pg.NullRenderer(SR)
+        r2.set_source(ref)
+        r2.start()
+        for i in range(5):
+            ref.render(i * 1024, 1024)
+        want = ref._state.to_host().copy()
+        r2.stop()
+    finally:
+        look_ahead.set_enabled(True)
+    assert not np.allclose(ahead_state, want)
+    assert np.allclose(settled, want, rtol=1e-9, atol=1e-12)
+
+
+def test_graphs_that_must_not_look_ahead():
+    pg.set_sample_rate(SR)
+    src = pg.SinePE(220.0)
+    assert not look_ahead.capable(pg.GainPE(src, 0.5))                               # pure: read-ahead's business
+    assert not look_ahead.capable(pg.EnvelopePE(src, mode=pg.DetectionMode.RMS))     # block-local RMS window
+    assert not look_ahead.capable(pg.TransformPE(pg.BiquadPE(src, 500.0, 1.0), func=lambda x: x * 2.0))
+    assert not look_ahead.capable(pg.CompressorPE(src))                              # CachePE inside
+    bank = pg.MixPE(*[pg.BlitSawPE(100.0 + i) for i in range(6)])
+    assert not look_ahead.capable(bank)                                              # voice bank keeps its own states
+    assert look_ahead.capable(pg.MixPE(pg.BlitSawPE(100.0), pg.BlitSawPE(150.0)))
+
+
+def test_autowah_matches_the_oracle_through_look_ahead():
+    from oracle import graph_eval
+    from oracle.golden_cases import S
+    pg.set_sample_rate(SR)
+    root, _ = autowah("biquad")
+    r = pg.NullRenderer(SR)
+    r.set_source(root)
+    r.start()
+    got = np.concatenate([root.render(i * 1024, 1024).data for i in range(40)])
+    r.stop()
+    src = S("SinePE", frequency=220.0, amplitude=0.8)
+    env = S("EnvelopePE", source=src, attack=0.005, release=0.05, mode="peak")
+    ctl = S("TransformPE", source=env, ops=[["clip", 0.0, 1.0], ["sqrt"], ["affine", 2900.0, 100.0]])
+    g = graph_eval.Node(S("GainPE", source=S("BiquadPE", source=src, frequency=ctl, q=10.0, mode="lowpass"),
+                          gain=1.0), SR)
+    want = np.concatenate([g.render(i * 1024, 1024) for i in range(40)])
+    assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))

@@ -4,8 +4,9 @@ The reference's own throughput suite, benchmarks/benchmark_pes.py (:149-196 prot
 for every config whose PEs exist here: 5 warm-up + 50 timed contiguous renders of 44 100 frames through a
 started NullRenderer graph; Msamples/s = frames per render / mean render time.
 
-Two device figures per config: "sync" waits for the stream after every render (the latency a caller that
-reads each block sees), "pipelined" waits once after the 50 renders (the offline rate).  With `cpu` the
+Three device figures per config: "sync" waits for the stream after every render (the latency a caller that
+reads each block sees), "pipelined" waits once after the 50 renders (the offline rate), and the pipelined rate
+with read-ahead / look-ahead switched off (every render its own launch sequence).  With `cpu` the
 oracle's restatement of the reference is timed on this host for the same graph, same protocol, 1 thread.
 
     python tools/bench_suite.py [cpu] > profiles/<name>.md
@@ -56,36 +57,50 @@ CONFIGS = [
 MISSING = ["RandomPE x3 (random_pe.py is disabled in the reference: the import fails there too)"]
 
 
-def device_rates(spec):
+def device_rates(spec, modes=("sync", "pipelined", "block_by_block")):
+    """Msamples/s of one config under the reference's protocol.
+    sync: wait for the device after every render; pipelined: wait once after the 50 renders; block_by_block:
+    pipelined with read-ahead / look-ahead switched off (every render is its own launch sequence).
+    The timed renders start away from the warm-up renders, so every frame of the timed region is rendered
+    inside it (a look-ahead window opened during the warm-up is never served from)."""
     import pygmu2_amd as pg
-    from pygmu2_amd import device
+    from pygmu2_amd import device, look_ahead, read_ahead
     import spec_build
     pg.set_sample_rate(SR)
-    out = []
-    for sync_each in (True, False):
-        pe = spec_build.build(spec)
-        r = pg.NullRenderer(sample_rate=SR)
-        r.set_source(pe)
-        r.start()
-        for i in range(WARM):
-            keep = pe.render(i * N, N)
-        device.synchronize()
-        if sync_each:
-            times = []
-            for i in range(RUNS):
-                t0 = time.perf_counter()
-                keep = pe.render((WARM + i) * N, N)
-                device.synchronize()
-                times.append(time.perf_counter() - t0)
-            mean = float(np.mean(times))
-        else:
-            t0 = time.perf_counter()
-            for i in range(RUNS):
-                keep = pe.render((WARM + i) * N, N)
+    out = {}
+    for mode in modes:
+        ahead = mode != "block_by_block"
+        look_ahead.set_enabled(ahead)
+        read_ahead.set_enabled(ahead)
+        try:
+            pe = spec_build.build(spec)
+            r = pg.NullRenderer(sample_rate=SR)
+            r.set_source(pe)
+            r.start()
+            for i in range(WARM):
+                keep = pe.render(i * N, N)
             device.synchronize()
-            mean = (time.perf_counter() - t0) / RUNS
-        r.stop()
-        out.append(N / mean / 1e6)
+            first = (WARM + 1000) * N
+            if mode == "sync":
+                times = []
+                for i in range(RUNS):
+                    t0 = time.perf_counter()
+                    keep = pe.render(first + i * N, N)
+                    device.synchronize()
+                    times.append(time.perf_counter() - t0)
+                mean = float(np.mean(times))
+            else:
+                t0 = time.perf_counter()
+                for i in range(RUNS):
+                    keep = pe.render(first + i * N, N)
+                keep.dev
+                device.synchronize()
+                mean = (time.perf_counter() - t0) / RUNS
+            r.stop()
+        finally:
+            look_ahead.set_enabled(True)
+            read_ahead.set_enabled(True)
+        out[mode] = N / mean / 1e6
     return out
 
 
@@ -111,16 +126,17 @@ def main():
     with_cpu = "cpu" in sys.argv[1:]
     print("# benchmark_pes.py suite on MI355X (44 100-frame renders, 5 warm-up + 50 timed, Msamples/s)\n")
     print("Protocol and configs: reference `benchmarks/benchmark_pes.py:149-196, 257-383`; made by `tools/bench_suite.py`.\n")
-    head = "| config | device, sync per render | device, pipelined |"
-    sep = "|---|---|---|"
+    head = "| config | device, sync per render | device, pipelined | pipelined, look-ahead off |"
+    sep = "|---|---|---|---|"
     if with_cpu:
         head += " CPU oracle, 1 thread | pipelined / CPU |"
         sep += "---|---|"
     print(head)
     print(sep)
     for name, spec in CONFIGS:
-        s, p = device_rates(spec)
-        row = f"| {name} | {s:.0f} | {p:.0f} |"
+        rates = device_rates(spec)
+        s, p = rates["sync"], rates["pipelined"]
+        row = f"| {name} | {s:.0f} | {p:.0f} | {rates['block_by_block']:.0f} |"
         if with_cpu:
             c = cpu_rate(spec)
             row += f" {c:.1f} | {p / c:.0f}x |"
