@@ -47,80 +47,85 @@ __device__ __forceinline__ cplx twiddle(int64_t m, double inv_n) {
     return cplx{cs, -sn};
 }
 
-// Forward DFT of TILE/M sequences of length M = 2^lm stored at buf[s*stride + i], in place, natural
-// order in and out.  tw[p] = W_M^p.  All 256 threads take part; ends with a barrier.
-template <int TILE>
-__device__ void lds_fft(cplx *buf, const cplx *tw, int lm, int stride) {
-    const int tid = threadIdx.x;
-    constexpr int U4 = TILE / 4 / kFBlock;                     // radix-4 butterflies per thread
-    constexpr int U2 = TILE / 2 / kFBlock;                     // radix-2 butterflies per thread
-    for (int lns = 0; lns < lm;) {
-        const int Ns = 1 << lns;
+// Per-stage twiddle tables in LDS.  A radix-4 stage with sub-transform length Ns needs W_{4Ns}^(k*t), k < Ns,
+// t = 1..3; read from the one table W_M^p they sit (k*t) << (lm-2-lns) apart -- up to 16 lanes on the same
+// banks.  Laid out per stage as [t][k] the lanes of a wave read consecutive words:
+//   radix-4 stage Ns:  st[(Ns - 1) + (t - 1) * Ns + k]          (the stages before it hold 4^s - 1 = Ns - 1 entries)
+//   final radix-2 stage (odd lm), Ns = M/2:  st[(Ns - 1) + k] = W_M^k
+// M - 1 entries in all.  Filled from the global table g[p] = W_M^p.
+__device__ __forceinline__ void fill_stage_twiddles(cplx *st, const cplx *g, int lm) {
+    const int M = 1 << lm;
+    for (int e = threadIdx.x; e < M - 1; e += kFBlock) {
+        // stage of entry e: the largest Ns = 4^s with Ns - 1 <= e
+        int lns = (31 - __builtin_clz(e + 1)) & ~1;
+        if (lns > lm - 1) lns = lm - 1;                           // (cannot happen for e < M - 1; keeps lns in range)
+        const int Ns = 1 << lns, r = e - (Ns - 1);
+        int p;
         if (lm - lns >= 2) {
-            const int lq = lm - 2, q = 1 << lq;                    // butterflies per sequence
-            cplx r[U4][4];
-#pragma unroll
-            for (int u = 0; u < U4; ++u) {
-                const int w = tid + u * kFBlock;
-                const int s = w >> lq, j = w & (q - 1);
-                const int k = j & (Ns - 1);
-                const cplx *b = buf + s * stride;
-                const int step = k << (lq - lns);                  // W_{4Ns}^(k*t) = W_M^(step*t)
-                const cplx a = b[j];
-                const cplx c1 = cmul(b[j + q], tw[step]);
-                const cplx c2 = cmul(b[j + 2 * q], tw[2 * step]);
-                const cplx c3 = cmul(b[j + 3 * q], tw[3 * step]);
-                const cplx s0 = cadd(a, c2), s1 = csub(a, c2), s2 = cadd(c1, c3), s3 = mul_neg_i(csub(c1, c3));
-                r[u][0] = cadd(s0, s2);
-                r[u][1] = cadd(s1, s3);
-                r[u][2] = csub(s0, s2);
-                r[u][3] = csub(s1, s3);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < U4; ++u) {
-                const int w = tid + u * kFBlock;
-                const int s = w >> lq, j = w & (q - 1);
-                const int k = j & (Ns - 1);
-                cplx *b = buf + s * stride + (j - k) * 4 + k;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) b[t * Ns] = r[u][t];
-            }
-            __syncthreads();
-            lns += 2;
+            const int t = r >> lns, k = r & (Ns - 1);             // t = 0..2 -> W^(k*(t+1))
+            p = (k * (t + 1)) << (lm - 2 - lns);
         } else {
-            const int lq = lm - 1, q = 1 << lq;
-            cplx r[U2][2];
-#pragma unroll
-            for (int u = 0; u < U2; ++u) {
-                const int w = tid + u * kFBlock;
-                const int s = w >> lq, j = w & (q - 1);
-                const int k = j & (Ns - 1);
-                const cplx *b = buf + s * stride;
-                const cplx a = b[j];
-                const cplx c1 = cmul(b[j + q], tw[k << (lq - lns)]);
-                r[u][0] = cadd(a, c1);
-                r[u][1] = csub(a, c1);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < U2; ++u) {
-                const int w = tid + u * kFBlock;
-                const int s = w >> lq, j = w & (q - 1);
-                const int k = j & (Ns - 1);
-                cplx *b = buf + s * stride + (j - k) * 2 + k;
-                b[0] = r[u][0];
-                b[Ns] = r[u][1];
-            }
-            __syncthreads();
-            lns += 1;
+            p = r;                                                // radix-2: W_M^k
         }
+        st[e] = g[p];
     }
 }
 
-__device__ __forceinline__ void fill_twiddles(cplx *tw, int M) {
-    const double inv = 1.0 / (double)M;
-    for (int p = threadIdx.x; p < M; p += kFBlock) tw[p] = twiddle(p, inv);
+// Forward DFT of TILE/M sequences of length M = 2^lm stored at a[s*stride + i], natural order in and out.
+// Stockham autosort between two LDS images (`a` holds the input, `b` is scratch): one barrier per stage.
+// `st`: the stage tables above.  All 256 threads take part; the input must be visible (barrier) on entry;
+// returns the image that holds the result, visible to every thread.
+template <int TILE>
+__device__ cplx *lds_fft(cplx *a, cplx *b, const cplx *st, int lm, int stride) {
+    const int tid = threadIdx.x;
+    constexpr int U4 = TILE / 4 / kFBlock;                     // radix-4 butterflies per thread
+    constexpr int U2 = TILE / 2 / kFBlock;                     // radix-2 butterflies per thread
+    cplx *src = a, *dst = b;
+    for (int lns = 0; lns < lm;) {
+        const int Ns = 1 << lns;
+        const cplx *tws = st + (Ns - 1);
+        if (lm - lns >= 2) {
+            const int lq = lm - 2, q = 1 << lq;                    // butterflies per sequence
+#pragma unroll
+            for (int u = 0; u < U4; ++u) {
+                const int w = tid + u * kFBlock;
+                const int s = w >> lq, j = w & (q - 1);
+                const int k = j & (Ns - 1);
+                const cplx *bi = src + s * stride;
+                const cplx x0 = bi[j];
+                const cplx c1 = cmul(bi[j + q], tws[k]);
+                const cplx c2 = cmul(bi[j + 2 * q], tws[Ns + k]);
+                const cplx c3 = cmul(bi[j + 3 * q], tws[2 * Ns + k]);
+                const cplx s0 = cadd(x0, c2), s1 = csub(x0, c2), s2 = cadd(c1, c3), s3 = mul_neg_i(csub(c1, c3));
+                cplx *bo = dst + s * stride + (j - k) * 4 + k;
+                bo[0] = cadd(s0, s2);
+                bo[Ns] = cadd(s1, s3);
+                bo[2 * Ns] = csub(s0, s2);
+                bo[3 * Ns] = csub(s1, s3);
+            }
+            lns += 2;
+        } else {
+            const int lq = lm - 1, q = 1 << lq;
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int w = tid + u * kFBlock;
+                const int s = w >> lq, j = w & (q - 1);
+                const int k = j & (Ns - 1);
+                const cplx *bi = src + s * stride;
+                const cplx x0 = bi[j];
+                const cplx c1 = cmul(bi[j + q], tws[k]);
+                cplx *bo = dst + s * stride + (j - k) * 2 + k;
+                bo[0] = cadd(x0, c1);
+                bo[Ns] = csub(x0, c1);
+            }
+            lns += 1;
+        }
+        __syncthreads();
+        cplx *t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
 }
 
 // Where the real sequences come from / go to.
@@ -134,6 +139,25 @@ struct ConvGeom {
     int64_t npairs;       // ceil(nblocks / 2)
     int src_ch, out_ch;
 };
+
+// Twiddle tables, made once per filter next to its spectrum (pgx_convolve_fft_prepare):
+//   big[(k1 << l2) + i2] = W_N^(i2*k1)   the four-step twiddle, in the layout of the work buffer
+//   t1[p] = W_N1^p,  t2[p] = W_N2^p      the in-LDS FFT twiddles
+struct Tables {
+    const cplx *big, *t1, *t2;
+};
+
+__global__ void __launch_bounds__(kFBlock)
+k_fft_tables(cplx *big, cplx *t1, cplx *t2, ConvGeom g) {
+    const double inv_n = 1.0 / (double)g.N;
+    const int64_t stride = (int64_t)gridDim.x * kFBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kFBlock + threadIdx.x; e < g.N; e += stride) {
+        const int64_t k1 = e >> g.l2, i2 = e & (g.N2 - 1);
+        big[e] = twiddle(i2 * k1, inv_n);
+        if (e < g.N1) t1[e] = twiddle(e, 1.0 / (double)g.N1);
+        if (e < g.N2) t2[e] = twiddle(e, 1.0 / (double)g.N2);
+    }
+}
 
 // sample `pos` of overlap-save block `b` of output channel `ch`: (history | x) at b*V + pos
 __device__ __forceinline__ double conv_input(const ConvGeom &g, const float *x, const float *hist, int64_t b, int ch,
@@ -150,13 +174,16 @@ __device__ __forceinline__ double conv_input(const ConvGeom &g, const float *x, 
 // preparation); MODE 2: inverse, output = float32 samples.
 template <int MODE, int TILE>
 __global__ void __launch_bounds__(kFBlock)
-k_fft_cols(cplx *work, ConvGeom g, const float *x, const float *hist, const float *h, int fir_ch, float *out) {
+k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist, const float *h, int fir_ch,
+           float *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PT = TILE / kFBlock;                             // points per thread
     const int N1 = (int)g.N1;
     const int CW = TILE >> g.l1, lcw = __builtin_ctz(CW);          // columns per workgroup
     const int stride = N1 + 1;                                     // +1: spread the columns over the banks
     cplx *buf = reinterpret_cast<cplx *>(smem);
-    cplx *tw = buf + CW * stride;
+    cplx *alt = buf + CW * stride;
+    cplx *tw = alt + CW * stride;
     const int tid = threadIdx.x;
     const int64_t pair = blockIdx.y;
     const int64_t col0 = (int64_t)blockIdx.x * CW;
@@ -165,77 +192,126 @@ k_fft_cols(cplx *work, ConvGeom g, const float *x, const float *hist, const floa
     const int64_t p = (MODE == 1) ? 0 : pair - (int64_t)ch * g.npairs;
     const double inv_n = 1.0 / (double)g.N;
 
-    fill_twiddles(tw, N1);
-    for (int e = tid; e < TILE; e += kFBlock) {
+    // everything that comes from HBM is requested first: the inputs, then the twiddles used at the very end
+    cplx v[PT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int e = tid + u * kFBlock;
         const int c = e & (CW - 1), i1 = e >> lcw;
         const int64_t pos = ((int64_t)i1 << g.l2) + col0 + c;
-        cplx v;
         if (MODE == 0) {
-            v = cplx{conv_input(g, x, hist, 2 * p, ch, pos), conv_input(g, x, hist, 2 * p + 1, ch, pos)};
+            v[u] = cplx{conv_input(g, x, hist, 2 * p, ch, pos), conv_input(g, x, hist, 2 * p + 1, ch, pos)};
         } else if (MODE == 1) {
-            v = cplx{pos < g.L ? (double)h[pos * fir_ch + ch] : 0.0, 0.0};
+            v[u] = cplx{pos < g.L ? (double)h[pos * fir_ch + ch] : 0.0, 0.0};
         } else {
-            v = cconj(wk[pos]);                                    // inverse = conj(FFT(conj(.)))
+            v[u] = cconj(wk[pos]);                                 // inverse = conj(FFT(conj(.)))
         }
-        buf[c * stride + i1] = v;
+    }
+    cplx bigtw[MODE != 2 ? PT : 1];
+    if (MODE != 2) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int e = tid + u * kFBlock;
+            const int c = e & (CW - 1), k1 = e >> lcw;
+            bigtw[u] = tb.big[((int64_t)k1 << g.l2) + col0 + c];
+        }
+    }
+    fill_stage_twiddles(tw, tb.t1, g.l1);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int e = tid + u * kFBlock;
+        buf[(e & (CW - 1)) * stride + (e >> lcw)] = v[u];
     }
     __syncthreads();
-    lds_fft<TILE>(buf, tw, g.l1, stride);
-    for (int e = tid; e < TILE; e += kFBlock) {
+    const cplx *res = lds_fft<TILE>(buf, alt, tw, g.l1, stride);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int e = tid + u * kFBlock;
         const int c = e & (CW - 1), k1 = e >> lcw;
         const int64_t i2 = col0 + c;
-        const cplx v = buf[c * stride + k1];
+        const cplx r = res[c * stride + k1];
         if (MODE != 2) {
-            wk[((int64_t)k1 << g.l2) + i2] = cmul(v, twiddle(i2 * k1, inv_n));
+            wk[((int64_t)k1 << g.l2) + i2] = cmul(r, bigtw[u]);
         } else {
             // natural order: k1 is the row i1 of the time-domain block
             const int64_t pos = ((int64_t)k1 << g.l2) + i2;
             if (pos < g.L - 1) continue;                           // the wrapped-around part of overlap-save
             const int64_t o0 = 2 * p * g.V + pos - (g.L - 1);
-            if (o0 < g.n) out[o0 * g.out_ch + ch] = (float)(v.x * inv_n);
+            if (o0 < g.n) out[o0 * g.out_ch + ch] = (float)(r.x * inv_n);
             const int64_t o1 = o0 + g.V;
-            if (2 * p + 1 < g.nblocks && o1 < g.n) out[o1 * g.out_ch + ch] = (float)(-v.y * inv_n);   // conj
+            if (2 * p + 1 < g.nblocks && o1 < g.n) out[o1 * g.out_ch + ch] = (float)(-r.y * inv_n);   // conj
         }
     }
 }
 
 // FULL = false: forward row FFTs only (filter spectrum).  FULL = true: forward, times H, inverse,
 // conjugate twiddle.  One workgroup = TILE / N2 consecutive rows = TILE consecutive points.
+// hist_dst != nullptr (FULL only, blocks of at least L-1 frames): the workgroups also move the overlap
+// history on -- its new content is the last L-1 input frames, and the pass that read the old one is over.
 template <bool FULL, int TILE>
 __global__ void __launch_bounds__(kFBlock)
-k_fft_rows(cplx *work, ConvGeom g, const cplx *H, int fir_ch) {
+k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *hist_dst, const float *x) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PT = TILE / kFBlock;
     const int N2 = (int)g.N2;
     cplx *buf = reinterpret_cast<cplx *>(smem);
-    cplx *tw = buf + TILE;
+    cplx *alt = buf + TILE;
+    cplx *tw = alt + TILE;
     const int tid = threadIdx.x;
     const int64_t pair = blockIdx.y;
-    const int64_t row0 = ((int64_t)blockIdx.x * TILE) >> g.l2;
-    cplx *wk = work + pair * g.N + (int64_t)blockIdx.x * TILE;
-    const double inv_n = 1.0 / (double)g.N;
-    fill_twiddles(tw, N2);
-    for (int e = tid; e < TILE; e += kFBlock) buf[e] = wk[e];
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    cplx *wk = work + pair * g.N + tile0;
+    cplx v[PT], hv[FULL ? PT : 1], bigtw[FULL ? PT : 1];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) v[u] = wk[tid + u * kFBlock];
+    if (FULL) {
+        const int ch = (int)(pair / g.npairs);
+        const cplx *Hc = H + (int64_t)(fir_ch == 1 ? 0 : ch) * g.N + tile0;
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            hv[u] = Hc[tid + u * kFBlock];
+            bigtw[u] = tb.big[tile0 + tid + u * kFBlock];
+        }
+    }
+    fill_stage_twiddles(tw, tb.t2, g.l2);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) buf[tid + u * kFBlock] = v[u];
     __syncthreads();
-    lds_fft<TILE>(buf, tw, g.l2, N2);
+    cplx *res = lds_fft<TILE>(buf, alt, tw, g.l2, N2);
     if (!FULL) {
-        for (int e = tid; e < TILE; e += kFBlock) wk[e] = buf[e];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) wk[tid + u * kFBlock] = res[tid + u * kFBlock];
         return;
     }
-    const int ch = (int)(pair / g.npairs);
-    const cplx *Hc = H + (int64_t)(fir_ch == 1 ? 0 : ch) * g.N + (int64_t)blockIdx.x * TILE;
-    for (int e = tid; e < TILE; e += kFBlock) buf[e] = cconj(cmul(buf[e], Hc[e]));
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int e = tid + u * kFBlock;
+        res[e] = cconj(cmul(res[e], hv[u]));                       // own elements only: no barrier needed before
+    }
     __syncthreads();
-    lds_fft<TILE>(buf, tw, g.l2, N2);
-    for (int e = tid; e < TILE; e += kFBlock) {
-        const int r = e >> g.l2, i2 = e & (N2 - 1);
-        const int64_t k1 = row0 + r;
+    const cplx *fin = lds_fft<TILE>(res, res == buf ? alt : buf, tw, g.l2, N2);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int e = tid + u * kFBlock;
         // conj() completes the inverse row transform; the conjugate twiddle undoes step (1)'s
-        wk[e] = cmul(cconj(buf[e]), cconj(twiddle(k1 * i2, inv_n)));
+        wk[e] = cmul(cconj(fin[e]), cconj(bigtw[u]));
+    }
+    if (hist_dst != nullptr) {
+        const int64_t total = (g.L - 1) * g.out_ch;
+        const int64_t groups = (int64_t)gridDim.x * gridDim.y;
+        const int64_t me = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const int64_t share = (total + groups - 1) / groups;
+        const int64_t end = (me + 1) * share < total ? (me + 1) * share : total;
+        for (int64_t e = me * share + tid; e < end; e += kFBlock) {
+            const int64_t j = e / g.out_ch;
+            const int c = (int)(e - j * g.out_ch);
+            hist_dst[e] = x[(g.n + j - (g.L - 1)) * g.src_ch + (g.src_ch == 1 ? 0 : c)];
+        }
     }
 }
 
-// new history = the last L-1 samples of (history | x), per output channel.  dst == hist is allowed when
-// n >= L-1 (every value then comes from x); shorter blocks go through a scratch copy.
+// new history = the last L-1 samples of (history | x), per output channel, for blocks shorter than L-1
+// frames (longer ones: k_fft_rows).  Goes through a scratch copy: part of the old history survives.
 __global__ void __launch_bounds__(kFBlock)
 k_fft_hist(float *dst, const float *hist, const float *x, ConvGeom g) {
     const int64_t total = (g.L - 1) * g.out_ch;
@@ -270,33 +346,58 @@ bool fft_geometry(int64_t fft_size, int64_t L, ConvGeom &g) {
     return true;
 }
 
-size_t cols_smem(const ConvGeom &g, int tile) { return ((tile / g.N1) * (g.N1 + 1) + g.N1) * sizeof(cplx); }
-size_t rows_smem(const ConvGeom &g, int tile) { return (tile + g.N2) * sizeof(cplx); }
+size_t cols_smem(const ConvGeom &g, int tile) { return (2 * (tile / g.N1) * (g.N1 + 1) + g.N1) * sizeof(cplx); }
+size_t rows_smem(const ConvGeom &g, int tile) { return (2 * tile + g.N2) * sizeof(cplx); }
+
+// the spectrum blob: [H: fir_channels x N][big: N][t1: N1][t2: N2] complex doubles
+Tables tables_of(const cplx *spectrum, const ConvGeom &g, int fir_channels) {
+    const cplx *big = spectrum + (int64_t)fir_channels * g.N;
+    return Tables{big, big + g.N, big + g.N + g.N1};
+}
+
+// LDS images beyond the 64 KB a kernel gets by default (the 2^18-point geometry)
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    return PGX_OK;
+}
 
 template <int TILE>
 int launch_prepare(cplx *H, const ConvGeom &g, const float *h, int fir_channels) {
+    const Tables tb = tables_of(H, g, fir_channels);
+    hipLaunchKernelGGL(k_fft_tables, dim3(pgx::grid_for(g.N, kFBlock)), dim3(kFBlock), 0, pgx::stream(),
+                       const_cast<cplx *>(tb.big), const_cast<cplx *>(tb.t1), const_cast<cplx *>(tb.t2), g);
+    PGX_LAUNCH_CHECK("k_fft_tables");
     const dim3 grid((unsigned)(g.N / TILE), (unsigned)fir_channels);
-    hipLaunchKernelGGL((k_fft_cols<1, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), pgx::stream(), H, g,
+    if (int rc = allow_lds(k_fft_cols<1, TILE>, cols_smem(g, TILE))) return rc;
+    if (int rc = allow_lds(k_fft_rows<false, TILE>, rows_smem(g, TILE))) return rc;
+    hipLaunchKernelGGL((k_fft_cols<1, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), pgx::stream(), H, g, tb,
                        (const float *)nullptr, (const float *)nullptr, h, fir_channels, (float *)nullptr);
     PGX_LAUNCH_CHECK("k_fft_cols<filter>");
-    hipLaunchKernelGGL((k_fft_rows<false, TILE>), grid, dim3(kFBlock), rows_smem(g, TILE), pgx::stream(), H, g,
-                       (const cplx *)nullptr, fir_channels);
+    hipLaunchKernelGGL((k_fft_rows<false, TILE>), grid, dim3(kFBlock), rows_smem(g, TILE), pgx::stream(), H, g, tb,
+                       (const cplx *)nullptr, fir_channels, (float *)nullptr, (const float *)nullptr);
     PGX_LAUNCH_CHECK("k_fft_rows<filter>");
     return PGX_OK;
 }
 
 template <int TILE>
-int launch_convolve(float *out, const float *x, const cplx *H, float *hist, cplx *work, const ConvGeom &g,
-                    int fir_channels, int64_t pairs) {
+int launch_convolve(float *out, const float *x, const cplx *H, float *hist, float *hist_in_place, cplx *work,
+                    const ConvGeom &g, int fir_channels, int64_t pairs) {
     hipStream_t st = pgx::stream();
+    const Tables tb = tables_of(H, g, fir_channels);
     const dim3 grid((unsigned)(g.N / TILE), (unsigned)pairs);
-    hipLaunchKernelGGL((k_fft_cols<0, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), st, work, g, x,
+    if (int rc = allow_lds(k_fft_cols<0, TILE>, cols_smem(g, TILE))) return rc;
+    if (int rc = allow_lds(k_fft_cols<2, TILE>, cols_smem(g, TILE))) return rc;
+    if (int rc = allow_lds(k_fft_rows<true, TILE>, rows_smem(g, TILE))) return rc;
+    hipLaunchKernelGGL((k_fft_cols<0, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), st, work, g, tb, x,
                        (const float *)hist, (const float *)nullptr, fir_channels, (float *)nullptr);
     PGX_LAUNCH_CHECK("k_fft_cols<forward>");
-    hipLaunchKernelGGL((k_fft_rows<true, TILE>), grid, dim3(kFBlock), rows_smem(g, TILE), st, work, g, H,
-                       fir_channels);
+    hipLaunchKernelGGL((k_fft_rows<true, TILE>), grid, dim3(kFBlock), rows_smem(g, TILE), st, work, g, tb, H,
+                       fir_channels, hist_in_place, x);
     PGX_LAUNCH_CHECK("k_fft_rows");
-    hipLaunchKernelGGL((k_fft_cols<2, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), st, work, g,
+    hipLaunchKernelGGL((k_fft_cols<2, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), st, work, g, tb,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, fir_channels, out);
     PGX_LAUNCH_CHECK("k_fft_cols<inverse>");
     return PGX_OK;
@@ -315,7 +416,9 @@ int64_t pgx_convolve_fft_size(int64_t fir_len) {
 
 size_t pgx_convolve_fft_spectrum_bytes(int64_t fft_size, int fir_channels) {
     if (fft_size <= 0 || fir_channels <= 0) return 0;
-    return (size_t)fft_size * fir_channels * sizeof(cplx);
+    ConvGeom g{};
+    if (!fft_geometry(fft_size, 2, g)) return 0;
+    return ((size_t)fft_size * fir_channels + (size_t)fft_size + g.N1 + g.N2) * sizeof(cplx);   // H + twiddle tables
 }
 
 size_t pgx_convolve_fft_workspace_bytes(int64_t n, int64_t fir_len, int out_channels, int64_t fft_size) {
@@ -360,15 +463,19 @@ int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, co
     float *hist_new = (float *)(work + pairs * g.N);
     const cplx *H = (const cplx *)spectrum;
     hipStream_t st = pgx::stream();
-    const int rc = fft_tile(fft_size) == 2048 ? launch_convolve<2048>(out, x, H, hist, work, g, fir_channels, pairs)
-                                              : launch_convolve<1024>(out, x, H, hist, work, g, fir_channels, pairs);
+    const bool in_place = n >= fir_len - 1;                     // then nothing of the old history survives:
+    float *hip = in_place ? hist : nullptr;                     // the row pass rewrites it on the side
+    const int rc = fft_tile(fft_size) == 2048
+                       ? launch_convolve<2048>(out, x, H, hist, hip, work, g, fir_channels, pairs)
+                       : launch_convolve<1024>(out, x, H, hist, hip, work, g, fir_channels, pairs);
     if (rc != PGX_OK) return rc;
-    const int64_t hist_elems = (fir_len - 1) * out_channels;
-    const bool in_place = n >= fir_len - 1;                     // then nothing of the old history is read
-    hipLaunchKernelGGL(k_fft_hist, dim3(pgx::grid_for(hist_elems, kFBlock)), dim3(kFBlock), 0, st,
-                       in_place ? hist : hist_new, (const float *)hist, x, g);
-    PGX_LAUNCH_CHECK("k_fft_hist");
-    if (!in_place) PGX_HIP(hipMemcpyAsync(hist, hist_new, hist_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (!in_place) {
+        const int64_t hist_elems = (fir_len - 1) * out_channels;
+        hipLaunchKernelGGL(k_fft_hist, dim3(pgx::grid_for(hist_elems, kFBlock)), dim3(kFBlock), 0, st, hist_new,
+                           (const float *)hist, x, g);
+        PGX_LAUNCH_CHECK("k_fft_hist");
+        PGX_HIP(hipMemcpyAsync(hist, hist_new, hist_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     return PGX_OK;
 }
 

@@ -21,8 +21,13 @@ from .snippet import Snippet
 
 class SinePE(ProcessingElement):
     _READ_AHEAD_SAFE = True
-    _LOOK_AHEAD_SAFE = True            # stateful path: the carried phase is sample-exact
+    _LOOK_AHEAD_SAFE = True            # stateful path: the carried phase is sample-exact ...
     _STATE_FIELDS = ("_state",)
+
+    def _look_ahead_condition(self) -> bool:
+        # ... unless a phase offset is in play: the reference carries `phase + offset` into the next block
+        # and adds the offset again (sine_pe.py:217-232), so its output depends on where the blocks are cut
+        return self.is_pure() or (not isinstance(self._phase, ProcessingElement) and float(self._phase) == 0.0)
 
     def __init__(self, frequency=440.0, amplitude=1.0, phase=0.0, channels: int = 1):
         self._frequency = frequency

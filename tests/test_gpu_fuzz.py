@@ -261,13 +261,20 @@ def test_random_voice_bank_matches_oracle_and_per_voice_rendering(seed):
     pg.set_sample_rate(case["sr"])
 
     def render(bank_allowed):
+        from pygmu2_amd import look_ahead
         pe = spec_build.build(case["graph"])
         if not bank_allowed:
             pe._bank = False
         r = pg.NullRenderer(sample_rate=case["sr"])
         r.set_source(pe)
         r.start()
-        outs = [pe.render(s, n).data for s, n in case["blocks"]]
+        # the property here is "a bank renders the caller's blocks like its voices would": per-voice rendering must
+        # see those same blocks (its look-ahead would cut the stream differently; tests/test_gpu_look_ahead.py)
+        look_ahead.set_enabled(False)
+        try:
+            outs = [pe.render(s, n).data for s, n in case["blocks"]]
+        finally:
+            look_ahead.set_enabled(True)
         used = bool(pe._bank)
         r.stop()
         return outs, used

@@ -154,6 +154,8 @@ def test_graphs_that_must_not_look_ahead():
     assert not look_ahead.capable(pg.EnvelopePE(src, mode=pg.DetectionMode.RMS))     # block-local RMS window
     assert not look_ahead.capable(pg.TransformPE(pg.BiquadPE(src, 500.0, 1.0), func=lambda x: x * 2.0))
     assert not look_ahead.capable(pg.CompressorPE(src))                              # CachePE inside
+    fm = pg.SinePE(frequency=pg.GainPE(pg.SinePE(3.0), 50.0), phase=0.5)           # the reference re-adds the offset
+    assert not look_ahead.capable(fm) and look_ahead.capable(pg.SinePE(frequency=pg.GainPE(pg.SinePE(3.0), 50.0)))
     bank = pg.MixPE(*[pg.BlitSawPE(100.0 + i) for i in range(6)])
     assert not look_ahead.capable(bank)                                              # voice bank keeps its own states
     assert look_ahead.capable(pg.MixPE(pg.BlitSawPE(100.0), pg.BlitSawPE(150.0)))
