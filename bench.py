@@ -559,7 +559,7 @@ def conv_fft_roofline(pg, frames, launches):
     ws = device.DeviceBuffer((lib.pgx_convolve_fft_workspace_bytes(frames, L, 2, nfft),), np.uint8)
 
     def launch():
-        device.check(lib.pgx_convolve_fft(out.ptr, xd.ptr, frames, 2, spec.ptr, L, 1, 2, nfft, hist.ptr, ws.ptr))
+        device.check(lib.pgx_convolve_fft(out.ptr, xd.ptr, frames, 2, spec.ptr, L, 1, 2, nfft, hist.ptr, ws.ptr, 0))
 
     ms = event_avg_ms(launch, launches, warm=2)
     algo_bytes = 4.0 * (2 + 2) * frames              # 4(C_in + C_out) per frame; taps are read once

@@ -462,7 +462,8 @@ int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, in
                              int64_t fft_size);
 int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, const void *spectrum,
                      int64_t fir_len, int fir_channels, int out_channels, int64_t fft_size,
-                     float *hist, void *workspace);
+                     float *hist, void *workspace,
+                     int hist_is_zero /* fresh stream: the history counts as zeros and is only written */);
 
 /* ------------------------------------------------------------------ multi-GPU exchange (RCCL over xGMI)
  * The one exchange step of the path: the partial mixes of a MixPE whose inputs are dealt i mod world over

@@ -40,6 +40,9 @@ class ArrayPE(SourcePE):
     def _render(self, start: int, duration: int) -> Snippet:
         if self._dev is None:
             self._dev = DeviceBuffer.from_host(np.ascontiguousarray(self._data))
+        if start >= 0 and start + duration <= self._length:
+            # entirely inside the array: hand out the resident rows themselves (Snippets are read-only)
+            return Snippet.window_rows(start, self._dev, start, duration)
         out = new_output(duration, self._channels)
         hold_first = self._extend_mode in (ExtendMode.HOLD_FIRST, ExtendMode.HOLD_BOTH)
         hold_last = self._extend_mode in (ExtendMode.HOLD_LAST, ExtendMode.HOLD_BOTH)

@@ -162,14 +162,16 @@ class ConvolvePE(ProcessingElement):
         length = self._fir_len
         if int(self._fft_size) - (length - 1) < 1:
             raise ValueError(f"fft_size ({self._fft_size}) too small for filter length ({length})")
-        if self._last_render_end is None or start != self._last_render_end:
-            self._hist.zero_()
+        fresh = self._last_render_end is None or start != self._last_render_end
+        if fresh and not self._device_fft:
+            self._hist.zero_()                # (the FFT path is told instead: it never reads the old history)
         x = self._src.render(start, duration)
         src_ch = x.channels
         out_ch = src_ch if self._fir_ch == 1 else self._fir_ch
         if out_ch != self._out_ch:
             self._out_ch = out_ch
             self._hist = DeviceBuffer((max(length - 1, 1), out_ch), np.float32, zero=True)
+            fresh = True
         if src_ch != 1 and src_ch != out_ch:
             raise ValueError(f"ConvolvePE src channels ({src_ch}) incompatible with output channels ({out_ch})")
         L = lib()
@@ -184,7 +186,7 @@ class ConvolvePE(ProcessingElement):
         if self._device_fft:
             check(L.pgx_convolve_fft(out.ptr, x.dev.ptr, duration, src_ch, self._spectrum.ptr, length,
                                      self._fir_ch, out_ch, self._device_fft, self._hist.ptr,
-                                     self._workspace.ptr), "pgx_convolve_fft")
+                                     self._workspace.ptr, 1 if fresh else 0), "pgx_convolve_fft")
         else:
             check(L.pgx_convolve(out.ptr, x.dev.ptr, duration, src_ch, self._h.ptr, length, self._fir_ch,
                                  out_ch, self._hist.ptr, self._workspace.ptr), "pgx_convolve")

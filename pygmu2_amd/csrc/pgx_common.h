@@ -166,6 +166,15 @@ __device__ __forceinline__ double pgx_sin(double x) {
     const double v = pgx_sin_poly(r);
     return (qi & 1) ? -v : v;
 }
+// The same routine for callers that guarantee |x| < 3e6: without the fallback branch the code is one basic
+// block, so the compiler interleaves several evaluations (the oscillators evaluate 16 per thread and tile; with
+// the branch each one ran as a lone dependent chain).  Same bits as pgx_sin on that range.
+__device__ __forceinline__ double pgx_sin_bounded(double x) {
+    int qi;
+    const double r = pgx_reduce_pi(x, qi);
+    const double v = pgx_sin_poly(r);
+    return (qi & 1) ? -v : v;
+}
 __device__ __forceinline__ void pgx_sincos(double x, double &sn, double &cs) {
     if (!(fabs(x) < 3.0e6)) {
         sn = sin(x);

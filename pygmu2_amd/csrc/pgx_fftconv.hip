@@ -32,8 +32,10 @@ constexpr double kTwoPi = 6.283185307179586;
 struct cplx {
     double x, y;
 };
+// (explicit FMAs: the transforms are not bound to a reference operation order, only to its float64 accuracy --
+// one rounding less per product, and a third fewer instructions in a pass that is issue-bound)
 __device__ __forceinline__ cplx cmul(const cplx &a, const cplx &b) {
-    return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    return cplx{__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x)};
 }
 __device__ __forceinline__ cplx cadd(const cplx &a, const cplx &b) { return cplx{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cplx csub(const cplx &a, const cplx &b) { return cplx{a.x - b.x, a.y - b.y}; }
@@ -138,6 +140,7 @@ struct ConvGeom {
     int64_t nblocks;      // overlap-save blocks per channel
     int64_t npairs;       // ceil(nblocks / 2)
     int src_ch, out_ch;
+    int hist_zero;        // the overlap history is all zeros (fresh stream): its buffer is not read
 };
 
 // Twiddle tables, made once per filter next to its spectrum (pgx_convolve_fft_prepare):
@@ -164,7 +167,7 @@ __device__ __forceinline__ double conv_input(const ConvGeom &g, const float *x, 
                                              int64_t pos) {
     if (b >= g.nblocks) return 0.0;
     const int64_t e = b * g.V + pos;                               // index into (history | x)
-    if (e < g.L - 1) return (double)hist[e * g.out_ch + ch];
+    if (e < g.L - 1) return g.hist_zero ? 0.0 : (double)hist[e * g.out_ch + ch];
     const int64_t i = e - (g.L - 1);
     if (i >= g.n) return 0.0;
     return (double)x[i * g.src_ch + (g.src_ch == 1 ? 0 : ch)];
@@ -320,7 +323,7 @@ k_fft_hist(float *dst, const float *hist, const float *x, ConvGeom g) {
         const int64_t j = e / g.out_ch;
         const int c = (int)(e - j * g.out_ch);
         const int64_t k = g.n + j;                                 // index into (history | x)
-        dst[e] = (k < g.L - 1) ? hist[k * g.out_ch + c]
+        dst[e] = (k < g.L - 1) ? (g.hist_zero ? 0.0f : hist[k * g.out_ch + c])
                                : x[(k - (g.L - 1)) * g.src_ch + (g.src_ch == 1 ? 0 : c)];
     }
 }
@@ -434,7 +437,7 @@ int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, in
     ConvGeom g{};
     PGX_CHECK_ARG(spectrum && h && fir_len >= 1 && fir_channels >= 1, "pgx_convolve_fft_prepare: bad argument");
     PGX_CHECK_ARG(fft_geometry(fft_size, fir_len, g), "pgx_convolve_fft_prepare: unsupported fft size");
-    g.n = 0; g.nblocks = 0; g.npairs = 1; g.src_ch = 1; g.out_ch = fir_channels;
+    g.n = 0; g.nblocks = 0; g.npairs = 1; g.src_ch = 1; g.out_ch = fir_channels; g.hist_zero = 0;
     cplx *H = (cplx *)spectrum;
     return fft_tile(fft_size) == 2048 ? launch_prepare<2048>(H, g, h, fir_channels)
                                       : launch_prepare<1024>(H, g, h, fir_channels);
@@ -442,7 +445,7 @@ int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, in
 
 int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, const void *spectrum,
                      int64_t fir_len, int fir_channels, int out_channels, int64_t fft_size, float *hist,
-                     void *workspace) {
+                     void *workspace, int hist_is_zero) {
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     ConvGeom g{};
@@ -457,6 +460,7 @@ int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, co
     g.npairs = (g.nblocks + 1) / 2;
     g.src_ch = src_channels;
     g.out_ch = out_channels;
+    g.hist_zero = hist_is_zero ? 1 : 0;
     const int64_t pairs = g.npairs * out_channels;
     PGX_CHECK_ARG(pairs <= 65535, "pgx_convolve_fft: block too long for one call");
     cplx *work = (cplx *)workspace;

@@ -872,6 +872,15 @@ __device__ __forceinline__ SawConst saw_const(double f, double sr, double m_para
     return c;
 }
 
+// sin(m*theta) / sin(theta) of the Dirichlet kernel.  theta = pi * phase is below pi; m*theta stays below 3e6 for
+// every M the rule sr / (2f) can produce (and for explicit M up to 9e5): then the bounded sine applies and the
+// samples of a thread interleave.  BOUNDED is a workgroup-uniform choice made outside the sample loops.
+template <bool BOUNDED>
+__device__ __forceinline__ double saw_sin_num(double m_theta) {
+    return BOUNDED ? pgx::pgx_sin_bounded(m_theta) : pgx::pgx_sin(m_theta);
+}
+constexpr double kSawBoundedM = 9.0e5;
+
 // STREAMS = false: scalar frequency / amplitude / M (every voice-bank and SuperSaw launch): the
 // per-voice constants are hoisted out of the sample loops.
 // NW = 4: 256 threads, 2048-frame tiles (banks of oscillators).  NW = 8: 512 threads, 4096-frame tiles --
@@ -993,22 +1002,28 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 
         // ---- Dirichlet kernel (blit_saw_pe.py:194-217) ----
         double xb[kSawT];
+        auto dirichlet = [&](auto bounded) {
 #pragma unroll
-        for (int j = 0; j < kSawT; ++j) {
-            const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));      // np.mod(phase, 1.0)
-            const double theta = kPi * ph;
-            const double m_theta = kc[j].m * theta;
-            const double sin_num = pgx::pgx_sin(m_theta);
-            const double sin_den = pgx::pgx_sin(theta);
-            // |P*sin_den| >= 1e-9: a Newton-refined reciprocal (<= 1 ulp) replaces the IEEE division sequence
-            const double blit = (fabs(sin_den) < 1e-9) ? (kc[j].m / kc[j].P)
-                                                       : pgx::pgx_div_fast(sin_num, kc[j].P * sin_den);
-            xb[j] = (f0 + j < n) ? (blit - kc[j].invP) : 0.0;
-            if (f0 + j == n - 1) {
-                final_phase = ph;
-                have_final = true;
+            for (int j = 0; j < kSawT; ++j) {
+                const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));      // np.mod(phase, 1.0)
+                const double theta = kPi * ph;
+                const double m_theta = kc[j].m * theta;
+                const double sin_num = saw_sin_num<decltype(bounded)::value>(m_theta);
+                const double sin_den = pgx::pgx_sin_bounded(theta);
+                // |P*sin_den| >= 1e-9: a Newton-refined reciprocal (<= 1 ulp) replaces the IEEE division sequence.
+                // Evaluated unconditionally and then overridden at the singularity (a select, not a branch: the
+                // samples of a thread must stay in one basic block to be interleaved)
+                double blit = pgx::pgx_div_fast(sin_num, kc[j].P * sin_den);
+                if (fabs(sin_den) < 1e-9) blit = kc[j].m / kc[j].P;
+                xb[j] = (f0 + j < n) ? (blit - kc[j].invP) : 0.0;
+                if (f0 + j == n - 1) {
+                    final_phase = ph;
+                    have_final = true;
+                }
             }
-        }
+        };
+        if (!STREAMS && k0.m < kSawBoundedM) dirichlet(std::true_type{});
+        else dirichlet(std::false_type{});
 
         // ---- leaky integrator y[n] = x[n] + leak*y[n-1] (blit_saw_pe.py:222-234) ----
         double e = 0.0;
@@ -1111,18 +1126,23 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                                            : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
             double xb[kSawT];
             double final_phase = 0.0, final_y = 0.0;
+            const double m_over_p = k0.m / k0.P;
+            auto dirichlet = [&](auto bounded) {
 #pragma unroll
-            for (int j = 0; j < kSawT; ++j) {
-                const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));
-                const double theta = kPi * ph;
-                const double m_theta = k0.m * theta;
-                const double sin_num = pgx::pgx_sin(m_theta);
-                const double sin_den = pgx::pgx_sin(theta);
-                const double blit = (fabs(sin_den) < 1e-9) ? (k0.m / k0.P)
-                                                           : pgx::pgx_div_fast(sin_num, k0.P * sin_den);
-                xb[j] = (f0 + j < n) ? (blit - k0.invP) : 0.0;
-                if (f0 + j == n - 1) final_phase = ph;
-            }
+                for (int j = 0; j < kSawT; ++j) {
+                    const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));
+                    const double theta = kPi * ph;
+                    const double m_theta = k0.m * theta;
+                    const double sin_num = saw_sin_num<decltype(bounded)::value>(m_theta);
+                    const double sin_den = pgx::pgx_sin_bounded(theta);
+                    double blit = pgx::pgx_div_fast(sin_num, k0.P * sin_den);   // a select, not a branch (k_blitsaw)
+                    if (fabs(sin_den) < 1e-9) blit = m_over_p;
+                    xb[j] = (f0 + j < n) ? (blit - k0.invP) : 0.0;
+                    if (f0 + j == n - 1) final_phase = ph;
+                }
+            };
+            if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
+            else dirichlet(std::false_type{});
             double e = 0.0;
 #pragma unroll
             for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];

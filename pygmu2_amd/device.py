@@ -88,7 +88,7 @@ _SIGNATURES = [
     ("pgx_convolve_fft_spectrum_bytes", _Z, [_L, _I]),
     ("pgx_convolve_fft_workspace_bytes", _Z, [_L, _L, _I, _L]),
     ("pgx_convolve_fft_prepare", _I, [_P, _P, _L, _I, _L]),
-    ("pgx_convolve_fft", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _L, _P, _P]),
+    ("pgx_convolve_fft", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _L, _P, _P, _I]),
     ("pgx_channel_adapt", _I, [_P, _P, _L, _I, _I]),
     ("pgx_pan", _I, [_P, _P, _L, _I, C.c_float, _P, _I]),
     ("pgx_mono_mean", _I, [_P, _P, _L, _I]),

@@ -21,7 +21,7 @@ def dev():
     return device
 
 
-def _fft_conv(dev, x, h, hist, fft_size):
+def _fft_conv(dev, x, h, hist, fft_size, hist_is_zero=0):
     lib = dev.ensure_init()
     n, src_ch = x.shape
     L, fir_ch = h.shape
@@ -34,7 +34,7 @@ def _fft_conv(dev, x, h, hist, fft_size):
     ws = dev.DeviceBuffer((lib.pgx_convolve_fft_workspace_bytes(n, L, out_ch, fft_size),), np.uint8)
     out = dev.DeviceBuffer((n, out_ch), np.float32)
     dev.check(lib.pgx_convolve_fft(out.ptr, xd.ptr, n, src_ch, spec.ptr, L, fir_ch, out_ch, fft_size, histd.ptr,
-                                   ws.ptr))
+                                   ws.ptr, hist_is_zero))
     return out.to_host(), histd.to_host()
 
 
@@ -77,6 +77,11 @@ def test_fft_conv_matches_numpy(dev, L, n, fft_size, src_ch, fir_ch):
     err = float(np.max(np.abs(got.astype(np.float64) - want)))
     assert err <= 1e-6 * peak, (err, peak)              # float64 transforms: float32 rounding only
     assert np.array_equal(got_hist, want_hist.astype(np.float32))
+    # a fresh stream: whatever the history buffer holds counts as zeros, and it is still rewritten
+    got0, got_hist0 = _fft_conv(dev, x, h, hist, fft_size, hist_is_zero=1)
+    want0, want_hist0 = _numpy_conv(x, h, np.zeros_like(hist))
+    assert float(np.max(np.abs(got0.astype(np.float64) - want0))) <= 1e-6 * float(np.max(np.abs(want0)))
+    assert np.array_equal(got_hist0, want_hist0.astype(np.float32))
 
 
 def test_fft_size_rule_and_argument_checks(dev):
