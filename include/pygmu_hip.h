@@ -360,7 +360,11 @@ int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, in
  * only meaningful below self-oscillation): the block is cut into segments that each start W samples
  * early from a zero state; the library verifies every segment against its left neighbour's final
  * state (1e-8 relative) and re-renders a chain sequentially when the check fails, so W affects
- * speed, never results beyond that bound.  workspace: pgx_ladder_workspace_bytes(...) bytes
+ * speed, never results beyond that bound.  accurate_frames = A (0 < A < W): only the last A warm-up samples
+ * of a segment evaluate tanh in float64; the W - A before them, which merely have to forget the zero start,
+ * use the float32 exponential unit (state error ~1e-7, contracted by the accurate tail; 0 or >= W: all of the
+ * warm-up is accurate).  Warm-ups run on fused multiply-adds; emitted samples keep the reference's operation
+ * order.  workspace: pgx_ladder_workspace_bytes(...) bytes
  * (NULL when 0); the int32 at byte offset (size - 16) counts chains that fell back (zero it to count). */
 typedef struct {
     double freq;
@@ -374,7 +378,8 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
                int batch, int64_t n, int channels, double sample_rate,
                const pgx_ladder_params *params,
                const float *freq, const float *resonance, const float *drive, /* batch==1 only */
-               double *state /* [batch][channels][9] */, int64_t settle_frames, void *workspace);
+               double *state /* [batch][channels][9] */, int64_t settle_frames, int64_t accurate_frames,
+               void *workspace);
 size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames);
 
 /* ------------------------------------------------------------------ CombPE

@@ -175,6 +175,13 @@ __device__ __forceinline__ double pgx_sin_bounded(double x) {
     const double v = pgx_sin_poly(r);
     return (qi & 1) ? -v : v;
 }
+__device__ __forceinline__ void pgx_sincos_bounded(double x, double &sn, double &cs) {   // |x| < 3e6 (or NaN)
+    int qi;
+    const double r = pgx_reduce_pi(x, qi);
+    const double a = pgx_sin_poly(r), b = pgx_cos_poly(r);
+    sn = (qi & 1) ? -a : a;
+    cs = (qi & 1) ? -b : b;
+}
 __device__ __forceinline__ void pgx_sincos(double x, double &sn, double &cs) {
     if (!(fabs(x) < 3.0e6)) {
         sn = sin(x);

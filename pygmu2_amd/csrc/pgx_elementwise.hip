@@ -121,8 +121,33 @@ __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride,
     int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
     for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
         float v[4];
-        // frame of element e + j without a 64-bit division per element (software on this hardware): mono is the
-        // identity, otherwise one division per thread and a running remainder
+        if (channels == 1) {
+            // mono: four phases first; while they are all below the fast range of the sine (18 minutes of a
+            // 440 Hz tone) the four evaluations are one basic block and interleave -- same bits as pgx_sin
+            double ph[4];
+            bool fast = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double t = (double)(start + e + j) / sr;
+                ph[j] = p.phase0 + p.w * t;
+                fast = fast && (fabs(ph[j]) < 3.0e6);
+            }
+            if (fast) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (float)(p.amp * pgx::pgx_sin_bounded(ph[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (float)(p.amp * pgx::pgx_sin(ph[j]));
+            }
+            if (has_gain) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] * post_gain;
+            }
+            store4(o, e, n_elems, aligned, v);
+            continue;
+        }
+        // frame of element e + j without a 64-bit division per element (software on this hardware): one
+        // division per thread and a running remainder
         int64_t f = e;
         int rem = 0;
         if (channels != 1) {

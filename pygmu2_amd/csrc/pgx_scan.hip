@@ -1356,7 +1356,7 @@ __device__ __forceinline__ void rbj(int mode, double f, double q, double A, doub
     // those were 40 % of this kernel's instructions, and the coefficients feed a result held to 1e-5
     double omega = pgx::pgx_div_fast((2.0 * kPi) * f, sr);
     double sn, cs;
-    pgx::pgx_sincos(omega, sn, cs);
+    pgx::pgx_sincos_bounded(omega, sn, cs);                   // omega < pi: branch-free, the samples of a thread interleave
     double alpha = pgx::pgx_div_fast(sn, 2.0 * q);
     double a0;
     switch (mode) {
@@ -1582,7 +1582,7 @@ __device__ __forceinline__ SvCoef svf_coef(int mode, double freq, double q, doub
     if (res > 0.999) res = 0.999;
     const double k = 2.0 - 2.0 * res;
     double sn, cs;
-    pgx::pgx_sincos(kPi * f_norm, sn, cs);
+    pgx::pgx_sincos_bounded(kPi * f_norm, sn, cs);     // <= pi/2
     double g = pgx::pgx_div_fast(sn, cs);              // tan(pi * f_norm)
     double shelf_a = 1.0;
     if (mode == 5) shelf_a = 1.0 / sqrt(a_lin);
@@ -2168,6 +2168,7 @@ int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, in
                   "pgx_supersaw_bank: bad argument");
     PGX_CHECK_ARG(nvoices >= 1 && nvoices <= 16, "pgx_supersaw_bank: 1..16 voices per instance");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_bank: out_stride too small");
+    // (a third wave per SIMD, forced with a 168-VGPR cap, spills and is slower: 0.88 against 0.78 ms per block)
     if (batch >= 512)
         hipLaunchKernelGGL(k_supersaw_bank<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
                            nvoices, n, channels, sample_rate, params, state, amp_scalar);

@@ -4,6 +4,8 @@
 // Parallelism comes from independent chains (voices x channels); inside one chain the
 // reference's per-sample operation order is followed literally (-ffp-contract=off).
 
+#include <cstdlib>
+
 #include "pgx_common.h"
 
 namespace {
@@ -186,6 +188,120 @@ __device__ __forceinline__ void ladder_advance_impl(const LadderConsts &c, Ladde
     run(emit_from, i1, true);
 }
 
+// Warm-up of a time segment (scalar parameters): samples [i0, i1) advance the state and nothing is written.  What
+// the warm-up has to deliver is a state within ~1e-10 of the true trajectory at its end, not the reference's
+// roundings along the way, so it runs on fused multiply-adds with the stages regrouped and skips the output taps.
+// FAST takes tanh from the float32 exponential unit (absolute error ~1e-7, 8 dependent operations instead of 35):
+// the bulk of a warm-up only has to forget the zero start; the accurate tail (tanh to ~1e-11, ladder_tanh_mid)
+// then contracts the 1e-7 the fast part leaves behind.
+__device__ __forceinline__ double ladder_tanh_fast(double g) {
+    const float e = __expf(2.0f * (float)g);                       // inf / 0 at the ends: the quotient saturates
+    return (double)__builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);   // v_rcp_f32: 1 ulp is plenty
+}
+
+// tanh to ~1e-11 absolute for the accurate tail of a warm-up (its target is 2e-10): pgx_tanh's scheme with a
+// degree-9 polynomial and one Newton step on the reciprocal -- 20 dependent operations instead of 35.
+__device__ __forceinline__ double ladder_tanh_mid(double x) {
+    double ax = fabs(x);
+    ax = ax < 40.0 ? ax : 40.0;
+    const double t = ax + ax;
+    const double kf = rint(t * 1.4426950408889634);
+    double r = __builtin_fma(-kf, 6.93147180369123816490e-01, t);
+    r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);       // r in [-ln2/2, ln2/2]
+    double p = -1.0 / 362880.0;                                  // exp(-r), Taylor to r^9: 7e-12 relative
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, -1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, -1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, -1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, -1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double e = ldexp(p, -(int)kf);                         // exp(-2|x|)
+    const double den = 1.0 + e;
+    double y = __builtin_amdgcn_rcp(den);
+    y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+    return copysign((1.0 - e) * y, x);
+}
+
+template <bool FAST, int OS>
+__device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderState &s, int64_t i0, int64_t i1) {
+    const double state_decay = 0.95, input_threshold = 1e-5, resonance_multiplier = 1.8;
+    const double two_pi = 2.0 * 3.141592653589793;
+    double cutoff = c.p_freq;
+    if (cutoff < 5.0) cutoff = 5.0;
+    if (cutoff > c.max_cutoff) cutoff = c.max_cutoff;
+    const double wc = cutoff * two_pi / (c.sr * (double)c.oversample);
+    const double wc2 = wc * wc, wc3 = wc2 * wc, wc4 = wc3 * wc;
+    const double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
+    const double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
+    double res = c.p_res;
+    if (res < 0.0) res = 0.0;
+    if (res > 1.0) res = 1.0;
+    const double kq = 4.0 * res * resonance_multiplier * q_adjust;
+    const double drive_scaled = ladder_drive_scale(c.p_drive, c.pbg);
+    const double ac0 = alpha * 0.76923077, ac1 = alpha * 0.23076923, oma = 1.0 - alpha;
+    const int oversample = OS ? OS : c.oversample;               // OS = 2: a constant trip count, unrolled
+
+    auto sample = [&](float x) {
+        const double input_sample = (double)x * drive_scaled;
+        const double decay = fabs(input_sample) < input_threshold ? state_decay : 1.0;   // a select: no branch
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s.z0[q] *= decay;
+            s.z1[q] *= decay;
+        }
+        s.old_input *= decay;
+        double interp = 0.0;
+#pragma unroll
+        for (int os = 0; os < oversample; ++os) {
+            const double in_interp = __builtin_fma(interp, s.old_input, (1.0 - interp) * input_sample);
+            const double g = __builtin_fma(-(s.z1[3] - c.pbg * in_interp), kq, in_interp);
+            // a stage, ft = alpha * (c0*in + c1*z0 - z1) + z1, regrouped as (alpha*c0) * in + w with
+            // w = (alpha*c1) * z0 + (1 - alpha) * z1 known before the stage input is: one dependent operation per
+            // stage on the chain through the four stages instead of two
+            double w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = __builtin_fma(ac1, s.z0[q], oma * s.z1[q]);
+            double stage_in = FAST ? ladder_tanh_fast(g) : ladder_tanh_mid(g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double ft = __builtin_fma(ac0, stage_in, w[q]);
+                s.z1[q] = ft;
+                s.z0[q] = stage_in;
+                stage_in = ft;
+            }
+            interp += c.oversample_recip;
+        }
+        s.old_input = input_sample;
+    };
+    int64_t base = i0;
+    if (i1 - i0 >= kLadderChunk) {
+        float xn[kLadderChunk];
+#pragma unroll
+        for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + j) * c.channels + c.ch];
+        for (; base + kLadderChunk <= i1; base += kLadderChunk) {
+            float xc[kLadderChunk];
+#pragma unroll
+            for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
+            if (base + 2 * kLadderChunk <= i1) {
+#pragma unroll
+                for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + kLadderChunk + j) * c.channels + c.ch];
+            }
+#pragma unroll
+            for (int j = 0; j < kLadderChunk; ++j) sample(xc[j]);
+        }
+    }
+    for (; base < i1; ++base) sample(c.x[base * c.channels + c.ch]);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void ladder_warm(const LadderConsts &c, LadderState &s, int64_t i0, int64_t i1) {
+    if (__all(c.oversample == 2)) ladder_warm_impl<FAST, 2>(c, s, i0, i1);      // every active lane: wave-uniform
+    else ladder_warm_impl<FAST, 0>(c, s, i0, i1);
+}
+
 __device__ __forceinline__ void ladder_advance(const LadderConsts &c, LadderState &s, int64_t i0, int64_t emit_from,
                                                int64_t i1, double *snap = nullptr) {
     const int mode_u = __builtin_amdgcn_readfirstlane(c.mode);
@@ -238,7 +354,7 @@ __global__ void __launch_bounds__(64)
 k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
                   int channels, double sr, const pgx_ladder_params *params, const float *freq,
                   const float *resonance, const float *drive, const double *state, int64_t settle,
-                  int64_t seg_len, int nseg, double *warm, double *ends) {
+                  int64_t accurate, int64_t seg_len, int nseg, double *warm, double *ends) {
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t chains = (int64_t)batch * channels;
     if (t >= chains * nseg) return;
@@ -252,17 +368,31 @@ k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_st
     if (se > n) se = n;
     const int64_t ws = sb - settle;
     LadderState s;
-    int64_t i0 = 0;
+    // Every lane runs the same three phases (a wave that took different code paths would run them one after the
+    // other): fast warm-up [w0, w1), accurate warm-up [w1, sb), exact samples [sb, se).  A segment whose warm-up
+    // would reach before the block start begins at the block start from the carried state instead (nothing it
+    // produces before sb is emitted; k_ladder_finish checks it like any other segment).
+    int64_t w0, w1;
+    const bool scalar_params = !freq && !resonance && !drive;    // kernel arguments: uniform
     if (ws <= 0) {
-        s = ladder_load(state + (int64_t)chain * 9);             // reaches the block start: exact
+        s = ladder_load(state + (int64_t)chain * 9);
+        w0 = 0;
+        w1 = sb - accurate > 0 ? sb - accurate : 0;
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) s.z0[j] = s.z1[j] = 0.0;
         s.old_input = (double)c.x[(ws - 1) * channels + ch] *
                       ladder_drive_scale(drive ? (double)drive[ws - 1] : p.drive, c.pbg);
-        i0 = ws;
+        w0 = ws;
+        w1 = sb - accurate > ws ? sb - accurate : ws;
     }
-    ladder_advance(c, s, i0, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
+    if (scalar_params) {
+        ladder_warm<true>(c, s, w0, w1);
+        ladder_warm<false>(c, s, w1, sb);
+        ladder_advance(c, s, sb, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
+    } else {
+        ladder_advance(c, s, w0, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
+    }
     ladder_store(ends + ((int64_t)chain * nseg + seg) * 9, s);
 }
 
@@ -276,7 +406,6 @@ k_ladder_finish(float *out, int64_t out_stride, const float *in, int64_t in_stri
     const int chain = blockIdx.x, lane = threadIdx.x;
     bool bad = false;
     for (int seg = 1 + lane; seg < nseg; seg += 64) {
-        if ((int64_t)seg * seg_len - settle <= 0) continue;      // exact continuation, nothing assumed
         const double *a = warm + ((int64_t)chain * nseg + seg) * 9;
         const double *b = ends + ((int64_t)chain * nseg + seg - 1) * 9;
 #pragma unroll
@@ -430,7 +559,8 @@ LadderPlan ladder_plan(int batch, int64_t n, int channels, int64_t settle) {
     // CU: measured on C4 (64 chains x 48 000 frames, settle 1024), ms per block by lane count: 8 Ki 0.66, 16 Ki
     // 0.58, 24 Ki 0.56, 32 Ki 0.555, 48 Ki 0.78, 64 Ki 0.83 (the unrolled sample loop is ~40 KB of code: more waves
     // per CU at different places in it fall out of the instruction cache).  Never shorter than 32 samples.
-    int64_t seg_len = pgx::ceil_div(n * chains, (int64_t)32768);
+    static const int64_t lanes_target = getenv("PGX_LADDER_LANES") ? atoll(getenv("PGX_LADDER_LANES")) : 32768;
+    int64_t seg_len = pgx::ceil_div(n * chains, lanes_target);
     if (seg_len < 32) seg_len = 32;
     if (n < 2 * (settle + seg_len)) return p;                     // nothing to win
     p.segmented = true;
@@ -450,7 +580,7 @@ size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t se
 int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
                int channels, double sample_rate, const pgx_ladder_params *params, const float *freq,
                const float *resonance, const float *drive, double *state, int64_t settle_frames,
-               void *workspace) {
+               int64_t accurate_frames, void *workspace) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && params && state && channels >= 1 && sample_rate > 0, "pgx_ladder: bad argument");
@@ -473,7 +603,9 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
     const int64_t lanes = (int64_t)chains * p.nseg;
     hipLaunchKernelGGL(k_ladder_segments, dim3((unsigned)pgx::ceil_div(lanes, 64)), dim3(64), 0, pgx::stream(), out,
                        out_stride, in, in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
-                       (const double *)state, settle_frames, p.seg_len, p.nseg, warm, ends);
+                       (const double *)state, settle_frames,
+                       accurate_frames > 0 && accurate_frames < settle_frames ? accurate_frames : settle_frames,
+                       p.seg_len, p.nseg, warm, ends);
     PGX_LAUNCH_CHECK("k_ladder_segments");
     hipLaunchKernelGGL(k_ladder_finish, dim3(chains), dim3(64), 0, pgx::stream(), out, out_stride, in, in_stride, n,
                        channels, sample_rate, params, freq, resonance, drive, state, settle_frames, p.seg_len,

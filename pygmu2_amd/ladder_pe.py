@@ -21,6 +21,9 @@ from .processing_element import ProcessingElement
 from .snippet import Snippet
 
 
+ACCURATE_TAIL_FACTOR = 4e-4
+
+
 class LadderMode(Enum):
     LP24 = "lp24"
     LP12 = "lp12"
@@ -174,13 +177,21 @@ class LadderPE(ProcessingElement):
             self._workspace = DeviceBuffer((need,), np.uint8, zero=True)
         check(L.pgx_ladder(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate),
                            self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr, settle,
-                           ptr(self._workspace) if need else None), "pgx_ladder")
+                           self._accurate_frames(), ptr(self._workspace) if need else None), "pgx_ladder")
         return Snippet(start, out)
 
     def _settle_frames(self) -> int:
         if self._freq_is_pe or self._res_is_pe:
             return 0
         return ladder_settle_frames(self._frequency, self._resonance, self.sample_rate, self._oversample)
+
+    def _accurate_frames(self) -> int:
+        """Tail of a segment's warm-up that needs the float64 tanh: long enough to contract the ~1e-7 the
+        float32-tanh part leaves in the state down to the warm-up target (2e-10): a factor of 4e-4."""
+        if self._freq_is_pe or self._res_is_pe:
+            return 0
+        return ladder_settle_frames(self._frequency, self._resonance, self.sample_rate, self._oversample,
+                                    target=ACCURATE_TAIL_FACTOR)
 
     def __repr__(self) -> str:
         def s(is_pe, p):

@@ -206,6 +206,7 @@ class _LadderNode(_Node):
         self.ws = None
         settles = [pe._settle_frames() for pe in pes]
         self.settle = 0 if min(settles) == 0 else max(settles)     # one warm-up length for the batch
+        self.accurate = max(pe._accurate_frames() for pe in pes) if self.settle else 0
 
     def reset(self):
         super().reset()
@@ -226,8 +227,8 @@ class _LadderNode(_Node):
         if need and (self.ws is None or self.ws.nbytes < need):
             self.ws = DeviceBuffer((need,), np.uint8, zero=True)
         check(L.pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
-                           None, None, None, self.state.ptr, self.settle, ptr(self.ws) if need else None),
-              "pgx_ladder")
+                           None, None, None, self.state.ptr, self.settle, self.accurate,
+                           ptr(self.ws) if need else None), "pgx_ladder")
         return out
 
 

@@ -30,7 +30,8 @@ def env():
     return e
 
 
-def _ladder(e, x, settle, *, freq=1200.0, res=0.3, drive=1.0, mode=0, oversample=2, sr=48000.0, state0=None):
+def _ladder(e, x, settle, *, freq=1200.0, res=0.3, drive=1.0, mode=0, oversample=2, sr=48000.0, state0=None,
+            accurate=0):
     device, lib = e.device, e.lib
     n, ch = x.shape
     xin = device.DeviceBuffer.from_host(x)
@@ -41,7 +42,7 @@ def _ladder(e, x, settle, *, freq=1200.0, res=0.3, drive=1.0, mode=0, oversample
     need = lib.pgx_ladder_workspace_bytes(1, n, ch, settle)
     ws = device.DeviceBuffer((max(need, 8),), np.uint8, zero=True)
     device.check(lib.pgx_ladder(out.ptr, 0, xin.ptr, 0, 1, n, ch, sr, params.ptr, None, None, None, st.ptr,
-                                settle, ws.ptr if need else None))
+                                settle, accurate, ws.ptr if need else None))
     fallbacks = int(ws.to_host()[need - 16:need - 12].view(np.int32)[0]) if need else -1
     return out.to_host(), st.to_host(), fallbacks, need
 
@@ -71,6 +72,13 @@ def test_segmented_matches_sequential(env, mode, res, freq):
     peak = float(np.max(np.abs(y_seq)))
     assert float(np.max(np.abs(y_seg.astype(np.float64) - y_seq))) <= 1e-6 * peak
     assert np.allclose(st_seg, st_seq, rtol=1e-6, atol=1e-9)
+    # the two-speed warm-up LadderPE really uses: float32 tanh first, the float64 one for the tail
+    accurate = ladder_settle_frames(freq, res, 48000.0, 2, target=4e-4)
+    assert 0 < accurate < settle
+    y_two, st_two, fallbacks, _ = _ladder(env, x, settle, freq=freq, res=res, mode=mode, state0=s0, accurate=accurate)
+    assert fallbacks == 0, "the fast part of the warm-up left more than the accurate tail could contract"
+    assert float(np.max(np.abs(y_two.astype(np.float64) - y_seq))) <= 1e-6 * peak
+    assert np.allclose(st_two, st_seq, rtol=1e-6, atol=1e-9)
 
 
 def test_failed_check_rerenders_sequentially(env):
