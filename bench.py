@@ -232,9 +232,12 @@ def c2_graph(pg):
 def bench_c2(pg, dist, steps, warmup, frames=1_000_000):
     pe, r = c2_graph(pg)
     keep = {}
+    origin = (warmup + 1000) * frames                  # the timed steps start away from the warm-up steps: every
+                                                       # frame of the timed region is rendered inside it
 
     def step(i):
-        keep["s"] = pe.render(i * frames, frames)      # stays in HBM
+        pos = i * frames if i < warmup else origin + (i - warmup) * frames
+        keep["s"] = pe.render(pos, frames)             # stays in HBM
 
     dt = timed_steps(dist, step, steps, warmup)
     r.stop()
@@ -253,7 +256,7 @@ def bench_c2_with_d2h(pg, steps, warmup, frames=1_000_000):
         state = {"prev": None, "sum": 0.0}
 
         def step(i):
-            s = pe.render(i * frames, frames)
+            s = pe.render((i if i < warmup else i + 1000) * frames, frames)      # timed steps start cold
             if mode == "sync":
                 state["sum"] += float(s.data[-1, 0])
                 return
@@ -774,7 +777,12 @@ def main():
     if dist.rank == 0 and not args.no_extras and not sharded:
         solo = _Solo()
         result["device"] = device.device_name()
-        result["roofline"] = biquad_kernel_roofline(pg, 1_000_000, 200)
+        # the filter kernel as the C2 steps launch it: look-ahead renders `ahead` 1 M-frame steps per launch
+        from pygmu2_amd import look_ahead
+        ahead = max(2, min(look_ahead.AHEAD_BLOCKS, look_ahead.AHEAD_FRAMES // 1_000_000)) if look_ahead.enabled() else 1
+        result["roofline"] = biquad_kernel_roofline(pg, 1_000_000 * ahead, 100)
+        result["roofline"]["steps_per_launch"] = ahead
+        result["roofline_one_step"] = biquad_kernel_roofline(pg, 1_000_000, 200)
         result["roofline_scaled"] = biquad_kernel_roofline(pg, 1 << 26, 10)
         cases = {}
         if args.workload == "c2" and n_gpus == 1:

@@ -344,6 +344,14 @@ int pgx_supersaw_sum(float *out, int64_t out_stride, int batch, int nvoices, int
                      int channels, const float *voices, const double *amp_scalar /* [batch] */,
                      const float *amp, int64_t amp_stride);
 
+/* A bank of mono BiquadPE(BlitSawPE) voices with scalar parameters in one launch: the oscillator's float32
+ * samples go through the constant-coefficient section (scipy's DF-II-T order, pgx_biquad_const) without leaving
+ * the chip.  params / saw_state as for pgx_blitsaw; coef = [batch][5] {b0,b1,b2,a1,a2}; biquad_state = [batch][2].
+ * One workgroup per voice: for banks of >= 128 voices. */
+int pgx_blitsaw_biquad_bank(float *out, int64_t out_stride, int batch, int64_t n, double sample_rate,
+                            const pgx_blitsaw_params *params, double *saw_state /* [batch][2] */,
+                            const double *coef, double *biquad_state /* [batch][2] */);
+
 /* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
  * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the
  * [batch*nvoices][frames] intermediate (one workgroup per instance, one wave per oscillator; nvoices <= 16).

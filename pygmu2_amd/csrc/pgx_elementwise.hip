@@ -290,16 +290,19 @@ __global__ void __launch_bounds__(kBlock) k_gain_mix_batch(float *out, const flo
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elems; e += stride) {
         const int64_t ge = (gain_channels == channels) ? e : e / channels;
         float acc = x[e] * g[ge];
-        float xv[8], gv[8];
+        // one thread per frame (the additions are ordered by voice): what keeps HBM busy is the number of loads in
+        // flight per thread -- 32 voices x 2 streams
+        constexpr int U = 32;
+        float xv[U], gv[U];
         int b = 1;
-        for (; b + 8 <= batch; b += 8) {
+        for (; b + U <= batch; b += U) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 xv[u] = x[(int64_t)(b + u) * x_stride + e];
                 gv[u] = g[(int64_t)(b + u) * g_stride + ge];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 float prod = xv[u] * gv[u];
                 acc = acc + prod;
             }

@@ -1054,6 +1054,174 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// A bank of BiquadPE(BlitSawPE) voices in one launch (the C5 voice: blit_saw_pe.py:150-264 feeding
+// biquad_pe.py:383-404).  One 256-thread workgroup per voice, 2048-frame tiles rendered exactly as
+// k_blitsaw<false, 4, 0> renders them; the float32 oscillator samples then stay in registers and go through the
+// constant-coefficient section the way k_biquad_settled runs it: zero-state response of the thread's 8 frames
+// (fused multiply-adds: it only feeds carries), Kogge-Stone scan of the affine maps over the wave with the powers
+// A^(8*2^k) from LDS, waves folded in order, then the 8 frames re-run from the scanned carry-in in scipy's
+// DF-II-T operation order.  The [voices][frames] oscillator buffer is neither written nor read.  Mono, scalar
+// parameters.
+struct SawBqShared {
+    double sum[kWaves];
+    double aff[2 * kWaves];
+    V2 tot[2][kWaves];
+    M2 pstep[6];        // A^(8 * 2^k)
+    M2 pwave;           // A^(8 * 64)
+};
+__global__ void __launch_bounds__(kWaves * 64)
+k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx_blitsaw_params *params,
+                 double *saw_state, const double *coef, double *bq_state) {
+    constexpr int NW = kWaves;
+    constexpr int kTile = NW * 64 * kSawT;
+    __shared__ SawBqShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int inst = blockIdx.x;
+    const pgx_blitsaw_params p = params[inst];
+    float *ob = out + (int64_t)inst * out_stride;
+    const double b0 = coef[inst * 5 + 0], b1 = coef[inst * 5 + 1], b2 = coef[inst * 5 + 2];
+    const double a1 = coef[inst * 5 + 3], a2 = coef[inst * 5 + 4];
+    if (tid == 0) {
+        M2 q{-a1, 1.0, -a2, 0.0};
+#pragma unroll
+        for (int t = 1; t < kSawT; t <<= 1) q = mm(q, q);        // A^8
+        for (int k = 0; k < 6; ++k) {
+            sh.pstep[k] = q;
+            q = mm(q, q);
+        }
+        sh.pwave = q;
+    }
+    __syncthreads();
+    M2 mlane = m_identity();                                      // A^(8 * lane)
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (lane & (1 << k)) mlane = mm(sh.pstep[k], mlane);
+    const M2 pwave = sh.pwave;
+
+    const double phase0 = saw_state[inst * 2 + 0];
+    double carry_sum = 0.0;
+    double carry_y = saw_state[inst * 2 + 1];
+    V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
+    const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
+    const double m_over_p = k0.m / k0.P;
+    const double leak = p.leak;
+    double lamp[6], lam_wave, lam_lane = 1.0;
+    {
+        double l = leak;
+#pragma unroll
+        for (int t = 1; t < kSawT; t <<= 1) l = l * l;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            lamp[k] = l;
+            if (lane & (1 << k)) lam_lane = lam_lane * l;
+            l = l * l;
+        }
+        lam_wave = l;
+    }
+    int parity = 0;
+    for (int64_t base = 0; base < n; base += kTile, ++parity) {
+        const int64_t f0 = base + (int64_t)tid * kSawT;
+        double loc[kSawT];
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            run = run + ((f0 + j < n) ? k0.inc : 0.0);
+            loc[j] = run;
+        }
+        const double chunk_base = (base + kTile <= n) ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
+                                                      : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
+        double xb[kSawT];
+        double final_phase = 0.0, final_y = 0.0;
+        auto dirichlet = [&](auto bounded) {
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) {
+                const double ph = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));
+                const double theta = kPi * ph;
+                const double m_theta = k0.m * theta;
+                const double sin_num = saw_sin_num<decltype(bounded)::value>(m_theta);
+                const double sin_den = pgx::pgx_sin_bounded(theta);
+                double blit = pgx::pgx_div_fast(sin_num, k0.P * sin_den);
+                if (fabs(sin_den) < 1e-9) blit = m_over_p;
+                xb[j] = (f0 + j < n) ? (blit - k0.invP) : 0.0;
+                if (f0 + j == n - 1) final_phase = ph;
+            }
+        };
+        if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
+        else dirichlet(std::false_type{});
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
+        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lam_lane, sh.aff, parity, carry_y);
+        float xf[kSawT];
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            double z = leak * y;
+            y = z + xb[j];
+            xf[j] = (f0 + j < n) ? (float)((y * 2.0) * p.amp) : 0.0f;       // BlitSawPE's float32 output
+            if (f0 + j == n - 1) final_y = y;
+        }
+        const bool last = f0 <= n - 1 && n - 1 < f0 + kSawT;      // the thread that renders the last frame
+        if (last) {
+            saw_state[inst * 2 + 0] = final_phase;
+            saw_state[inst * 2 + 1] = final_y;
+        }
+
+        // ---- the filter section on the 8 frames in registers (biquad_pe.py:383-404) ----
+        V2 ez{0.0, 0.0};
+        const double na1 = -a1, na2 = -a2;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {
+            const double x = (double)xf[j];
+            const double yy = __builtin_fma(b0, x, ez.x);
+            ez.x = __builtin_fma(na1, yy, __builtin_fma(b1, x, ez.y));
+            ez.y = __builtin_fma(na2, yy, b2 * x);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const V2 o = shfl_up_v2(ez, 1 << k);
+            const M2 pk = sh.pstep[k];
+            if (lane >= (1 << k)) ez = mv_add_fma(pk, o, ez);
+        }
+        if (lane == 63) sh.tot[parity & 1][wave] = ez;
+        __syncthreads();
+        V2 cw = carry_z, fold = carry_z;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            fold = mv_add_fma(pwave, fold, sh.tot[parity & 1][w]);
+            if (w + 1 == wave) cw = fold;                         // this wave's carry-in
+        }
+        carry_z = fold;
+        V2 ex = shfl_up_v2(ez, 1);
+        if (lane == 0) ex = V2{0.0, 0.0};
+        const V2 zin = mv_add_fma(mlane, cw, ex);
+        V2 z = zin;
+        float yf[kSawT];
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) {                         // scipy lfilter DF-II-T operation order
+            const double x = (double)xf[j];
+            const double yy = z.x + b0 * x;
+            const double z0 = (z.y + b1 * x) - a1 * yy;
+            z.y = b2 * x - a2 * yy;
+            z.x = z0;
+            yf[j] = (float)yy;
+        }
+        store_frames<kSawT>(ob, f0, n, 1, 0, yf);
+        if (last) {                                               // the new filter state: up to the last frame only
+            z = zin;
+            for (int j = 0; j <= (int)(n - 1 - f0); ++j) {
+                const double x = (double)xf[j];
+                const double yy = z.x + b0 * x;
+                const double z0 = (z.y + b1 * x) - a1 * yy;
+                z.y = b2 * x - a2 * yy;
+                z.x = z0;
+            }
+            bq_state[inst * 2 + 0] = z.x;
+            bq_state[inst * 2 + 1] = z.y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A bank of SuperSawPEs, voices summed on chip (super_saw_pe.py:304-316 on top of blit_saw_pe.py:150-264).
 // One 512-thread workgroup per SuperSaw instance.  A 4096-frame tile is rendered voice after voice exactly as
 // k_blitsaw<false, 8, 0> renders it (same wave values, same folds: the float32 samples of every oscillator are
@@ -2156,6 +2324,20 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     else PGX_SAW_LAUNCH(false, kWaves, 0, dim3(batch));
 #undef PGX_SAW_LAUNCH
     PGX_LAUNCH_CHECK("k_blitsaw");
+    return PGX_OK;
+}
+
+int pgx_blitsaw_biquad_bank(float *out, int64_t out_stride, int batch, int64_t n, double sample_rate,
+                            const pgx_blitsaw_params *params, double *saw_state, const double *coef,
+                            double *biquad_state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && saw_state && coef && biquad_state && sample_rate > 0,
+                  "pgx_blitsaw_biquad_bank: bad argument");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_blitsaw_biquad_bank: out_stride too small");
+    hipLaunchKernelGGL(k_blitsaw_biquad, dim3(batch), dim3(kWaves * 64), 0, pgx::stream(), out, out_stride, n,
+                       sample_rate, params, saw_state, coef, biquad_state);
+    PGX_LAUNCH_CHECK("k_blitsaw_biquad");
     return PGX_OK;
 }
 

@@ -33,9 +33,9 @@ import numpy as np
 
 from . import read_ahead as _read_ahead
 
-SMALL_BLOCK = 65536         # pulls up to this many frames are served from a look-ahead window
+SMALL_BLOCK = 1 << 20       # pulls up to this many frames are served from a look-ahead window
 AHEAD_BLOCKS = 64           # at most this many blocks per window ...
-AHEAD_FRAMES = 1 << 19      # ... and about this many frames (44 100-frame pulls: 11 blocks per window)
+AHEAD_FRAMES = 1 << 22      # ... and about this many frames (1 M-frame pulls: 4 blocks per window)
 
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_LOOK_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")

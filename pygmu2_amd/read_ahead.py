@@ -22,9 +22,11 @@ from __future__ import annotations
 import os
 import threading
 
-SMALL_BLOCK = 65536         # requests up to this many frames are served from a resident window
+SMALL_BLOCK = 1 << 20       # requests up to this many frames are served from a resident window
 AHEAD_BLOCKS = 64           # at most this many blocks per refill ...
-AHEAD_FRAMES = 1 << 19      # ... and about this many frames (a 44 100-frame pull refills 11 blocks at a time)
+AHEAD_FRAMES = 1 << 22      # ... and about this many frames (16 MB per channel: a 44 100-frame pull refills 64
+                            # blocks at a time, a 1 M-frame pull 4: launches of that size leave the ~4 us floor
+                            # of a launch behind and stream at HBM rate)
 
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_READ_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")

@@ -36,6 +36,7 @@ from .snippet import Snippet
 from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
+FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 FUSED_SUPERSAW_MIN = 128     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
 
@@ -102,9 +103,13 @@ class _BlitSawNode(_Node):
     def channels(self):
         return self.ch
 
-    def render(self, start, n):
+    def prepare(self, start):
+        """The reset rule of blit_saw_pe.py: a render that does not continue the previous one starts over."""
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
+
+    def render(self, start, n):
+        self.prepare(start)
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
         ws = blitsaw_workspace(self, self.k, n, False)
         check(lib().pgx_blitsaw(out.ptr, n * self.ch, self.k, n, self.ch, self.sr, self.params.ptr,
@@ -177,7 +182,18 @@ class _BiquadNode(_Node):
 
     def render(self, start, n):
         L = lib()
-        x = self.children["source"].render(start, n)
+        src = self.children["source"]
+        if isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= FUSED_VOICE_MIN:
+            # oscillator -> filter without the [K][frames] oscillator buffer (pgx_blitsaw_biquad_bank)
+            if self.state is None:
+                self.state = DeviceBuffer((self.k, 1, 2), np.float64, zero=True)
+            src.prepare(start)
+            out = DeviceBuffer((self.k, n, 1), np.float32)
+            check(L.pgx_blitsaw_biquad_bank(out.ptr, n, self.k, n, self.sr, src.params.ptr, src.state.ptr,
+                                            self.coef.ptr, self.state.ptr), "pgx_blitsaw_biquad_bank")
+            src.last_end = start + n
+            return out
+        x = src.render(start, n)
         ch = x.shape[2]
         if self.state is None:
             self.state = DeviceBuffer((self.k, ch, 2), np.float64, zero=True)

@@ -176,3 +176,29 @@ def test_supersaw_bank_summed_on_chip_is_the_two_launch_path_bit_for_bit(voices,
     got_plain = _render_blocks(plain, 48000, blocks[:2])
     for a, b in zip(got_fused, got_plain):
         assert np.array_equal(a, b), float(np.max(np.abs(a - b)))
+
+
+def test_blitsaw_biquad_bank_in_one_launch_matches_the_two_launch_bank(monkeypatch):
+    """pgx_blitsaw_biquad_bank (oscillator samples filtered in registers) against pgx_blitsaw + pgx_biquad_const
+    over the same 140 voices: the oscillator bits are the same, the filter's carry-ins come out of a differently
+    shaped scan (so a float32 sample may differ in its last bit once in a long while), states carry over blocks,
+    a gap resets the oscillators."""
+    from pygmu2_amd import voice_bank
+    pg.set_sample_rate(48000)
+    idx = list(range(0, 512, 4)) + list(range(1, 48, 4))          # 140 voices
+
+    def make():
+        return pg.MixPE(*[c5_voice(pg, i) for i in idx])
+
+    blocks = [(0, 6000), (6000, 2048), (8048, 4097), (30000, 1000)]
+    fused = make()
+    got = _render_blocks(fused, 48000, blocks)
+    assert fused._bank and fused._bank.k == len(idx)
+    monkeypatch.setattr(voice_bank, "FUSED_VOICE_MIN", 10 ** 9)
+    plain = make()
+    want = _render_blocks(plain, 48000, blocks)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        peak = float(np.max(np.abs(b)))
+        assert float(np.max(np.abs(a.astype(np.float64) - b))) <= 2e-7 * peak
+        assert np.mean(a != b) < 1e-3
