@@ -33,6 +33,7 @@
 //     segment's affine map, the apply launch folds the earlier maps onto the carried state.
 // Many short chains (voices) use one workgroup per chain and no cross-workgroup traffic at all.
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "pgx_common.h"
@@ -2013,7 +2014,8 @@ constexpr double kEnvSettled = 1e-13;
 template <int NW, int T, bool PEAK>
 __global__ void __launch_bounds__(NW * 64)
 k_env_newton(float *out, const float *in, const double *det, int64_t n, int channels, double attack_coeff,
-             double release_coeff, double *state) {
+             double release_coeff, double *state, const int *run_flag) {
+    if (run_flag != nullptr && *run_flag == 0) return;       // armed only when the all-windows form gave up
     __shared__ double s_a[2][NW], s_b[2][NW], s_pa[T + 1], s_pr[T + 1];
     __shared__ int s_moved[2][NW];
     constexpr int kWindow = NW * 64 * T;
@@ -2156,6 +2158,221 @@ k_env_newton(float *out, const float *in, const double *det, int64_t n, int chan
         e_in = exit_level;                           // composition of all pieces (dead samples are the identity)
     }
     if (tid == 0) state[ch] = e_in;
+}
+
+// The same follower over a LONG block (look-ahead windows hand it millions of frames): all 8192-sample windows
+// at once.  A window's exit level is an affine function of its entry level on the piece the trajectory runs
+// through (A = product of the per-sample slopes, tiny after thousands of samples), so the entry levels of all
+// windows solve a piecewise linear system of their own, again by Newton rounds -- one launch per round:
+//   round 0   every window is solved (the inner rounds above) from the carried level and publishes its piece;
+//   round r   a window folds the pieces of the windows before it (published in round r-1) onto the carried
+//             level; if that entry is the one its samples were rendered from (1e-13) it republishes its piece and
+//             is done, otherwise it renders again from the new entry and raises the round's "moved" flag.
+// No window moved in a round = every window was rendered from the entry the others imply: converged; later
+// launches return at once.  Window w is final after at most w+1 rounds, audio settles in 2..4 (a window forgets
+// its entry by orders of magnitude).  If kEnvMwRounds are not enough the finishing kernel arms the sequential
+// kernel above, which then renders the block from the carried state: the result never depends on convergence.
+constexpr int kEnvMwRounds = 8;
+constexpr int kEnvMwNW = 8, kEnvMwT = 16, kEnvMwWindow = kEnvMwNW * 64 * kEnvMwT;      // 8192
+struct EnvMwCtl {
+    int moved[kEnvMwRounds + 1];
+    int fallback;
+};
+template <bool PEAK>
+__global__ void __launch_bounds__(kEnvMwNW * 64)
+k_env_newton_mw(float *out, const float *in, const double *det, int64_t n, int channels, double attack_coeff,
+                double release_coeff, const double *state, int round, int nwin, double *pa_buf, double *pb_buf,
+                double *guess, EnvMwCtl *ctl) {
+    constexpr int NW = kEnvMwNW, T = kEnvMwT, kWindow = kEnvMwWindow, kThreads = NW * 64;
+    __shared__ double s_a[2][NW], s_b[2][NW], s_pa[T + 1], s_pr[T + 1], s_entry;
+    __shared__ int s_moved[2][NW];
+    using Raw = typename std::conditional<PEAK, float, double>::type;
+    __shared__ Raw s_x[kWindow + kWindow / T];
+    __shared__ float s_y[kWindow + kWindow / T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x, ch = blockIdx.y;
+    if (round > 0 && ctl->moved[round - 1] == 0) return;         // converged in an earlier round
+    const int64_t base = (int64_t)w * kWindow;
+    const int cur = round & 1, prev = cur ^ 1;
+    double *pa_cur = pa_buf + ((int64_t)cur * channels + ch) * nwin, *pb_cur = pb_buf + ((int64_t)cur * channels + ch) * nwin;
+    const double *pa_prev = pa_buf + ((int64_t)prev * channels + ch) * nwin;
+    const double *pb_prev = pb_buf + ((int64_t)prev * channels + ch) * nwin;
+
+    // request the window's frames first: their latency covers the fold below
+    Raw raw[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        int64_t f = base + i * kThreads + tid;
+        f = f < n ? f : n - 1;
+        if constexpr (PEAK) raw[i] = in[f * channels + ch];
+        else raw[i] = det[f * channels + ch];
+    }
+    if (tid == 0) {
+        double pa = 1.0, pr = 1.0;
+        for (int k = 0; k <= T; ++k) {
+            s_pa[k] = pa;
+            s_pr[k] = pr;
+            pa = pa * (1.0 - attack_coeff);
+            pr = pr * (1.0 - release_coeff);
+        }
+    }
+    // entry level: the carried level pushed through the pieces of windows 0..w-1 (wave 0: lanes compose runs of
+    // pieces, then a scan over the lanes)
+    if (wave == 0) {
+        double a = 1.0, b = 0.0;
+        if (round > 0) {
+            const int per = (w + 63) / 64;
+            const int v0 = lane * per, v1 = (v0 + per < w) ? v0 + per : w;
+            for (int v = v0; v < v1; ++v) {
+                const double av = pa_prev[v], bv = pb_prev[v];
+                b = __builtin_fma(av, b, bv);
+                a = a * av;
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ao = __shfl_up(a, d, 64), bo = __shfl_up(b, d, 64);
+                if (lane >= d) {
+                    b = __builtin_fma(a, bo, b);
+                    a = a * ao;
+                }
+            }
+        }
+        if (lane == 63) s_entry = __builtin_fma(a, state[ch], b);
+    }
+    __syncthreads();
+    const double e_in = s_entry;
+    if (round > 0) {
+        const double g = guess[(int64_t)ch * nwin + w];
+        if (fabs(e_in - g) <= kEnvSettled * (fabs(e_in) + fabs(g))) {      // rendered from this entry already
+            if (tid == 0) {
+                pa_cur[w] = pa_prev[w];
+                pb_cur[w] = pb_prev[w];
+            }
+            return;
+        }
+    }
+    if (tid == 0) {
+        ctl->moved[round] = 1;
+        guess[(int64_t)ch * nwin + w] = e_in;
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int k = i * kThreads + tid;
+        s_x[k + k / T] = raw[i];
+    }
+    __syncthreads();
+    double t[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const Raw v = s_x[tid * (T + 1) + j];
+        t[j] = PEAK ? fabs((double)v) : (double)v;
+    }
+    const int64_t f0 = base + (int64_t)tid * T;
+    const int live = (n - f0 >= T) ? T : (n - f0 > 0 ? (int)(n - f0) : 0);
+    double entry = e_in, a_tot = 1.0, b_tot = 0.0;
+    double y[T];
+    for (int rnd = 0; rnd <= NW * 64 + 1; ++rnd) {
+        double e = entry;
+        int attacks = 0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const bool on = j < live;
+            const bool attack = t[j] > e;
+            const double stepped = e + (attack ? attack_coeff : release_coeff) * (t[j] - e);
+            attacks += (on && attack) ? 1 : 0;
+            e = on ? stepped : e;
+            y[j] = e;
+        }
+        double a = s_pa[attacks] * s_pr[live - attacks];
+        double b = __builtin_fma(-a, entry, e);
+#define PGX_ENV_STEP(CTRL, MASK)                                            \
+        {                                                                   \
+            const double ao = dpp_f64_keep<CTRL, MASK>(1.0, a);             \
+            const double bo = dpp_f64_keep<CTRL, MASK>(0.0, b);             \
+            b = __builtin_fma(a, bo, b);                                    \
+            a = a * ao;                                                     \
+        }
+        PGX_ENV_STEP(0x111, 0xf) PGX_ENV_STEP(0x112, 0xf) PGX_ENV_STEP(0x114, 0xf) PGX_ENV_STEP(0x118, 0xf)
+        PGX_ENV_STEP(0x142, 0xa) PGX_ENV_STEP(0x143, 0xc)
+#undef PGX_ENV_STEP
+        const int buf = rnd & 1;
+        if (lane == 63) {
+            s_a[buf][wave] = a;
+            s_b[buf][wave] = b;
+        }
+        __syncthreads();
+        double cw = e_in, ta = 1.0, tb = 0.0;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const double wa = s_a[buf][v], wb = s_b[buf][v];
+            if (v < wave) cw = __builtin_fma(wa, cw, wb);
+            tb = __builtin_fma(wa, tb, wb);                       // the window's piece: exit = ta * entry + tb
+            ta = ta * wa;
+        }
+        a_tot = ta;
+        b_tot = tb;
+        const double aex = dpp_f64_keep<0x138, 0xf>(1.0, a);
+        const double bex = dpp_f64_keep<0x138, 0xf>(0.0, b);
+        const double fresh = __builtin_fma(aex, cw, bex);
+        const bool moved = live > 0 && fabs(fresh - entry) > kEnvSettled * (fabs(fresh) + fabs(entry));
+        entry = fresh;
+        const bool wave_moved = __ballot(moved) != 0ull;
+        if (lane == 0) s_moved[buf][wave] = wave_moved ? 1 : 0;
+        __syncthreads();
+        int any = 0;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) any |= s_moved[buf][v];
+        if (!any) break;
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) s_y[tid * (T + 1) + j] = (float)y[j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int k = i * kThreads + tid;
+        if (base + k < n) out[(base + k) * channels + ch] = s_y[k + k / T];
+    }
+    if (tid == 0) {
+        pa_cur[w] = a_tot;
+        pb_cur[w] = b_tot;
+    }
+}
+
+// After the last round: converged -> the new carried level is the carried level pushed through every piece;
+// otherwise arm the sequential kernel.
+__global__ void __launch_bounds__(64)
+k_env_mw_finish(double *state, int channels, int nwin, const double *pa_buf, const double *pb_buf, EnvMwCtl *ctl,
+                int rounds) {
+    const int lane = threadIdx.x;
+    int last = 0;                                                 // the last round in which a window moved
+    for (int r = 0; r < rounds; ++r)
+        if (ctl->moved[r]) last = r;
+    const bool converged = last < rounds - 1;                     // a later round ran and found nothing to move
+    if (!converged) {
+        if (lane == 0 && blockIdx.x == 0) ctl->fallback = 1;
+        return;
+    }
+    // pieces of the converged configuration: published by the last round that ran to its end, i.e. `last` (a round
+    // in which nothing moved republishes the same pieces); round last + 1, if launched, returned at once
+    const int ch = blockIdx.x;
+    const int cur = (last + 1) & 1;                               // that later round republished every piece
+    const double *pa = pa_buf + ((int64_t)cur * channels + ch) * nwin, *pb = pb_buf + ((int64_t)cur * channels + ch) * nwin;
+    double a = 1.0, b = 0.0;
+    const int per = (nwin + 63) / 64;
+    const int v0 = lane * per, v1 = (v0 + per < nwin) ? v0 + per : nwin;
+    for (int v = v0; v < v1; ++v) {
+        b = __builtin_fma(pa[v], b, pb[v]);
+        a = a * pa[v];
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double ao = __shfl_up(a, d, 64), bo = __shfl_up(b, d, 64);
+        if (lane >= d) {
+            b = __builtin_fma(a, bo, b);
+            a = a * ao;
+        }
+    }
+    if (lane == 63) state[ch] = __builtin_fma(a, state[ch], b);
 }
 
 // ================================================================================================
@@ -2411,9 +2628,13 @@ int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_
     return PGX_OK;
 }
 
+constexpr int64_t kEnvMwMinFrames = 16 * (int64_t)kEnvMwWindow;      // from here on all windows at once
+
 size_t pgx_envelope_scratch_bytes(int64_t n, int channels) {
     if (n <= 0 || channels <= 0) return 0;
-    return (size_t)(n + (n + kEnvBlock - 1) / kEnvBlock) * channels * sizeof(double);
+    const size_t base = (size_t)(n + (n + kEnvBlock - 1) / kEnvBlock) * channels;
+    const size_t nwin = (size_t)((n + kEnvMwWindow - 1) / kEnvMwWindow);
+    return (base + 5 * nwin * channels + 8) * sizeof(double);              // + pieces (2 x 2), entries, control
 }
 
 int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
@@ -2440,9 +2661,37 @@ int pgx_envelope(float *out, const float *in, int64_t n, int channels, double at
         PGX_LAUNCH_CHECK("k_env_onepole");
     } else {
         const double *det = fused_peak ? nullptr : (const double *)scratch;
+        const int *run_flag = nullptr;
+        const int64_t nwin64 = (n + kEnvMwWindow - 1) / kEnvMwWindow;
+        if (n >= kEnvMwMinFrames && nwin64 <= 65535 && channels <= 65535) {
+            // all windows at once, one launch per Newton round over the windows' entry levels
+            const int nwin = (int)nwin64;
+            double *mw = scratch + (size_t)(n + (n + kEnvBlock - 1) / kEnvBlock) * channels;
+            double *pa_buf = mw, *pb_buf = mw + 2 * (size_t)nwin * channels, *guess = mw + 4 * (size_t)nwin * channels;
+            EnvMwCtl *ctl = reinterpret_cast<EnvMwCtl *>(mw + 5 * (size_t)nwin * channels);
+            PGX_HIP(hipMemsetAsync(ctl, 0, sizeof(EnvMwCtl), pgx::stream()));
+            // (PGX_ENV_MW_ROUNDS=1 makes every block give up: the test of the fallback)
+            static const int rounds_env = getenv("PGX_ENV_MW_ROUNDS") ? atoi(getenv("PGX_ENV_MW_ROUNDS")) : kEnvMwRounds;
+            const int rounds = rounds_env < 1 ? 1 : (rounds_env > kEnvMwRounds ? kEnvMwRounds : rounds_env);
+            for (int r = 0; r < rounds; ++r) {
+                if (fused_peak)
+                    hipLaunchKernelGGL(k_env_newton_mw<true>, dim3(nwin, channels), dim3(kEnvMwNW * 64), 0,
+                                       pgx::stream(), out, in, det, n, channels, attack_coeff, release_coeff,
+                                       (const double *)state, r, nwin, pa_buf, pb_buf, guess, ctl);
+                else
+                    hipLaunchKernelGGL(k_env_newton_mw<false>, dim3(nwin, channels), dim3(kEnvMwNW * 64), 0,
+                                       pgx::stream(), out, in, det, n, channels, attack_coeff, release_coeff,
+                                       (const double *)state, r, nwin, pa_buf, pb_buf, guess, ctl);
+                PGX_LAUNCH_CHECK("k_env_newton_mw");
+            }
+            hipLaunchKernelGGL(k_env_mw_finish, dim3(channels), dim3(64), 0, pgx::stream(), state, channels, nwin,
+                               (const double *)pa_buf, (const double *)pb_buf, ctl, rounds);
+            PGX_LAUNCH_CHECK("k_env_mw_finish");
+            run_flag = &ctl->fallback;                // the sequential kernel below runs only if that gave up
+        }
 #define PGX_ENV_LAUNCH(NW, T, PEAK)                                                                               \
         hipLaunchKernelGGL((k_env_newton<NW, T, PEAK>), dim3(channels), dim3(NW * 64), 0, pgx::stream(), out, in, det, \
-                           n, channels, attack_coeff, release_coeff, state)
+                           n, channels, attack_coeff, release_coeff, state, run_flag)
         if (n <= 1024) {
             if (fused_peak) PGX_ENV_LAUNCH(4, 4, true);
             else PGX_ENV_LAUNCH(4, 4, false);

@@ -35,7 +35,7 @@ from . import read_ahead as _read_ahead
 
 SMALL_BLOCK = 1 << 20       # pulls up to this many frames are served from a look-ahead window
 AHEAD_BLOCKS = 64           # at most this many blocks per window ...
-AHEAD_FRAMES = 1 << 22      # ... and about this many frames (1 M-frame pulls: 4 blocks per window)
+AHEAD_FRAMES = 1 << 23      # ... and about this many frames (1 M-frame pulls: 8 blocks per window)
 
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_LOOK_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")

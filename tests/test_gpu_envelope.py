@@ -76,3 +76,58 @@ def test_follower_long_block_and_detectors(mode):
     peak = float(np.max(np.abs(want)))
     err = float(np.max(np.abs(got.astype(np.float64) - want)))
     assert err <= REL_TOL * peak + 1e-7, (mode, err, peak)
+
+
+@pytest.mark.parametrize("attack,release", [(0.005, 0.05), (0.001, 2.0), (0.3, 0.0005), (0.0, 0.03)])
+@pytest.mark.parametrize("name", ["sine", "noise", "bursts", "silence_then_step"])
+def test_all_windows_at_once_matches_oracle_and_carries_state(name, attack, release):
+    """Blocks of >= 131 072 frames take the form that solves every 8192-sample window concurrently (Newton rounds
+    over the windows' entry levels, one launch per round): against the oracle's literal loop, over two such
+    blocks and a short one in a row (carried level), with a slow release (a window barely forgets its entry)."""
+    from oracle import pe_oracle as O
+    import pygmu2_amd as pg
+    pg.set_sample_rate(44100)
+    n = 700_000
+    mono = _signals(n)[name]
+    x = np.stack([mono, np.roll(mono, 1234) * 0.25], axis=1).astype(np.float32)
+    pe = pg.EnvelopePE(pg.ArrayPE(x), attack=attack, release=release)
+    r = pg.NullRenderer(sample_rate=44100)
+    r.set_source(pe)
+    r.start()
+    got = np.concatenate([pe.render(s, m).data for s, m in ((0, 300_001), (300_001, 4000), (304_001, 395_999))])
+    r.stop()
+    st = O.envelope_state()
+    want = O.envelope(st, x, attack=attack, release=release, mode="peak", sr=44100)
+    peak = float(np.max(np.abs(want))) or 1.0
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= REL_TOL * peak + 1e-7
+
+
+def test_all_windows_form_falls_back_when_its_rounds_run_out(tmp_path):
+    """One round is never enough (the first round renders every window from the same guess): the block must come
+    out of the sequential kernel, identical to a render that never tried."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PGX_ROOT"])
+import pygmu2_amd as pg
+pg.set_sample_rate(44100)
+t = np.arange(400_000) / 44100.0
+x = (0.7 * np.sin(2 * np.pi * 110.0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 1.5 * t))).astype(np.float32)
+pe = pg.EnvelopePE(pg.ArrayPE(x), attack=0.004, release=0.08)
+r = pg.NullRenderer(44100); r.set_source(pe); r.start()
+a = np.concatenate([pe.render(0, 250_000).data, pe.render(250_000, 150_000).data])
+r.stop()
+np.save(os.environ["PGX_OUT"], a)
+""")
+    outs = []
+    for rounds in ("1", "8"):
+        out = str(tmp_path / f"r{rounds}.npy")
+        env = dict(os.environ, PGX_ROOT=root, PGX_OUT=out, PGX_ENV_MW_ROUNDS=rounds)
+        p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(out))
+    assert outs[0].shape == outs[1].shape
+    assert float(np.max(np.abs(outs[0] - outs[1]))) <= 1e-6 * float(np.max(np.abs(outs[1])))
