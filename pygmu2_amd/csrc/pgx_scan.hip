@@ -2568,7 +2568,7 @@ int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, in
     PGX_CHECK_ARG(nvoices >= 1 && nvoices <= 16, "pgx_supersaw_bank: 1..16 voices per instance");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_bank: out_stride too small");
     // (a third wave per SIMD, forced with a 168-VGPR cap, spills and is slower: 0.88 against 0.78 ms per block)
-    if (batch >= 512)
+    if (batch > 256)                       // two 4-wave workgroups per CU; up to 256 instances: one 8-wave each
         hipLaunchKernelGGL(k_supersaw_bank<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
                            nvoices, n, channels, sample_rate, params, state, amp_scalar);
     else

@@ -37,7 +37,7 @@ from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
-FUSED_SUPERSAW_MIN = 128     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
+FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
 
 def _is_pe(x) -> bool:
