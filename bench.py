@@ -613,7 +613,7 @@ def mix_entry(pg, dist, config, steps, warmup, with_cpu):
     return out
 
 
-def cpu_mix(config, voices, frames, budget_s=4.0, max_picks=24):
+def cpu_mix(config, voices, frames, budget_s=5.0, max_picks=96):
     """CPU oracle on a bounded sample of the same workload: voices spread evenly over the index range (the
     cost grows with the oscillator frequency), one block each, until `budget_s` seconds are spent; the block of
     all `voices` is their mean x voices (voices are independent and the mix is one add per voice).  1 thread."""
