@@ -882,6 +882,55 @@ __device__ __forceinline__ double saw_sin_num(double m_theta) {
 }
 constexpr double kSawBoundedM = 9.0e5;
 
+// Scalar frequency, odd M (what the rule sr / (2f) always produces): a thread's 8 consecutive samples advance
+// the phase by the same increment, so only the first one evaluates sin / cos of theta and M*theta; the other seven
+// turn both pairs by the fixed angles pi*inc and M*pi*inc (two FMAs per component).  The wrap of the phase at 1
+// needs no attention: theta -> theta - pi flips the sign of sin(theta) and, M being odd, of sin(M*theta): the
+// ratio is unchanged.  71 -> ~40 instructions per sample in the Dirichlet block; the seven rotations add ~1e-15.
+struct SawRot {
+    double sd, cd, sm, cm;
+    bool usable;
+};
+__device__ __forceinline__ SawRot saw_rot(const SawConst &k) {
+    SawRot r;
+    const double d = kPi * k.inc;
+    pgx::pgx_sincos_bounded(d, r.sd, r.cd);
+    pgx::pgx_sincos_bounded(k.m * d, r.sm, r.cm);
+    const double half = k.m * 0.5;
+    r.usable = k.m < kSawBoundedM && half != floor(half) && k.inc >= 0.0 && k.inc <= 0.5;
+    return r;
+}
+// xb[j] = blit - 1/P for the thread's 8 samples; returns nothing else: the carried phase is taken elsewhere.
+__device__ __forceinline__ void saw_dirichlet_rot(double ph0, const SawConst &k0, const SawRot &rot, double m_over_p,
+                                                  int64_t f0, int64_t n, double (&xb)[kSawT]) {
+    double sd, cd, sn, cn;
+    const double theta = kPi * ph0;
+    pgx::pgx_sincos_bounded(theta, sd, cd);
+    pgx::pgx_sincos_bounded(k0.m * theta, sn, cn);
+#pragma unroll
+    for (int j = 0; j < kSawT; ++j) {
+        if (j) {
+            const double s2 = __builtin_fma(sd, rot.cd, cd * rot.sd);
+            cd = __builtin_fma(cd, rot.cd, -(sd * rot.sd));
+            sd = s2;
+            const double n2 = __builtin_fma(sn, rot.cm, cn * rot.sm);
+            cn = __builtin_fma(cn, rot.cm, -(sn * rot.sm));
+            sn = n2;
+        }
+        double blit = pgx::pgx_div_fast(sn, k0.P * sd);
+        if (fabs(sd) < 1e-9) blit = m_over_p;
+        xb[j] = (f0 + j < n) ? (blit - k0.invP) : 0.0;
+    }
+}
+// the phase of the thread's sample j (np.mod(phase, 1.0)), j wave-divergent: for the carried state only
+// (the thread's local phase sums are re-added rather than indexed: an indexed register array moves to LDS)
+__device__ __forceinline__ double saw_phase_at(double phase0, double chunk_base, double inc, int j) {
+    double l = 0.0;
+#pragma unroll
+    for (int q = 0; q < kSawT; ++q) l = (q <= j) ? l + inc : l;
+    return pgx::pgx_mod1(phase0 + (chunk_base + l));
+}
+
 // STREAMS = false: scalar frequency / amplitude / M (every voice-bank and SuperSaw launch): the
 // per-voice constants are hoisted out of the sample loops.
 // NW = 4: 256 threads, 2048-frame tiles (banks of oscillators).  NW = 8: 512 threads, 4096-frame tiles --
@@ -915,6 +964,8 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     double carry_sum = 0.0;                 // running np.cumsum(phase_inc) at the tile start
     double carry_y = (SEG == 2) ? wsi[1] : state[inst * 2 + 1];   // leaky integrator output y[n-1]
     const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
+    const SawRot rot = saw_rot(k0);
+    const double m_over_p = k0.m / k0.P;
     if (SEG == 1 && seg == 0 && tid == 0) {                       // the apply pass must not read what it overwrites
         wsi[0] = phase0;
         wsi[1] = carry_y;
@@ -1023,7 +1074,13 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
                 }
             }
         };
-        if (!STREAMS && k0.m < kSawBoundedM) dirichlet(std::true_type{});
+        if (!STREAMS && rot.usable) {
+            saw_dirichlet_rot(pgx::pgx_mod1(phase0 + (chunk_base + loc[0])), k0, rot, m_over_p, f0, n, xb);
+            if (f0 <= n - 1 && n - 1 < f0 + kSawT) {
+                final_phase = saw_phase_at(phase0, chunk_base, k0.inc, (int)(n - 1 - f0));
+                have_final = true;
+            }
+        } else if (!STREAMS && k0.m < kSawBoundedM) dirichlet(std::true_type{});
         else dirichlet(std::false_type{});
 
         // ---- leaky integrator y[n] = x[n] + leak*y[n-1] (blit_saw_pe.py:222-234) ----
@@ -1104,6 +1161,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
     double carry_y = saw_state[inst * 2 + 1];
     V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
     const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
+    const SawRot rot = saw_rot(k0);
     const double m_over_p = k0.m / k0.P;
     const double leak = p.leak;
     double lamp[6], lam_wave, lam_lane = 1.0;
@@ -1147,7 +1205,10 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
                 if (f0 + j == n - 1) final_phase = ph;
             }
         };
-        if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
+        if (rot.usable) {
+            saw_dirichlet_rot(pgx::pgx_mod1(phase0 + (chunk_base + loc[0])), k0, rot, m_over_p, f0, n, xb);
+            if (f0 <= n - 1 && n - 1 < f0 + kSawT) final_phase = saw_phase_at(phase0, chunk_base, k0.inc, (int)(n - 1 - f0));
+        } else if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
         else dirichlet(std::false_type{});
         double e = 0.0;
 #pragma unroll
@@ -1237,6 +1298,8 @@ struct SsShared {
     double aff[2 * NW];
     double carry_sum[kSsMaxVoices];
     double carry_y[kSsMaxVoices];
+    double rot[kSsMaxVoices][4];          // per voice: sin / cos of pi*inc and of M*pi*inc (saw_rot)
+    int rot_ok[kSsMaxVoices];
 };
 // NW = 4: 2048-frame tiles, two workgroups per CU (512 instances fill the chip in one round and one workgroup's
 // barrier waits overlap the other's arithmetic); NW = 8: 4096-frame tiles for fewer instances.  Same bits.
@@ -1255,6 +1318,10 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
     if (tid < nv) {
         sh.carry_sum[tid] = 0.0;
         sh.carry_y[tid] = sv[tid * 2 + 1];
+        const pgx_blitsaw_params pt = pv[tid];
+        const SawRot r = saw_rot(saw_const(pt.freq, sr, pt.m, false, 0.0));
+        sh.rot[tid][0] = r.sd; sh.rot[tid][1] = r.cd; sh.rot[tid][2] = r.sm; sh.rot[tid][3] = r.cm;
+        sh.rot_ok[tid] = r.usable ? 1 : 0;
     }
     __syncthreads();
     int parity = 0;
@@ -1310,7 +1377,11 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                     if (f0 + j == n - 1) final_phase = ph;
                 }
             };
-            if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
+            if (sh.rot_ok[v]) {
+                const SawRot rot{sh.rot[v][0], sh.rot[v][1], sh.rot[v][2], sh.rot[v][3], true};
+                saw_dirichlet_rot(pgx::pgx_mod1(phase0 + (chunk_base + loc[0])), k0, rot, m_over_p, f0, n, xb);
+                if (f0 <= n - 1 && n - 1 < f0 + kSawT) final_phase = saw_phase_at(phase0, chunk_base, k0.inc, (int)(n - 1 - f0));
+            } else if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
             else dirichlet(std::false_type{});
             double e = 0.0;
 #pragma unroll

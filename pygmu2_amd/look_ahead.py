@@ -35,7 +35,7 @@ from . import read_ahead as _read_ahead
 
 SMALL_BLOCK = 1 << 20       # pulls up to this many frames are served from a look-ahead window
 AHEAD_BLOCKS = 64           # at most this many blocks per window ...
-AHEAD_FRAMES = 1 << 23      # ... and about this many frames (1 M-frame pulls: 8 blocks per window)
+AHEAD_FRAMES = 1 << 24      # ... and about this many frames (1 M-frame pulls: 16 blocks per window)
 
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_LOOK_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")
@@ -148,8 +148,11 @@ def render(pe, start: int, duration: int):
     if not sequential:
         return None
     from .snippet import Snippet
-    nodes = []
-    _subtree(pe, set(), nodes)
+    nodes = d.get("_la_nodes")                        # graphs are static: the walk is done once
+    if nodes is None:
+        nodes = []
+        _subtree(pe, set(), nodes)
+        d["_la_nodes"] = nodes
     for n in nodes:                                   # a window below (opened while this PE was pulled one
         if n is not pe and n.__dict__.get("_la_win") is not None:      # level down) is closed first
             settle(n)

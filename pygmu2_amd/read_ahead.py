@@ -24,8 +24,8 @@ import threading
 
 SMALL_BLOCK = 1 << 20       # requests up to this many frames are served from a resident window
 AHEAD_BLOCKS = 64           # at most this many blocks per refill ...
-AHEAD_FRAMES = 1 << 23      # ... and about this many frames (32 MB per channel: a 44 100-frame pull refills 64
-                            # blocks at a time, a 1 M-frame pull 8: launches of that size leave the ~4 us floor
+AHEAD_FRAMES = 1 << 24      # ... and about this many frames (64 MB per channel: a 44 100-frame pull refills 64
+                            # blocks at a time, a 1 M-frame pull 16: launches of that size leave the ~4 us floor
                             # of a launch behind and stream at HBM rate)
 
 _tls = threading.local()
