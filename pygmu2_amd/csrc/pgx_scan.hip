@@ -1300,6 +1300,8 @@ struct SsShared {
     double carry_y[kSsMaxVoices];
     double rot[kSsMaxVoices][4];          // per voice: sin / cos of pi*inc and of M*pi*inc (saw_rot)
     int rot_ok[kSsMaxVoices];
+    double kc[kSsMaxVoices][6];           // per voice: inc, M, P, 1/P, M/P, phase0 -- made once, not per tile
+    double lam[kSsMaxVoices][8];          // per voice: leak^(8*2^k), k = 0..5, leak^(8*64)
 };
 // NW = 4: 2048-frame tiles, two workgroups per CU (512 instances fill the chip in one round and one workgroup's
 // barrier waits overlap the other's arithmetic); NW = 8: 4096-frame tiles for fewer instances.  Same bits.
@@ -1319,9 +1321,20 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         sh.carry_sum[tid] = 0.0;
         sh.carry_y[tid] = sv[tid * 2 + 1];
         const pgx_blitsaw_params pt = pv[tid];
-        const SawRot r = saw_rot(saw_const(pt.freq, sr, pt.m, false, 0.0));
+        const SawConst kt = saw_const(pt.freq, sr, pt.m, false, 0.0);
+        const SawRot r = saw_rot(kt);
         sh.rot[tid][0] = r.sd; sh.rot[tid][1] = r.cd; sh.rot[tid][2] = r.sm; sh.rot[tid][3] = r.cm;
         sh.rot_ok[tid] = r.usable ? 1 : 0;
+        sh.kc[tid][0] = kt.inc; sh.kc[tid][1] = kt.m; sh.kc[tid][2] = kt.P; sh.kc[tid][3] = kt.invP;
+        sh.kc[tid][4] = kt.m / kt.P;
+        sh.kc[tid][5] = sv[tid * 2 + 0];                    // (the state is rewritten only after the last tile)
+        double l = pt.leak;
+#pragma unroll
+        for (int t = 1; t < kSawT; t <<= 1) l = l * l;      // leak^T
+        for (int k = 0; k < 7; ++k) {
+            sh.lam[tid][k] = l;
+            l = l * l;
+        }
     }
     __syncthreads();
     int parity = 0;
@@ -1334,22 +1347,18 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
 #pragma unroll 1
         for (int v = 0; v < nv; ++v, ++parity) {
             const pgx_blitsaw_params p = pv[v];
-            const SawConst k0 = saw_const(p.freq, sr, p.m, false, 0.0);
-            const double phase0 = sv[v * 2 + 0];            // rewritten only after the last tile
+            // the voice's constants come from LDS (made once per launch: per tile they were a third of the work)
+            SawConst k0;
+            k0.inc = sh.kc[v][0]; k0.m = sh.kc[v][1]; k0.P = sh.kc[v][2]; k0.invP = sh.kc[v][3];
+            const double phase0 = sh.kc[v][5];
             const double leak = p.leak;
-            double lamp[6], lam_wave, lam_lane = 1.0;
-            {
-                double l = leak;
+            double lamp[6], lam_lane = 1.0;
 #pragma unroll
-                for (int s = 1; s < kSawT; s <<= 1) l = l * l;      // leak^T
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    lamp[k] = l;
-                    if (lane & (1 << k)) lam_lane = lam_lane * l;
-                    l = l * l;
-                }
-                lam_wave = l;
+            for (int k = 0; k < 6; ++k) {
+                lamp[k] = sh.lam[v][k];
+                if (lane & (1 << k)) lam_lane = lam_lane * lamp[k];
             }
+            const double lam_wave = sh.lam[v][6];
             double carry_sum = sh.carry_sum[v], carry_y = sh.carry_y[v];
             double loc[kSawT];
             double run = 0.0;
@@ -1362,7 +1371,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                                            : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
             double xb[kSawT];
             double final_phase = 0.0, final_y = 0.0;
-            const double m_over_p = k0.m / k0.P;
+            const double m_over_p = sh.kc[v][4];
             auto dirichlet = [&](auto bounded) {
 #pragma unroll
                 for (int j = 0; j < kSawT; ++j) {
