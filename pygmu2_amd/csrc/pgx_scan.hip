@@ -198,18 +198,52 @@ __device__ __forceinline__ double block_scan_scalar_affine(double e, const doubl
     return lam_lane * cw + ex;
 }
 
+// Inclusive scans over a wave on DPP moves (VALU; a `__shfl_up` step is two ds_bpermute round trips through LDS):
+// Kogge-Stone inside each 16-lane row (row_shr), then row 0 -> 1 and 2 -> 3 (lane 15 of the previous row), then
+// rows 0-1 -> 2, 3 (lane 31).  Lanes without a source receive the neutral element.  Every oscillator kernel scans
+// with these two, so their folds -- and bits -- agree with each other.
+__device__ __forceinline__ double wave_incl_sum_dpp(double v) {
+    v = dpp_f64_keep<0x111, 0xf>(0.0, v) + v;
+    v = dpp_f64_keep<0x112, 0xf>(0.0, v) + v;
+    v = dpp_f64_keep<0x114, 0xf>(0.0, v) + v;
+    v = dpp_f64_keep<0x118, 0xf>(0.0, v) + v;
+    v = dpp_f64_keep<0x142, 0xa>(0.0, v) + v;
+    v = dpp_f64_keep<0x143, 0xc>(0.0, v) + v;
+    return v;
+}
+// y' = lam^len * y + b: lamp[k] = lam^(T*2^k); lam16 / lam32 = lam^(T*((lane & 15) + 1)) / lam^(T*((lane & 31) + 1))
+__device__ __forceinline__ double wave_incl_affine_dpp(double e, const double (&lamp)[6], double lam16, double lam32) {
+    e = lamp[0] * dpp_f64_keep<0x111, 0xf>(0.0, e) + e;
+    e = lamp[1] * dpp_f64_keep<0x112, 0xf>(0.0, e) + e;
+    e = lamp[2] * dpp_f64_keep<0x114, 0xf>(0.0, e) + e;
+    e = lamp[3] * dpp_f64_keep<0x118, 0xf>(0.0, e) + e;
+    e = lam16 * dpp_f64_keep<0x142, 0xa>(0.0, e) + e;
+    e = lam32 * dpp_f64_keep<0x143, 0xc>(0.0, e) + e;
+    return e;
+}
+// the per-lane powers of a scan over chunks of T samples, from lamp[k] = lam^(T*2^k)
+struct LanePowers {
+    double lane, p16, p32;      // lam^(T*lane), lam^(T*((lane & 15) + 1)), lam^(T*((lane & 31) + 1))
+};
+__device__ __forceinline__ LanePowers lane_powers(const double (&lamp)[6], int lane) {
+    LanePowers r{1.0, 1.0, 1.0};
+    const int a = (lane & 15) + 1, b = (lane & 31) + 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (lane & (1 << k)) r.lane = r.lane * lamp[k];
+        if (a & (1 << k)) r.p16 = r.p16 * lamp[k];
+        if (b & (1 << k)) r.p32 = r.p32 * lamp[k];
+    }
+    return r;
+}
+
 // Wide forms for a workgroup of NW = 4*G waves that must reproduce, bit for bit, what a 4-wave workgroup
 // computes on G consecutive tiles: the wave values are the same, so it is enough to fold them in the same
 // order.  sum_carry: running sum entering the first of the G tiles (advanced to the one leaving the last).
 template <int NW>
 __device__ __forceinline__ double block_excl_sum_wide(double v, double *lds, double &sum_carry) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc = o + inc;
-    }
+    const double inc = wave_incl_sum_dpp(v);
     if (lane == 63) lds[wave] = inc;
     __syncthreads();
     double base = sum_carry, mine_base = sum_carry, woff = 0.0;
@@ -230,8 +264,7 @@ __device__ __forceinline__ double block_excl_sum_wide(double v, double *lds, dou
     }
     __syncthreads();
     sum_carry = base;
-    double ex = __shfl_up(inc, 1, 64);
-    if (lane == 0) ex = 0.0;
+    const double ex = dpp_f64_keep<0x138, 0xf>(0.0, inc);   // wave_shr:1 -- the lane before, 0 for lane 0
     return mine_base + (woff + ex);                          // chunk_base = carry_sum + off
 }
 
@@ -266,13 +299,8 @@ __device__ __forceinline__ double block_scan_scalar_affine_wide(double e, const 
 // barrier.  Same operations in the same order as the exchanging form, hence the same bits.
 template <int NW>
 __device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &sum_carry) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc = o + inc;
-    }
+    const int wave = threadIdx.x >> 6;
+    const double inc = wave_incl_sum_dpp(v);
     const double t = readlane_f64(inc, 63);
     double tot = 0.0, w_local = 0.0;
 #pragma unroll
@@ -287,8 +315,7 @@ __device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &
         base = base + tot;
     }
     sum_carry = base;
-    double ex = __shfl_up(inc, 1, 64);
-    if (lane == 0) ex = 0.0;
+    const double ex = dpp_f64_keep<0x138, 0xf>(0.0, inc);
     return mine_base + (w_local + ex);
 }
 
@@ -297,16 +324,11 @@ __device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &
 // barrier of the call in between.
 template <int NW>
 __device__ __forceinline__ double block_scan_scalar_affine_wide1(double e, const double (&lamp)[6], double lam_wave,
-                                                                 double lam_lane, double *lds, int parity,
+                                                                 const LanePowers &lp, double *lds, int parity,
                                                                  double &carry) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *img = lds + (parity & 1) * NW;
-    double inc = e;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        double o = __shfl_up(inc, 1 << k, 64);
-        if (lane >= (1 << k)) inc = lamp[k] * o + inc;
-    }
+    const double inc = wave_incl_affine_dpp(e, lamp, lp.p16, lp.p32);
     if (lane == 63) img[wave] = inc;
     __syncthreads();
     double cw = carry, cn = carry;
@@ -317,9 +339,8 @@ __device__ __forceinline__ double block_scan_scalar_affine_wide1(double e, const
         cn = lam_wave * cn + t;
     }
     carry = cn;
-    double ex = __shfl_up(inc, 1, 64);
-    if (lane == 0) ex = 0.0;
-    return lam_lane * cw + ex;
+    const double ex = dpp_f64_keep<0x138, 0xf>(0.0, inc);
+    return lp.lane * cw + ex;
 }
 
 // ================================================================================================
@@ -973,7 +994,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 
     // powers of leak for the affine scan
     const double leak = p.leak;
-    double lamp[6], lam_wave, lam_lane = 1.0;
+    double lamp[6], lam_wave;
     {
         double l = leak;
 #pragma unroll
@@ -981,11 +1002,11 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             lamp[k] = l;
-            if (lane & (1 << k)) lam_lane = lam_lane * l;
             l = l * l;
         }
         lam_wave = l;
     }
+    const LanePowers lane_pw = lane_powers(lamp, lane);
 
     double final_phase = 0.0, final_y = 0.0;
     bool have_final = false;
@@ -997,12 +1018,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         double run = 0.0;
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) run = run + k0.inc;
-        double inc = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            double o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc = o + inc;
-        }
+        const double inc = wave_incl_sum_dpp(run);          // the scan the tiles themselves use: same wave totals
         if (lane == 63) sh.sum[tid >> 6] = inc;
         __syncthreads();
         double tot[NW / kWaves];
@@ -1087,7 +1103,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         double e = 0.0;
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
-        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lam_lane, sh.aff, parity, carry_y);
+        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
         if (SEG == 1) {                      // the wave responses the scan just folded are still in LDS
             if (tid < NW) wsi[2 + (base / kTile) * NW + tid] = sh.aff[(parity & 1) * NW + tid];
             continue;
@@ -1164,7 +1180,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
     const SawRot rot = saw_rot(k0);
     const double m_over_p = k0.m / k0.P;
     const double leak = p.leak;
-    double lamp[6], lam_wave, lam_lane = 1.0;
+    double lamp[6], lam_wave;
     {
         double l = leak;
 #pragma unroll
@@ -1172,11 +1188,11 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             lamp[k] = l;
-            if (lane & (1 << k)) lam_lane = lam_lane * l;
             l = l * l;
         }
         lam_wave = l;
     }
+    const LanePowers lane_pw = lane_powers(lamp, lane);
     int parity = 0;
     for (int64_t base = 0; base < n; base += kTile, ++parity) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
@@ -1213,7 +1229,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
         double e = 0.0;
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
-        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lam_lane, sh.aff, parity, carry_y);
+        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
         float xf[kSawT];
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) {
@@ -1352,12 +1368,10 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             k0.inc = sh.kc[v][0]; k0.m = sh.kc[v][1]; k0.P = sh.kc[v][2]; k0.invP = sh.kc[v][3];
             const double phase0 = sh.kc[v][5];
             const double leak = p.leak;
-            double lamp[6], lam_lane = 1.0;
+            double lamp[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                lamp[k] = sh.lam[v][k];
-                if (lane & (1 << k)) lam_lane = lam_lane * lamp[k];
-            }
+            for (int k = 0; k < 6; ++k) lamp[k] = sh.lam[v][k];
+            const LanePowers lane_pw = lane_powers(lamp, lane);
             const double lam_wave = sh.lam[v][6];
             double carry_sum = sh.carry_sum[v], carry_y = sh.carry_y[v];
             double loc[kSawT];
@@ -1395,7 +1409,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             double e = 0.0;
 #pragma unroll
             for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
-            double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lam_lane, sh.aff, parity, carry_y);
+            double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
 #pragma unroll
             for (int j = 0; j < kSawT; ++j) {
                 double z = leak * y;
