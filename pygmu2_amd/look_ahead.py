@@ -138,6 +138,7 @@ def render(pe, start: int, duration: int):
     if win is not None:
         if start == win.served and start + duration <= win.end:
             win.served = start + duration
+            d["_la_last"] = win.served                # the pull after the window's last block continues the stream
             from .snippet import Snippet
             return Snippet.window_rows(start, win.buf, start - win.first, duration)
         settle(pe)
