@@ -668,7 +668,8 @@ def suite_rows(pg, with_cpu):
     wanted = ["SinePE (440 Hz)", "BlitSawPE (440 Hz, auto M)", "SuperSawPE (7 voices)", "GainPE (constant)",
               "MixPE (4 sources)", "BiquadPE (lowpass, fixed)", "BiquadPE (bandpass, fixed)",
               "BiquadPE (lowpass, modulated freq)", "BiquadPE (bandpass, modulated Q)",
-              "SVFilterPE (lowpass, fixed)", "SVFilterPE (lowpass, modulated freq)", "EnvelopePE", "CompressorPE"]
+              "SVFilterPE (lowpass, fixed)", "SVFilterPE (lowpass, modulated freq)", "EnvelopePE", "CompressorPE",
+              "LimiterPE"]
     rows = {}
     for name, spec in B.CONFIGS:
         if name not in wanted:

@@ -225,11 +225,15 @@ int pgx_svf(float *out, const float *in, int64_t n, int channels, double sample_
 /* EnvelopePE._render (envelope_pe.py:128-206) on the (already look-ahead shifted) source block.
  * one_pole != 0: attack == release, scipy lfilter one-pole as a scan; else the attack/release
  * switch of _envelope_ar_numba (envelope_pe.py:259-271), one lane per channel.
- * rms_window > 0 selects DetectionMode.RMS (block-local uniform_filter1d, mode='nearest').
- * state[channel] = envelope; scratch: pgx_envelope_scratch_bytes (detector output + 64-frame block sums). */
+ * rms_window > 0 selects DetectionMode.RMS (block-local uniform_filter1d, mode='nearest'); rms_period > 0: the
+ * n frames are several of the caller's blocks of rms_period frames rendered at once, and the detector restarts
+ * at every one of their edges (0: one block).
+ * state[channel] = envelope; scratch: pgx_envelope_scratch_bytes (detector output + 64-frame block sums, and
+ * the pieces / entries of the all-windows form used from 131 072 frames on). */
 size_t pgx_envelope_scratch_bytes(int64_t n, int channels);
 int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
-                 double release_coeff, int one_pole, int rms_window, double *state, double *scratch);
+                 double release_coeff, int one_pole, int rms_window, int64_t rms_period, double *state,
+                 double *scratch);
 
 /* TransformPE._render (transform_pe.py:96-152) for chains of named element-wise operations:
  * float32 -> float64 -> ops in order -> float32.

@@ -115,6 +115,7 @@ def settle_frames(a1: float, a2: float, limit: int = 1 << 16) -> int:
 
 
 class BiquadPE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _LOOK_AHEAD_SAFE = True            # look_ahead.py: block-partition invariant, state listed below
     _STATE_FIELDS = ("_state", "_state_channels")
 

@@ -9,6 +9,16 @@ from .snippet import Snippet
 
 
 class CachePE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py: the memo is restored with the other states ...
+    _STATE_FIELDS = ("_key", "_snippet")
+
+    def _look_ahead_condition(self) -> bool:
+        # ... but only over a pure source is the memo invisible: a stateful source pulled twice per block (an
+        # EnvelopePE with look-ahead next to the dry path) depends on how the stream is cut into blocks
+        from . import read_ahead
+        return read_ahead.eligible(self._source)
+
     def __init__(self, source: ProcessingElement):
         self._source = source
         self._key: tuple[int, int] | None = None

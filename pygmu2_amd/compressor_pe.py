@@ -27,6 +27,11 @@ def _setting(name):
 class _SideChainProcessor(ProcessingElement):
     """source -> CachePE -> { EnvelopePE , DynamicsPE(audio, envelope) }; the DynamicsPE is the output."""
 
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
+
+
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py: a wiring without state of its own
+
     def _wire(self, source, *, detector: dict, computer: dict, settings: dict) -> None:
         tap = CachePE(source)
         follower = EnvelopePE(tap, **detector)

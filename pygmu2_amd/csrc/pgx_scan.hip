@@ -2000,7 +2000,8 @@ k_env_blocks(double *blocks, const float *in, int64_t n, int channels) {
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_env_detect(double *det, const float *in, const double *blocks, int64_t n, int channels, int rms_window) {
+k_env_detect(double *det, const float *in, const double *blocks, int64_t n, int channels, int rms_window,
+             int64_t period) {
     const int64_t total = n * channels;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     auto sq = [&](int64_t f, int c) {
@@ -2014,16 +2015,23 @@ k_env_detect(double *det, const float *in, const double *blocks, int64_t n, int 
             det[e] = fabs((double)in[e]);
             continue;
         }
-        // window [i - size/2, i - size/2 + size) with indices clamped to the block ('nearest')
+        // window [i - size/2, i - size/2 + size) with indices clamped to the block ('nearest').  The block is the
+        // caller's: when a look-ahead window renders several of the caller's blocks at once (`period` frames each)
+        // the detector restarts at every one of their edges, as the reference's per-block filter does
+        int64_t p0 = 0, p1 = n;
+        if (period > 0) {
+            p0 = (i / period) * period;
+            p1 = p0 + period < n ? p0 + period : n;
+        }
         int64_t lo = i - rms_window / 2, hi = lo + rms_window;
         double acc = 0.0;
-        if (lo < 0) {
-            acc = acc + (double)(-lo) * sq(0, c);
-            lo = 0;
+        if (lo < p0) {
+            acc = acc + (double)(p0 - lo) * sq(p0, c);
+            lo = p0;
         }
-        if (hi > n) {
-            acc = acc + (double)(hi - n) * sq(n - 1, c);
-            hi = n;
+        if (hi > p1) {
+            acc = acc + (double)(hi - p1) * sq(p1 - 1, c);
+            hi = p1;
         }
         const int64_t b0 = (lo + kEnvBlock - 1) / kEnvBlock, b1 = hi / kEnvBlock;        // whole blocks [b0, b1)
         if (b0 < b1) {
@@ -2732,7 +2740,8 @@ size_t pgx_envelope_scratch_bytes(int64_t n, int channels) {
 }
 
 int pgx_envelope(float *out, const float *in, int64_t n, int channels, double attack_coeff,
-                 double release_coeff, int one_pole, int rms_window, double *state, double *scratch) {
+                 double release_coeff, int one_pole, int rms_window, int64_t rms_period, double *state,
+                 double *scratch) {
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && in && state && scratch && channels >= 1, "pgx_envelope: bad argument");
@@ -2746,7 +2755,7 @@ int pgx_envelope(float *out, const float *in, int64_t n, int channels, double at
             PGX_LAUNCH_CHECK("k_env_blocks");
         }
         hipLaunchKernelGGL(k_env_detect, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(),
-                           scratch, in, blocks, n, channels, rms_window);
+                           scratch, in, blocks, n, channels, rms_window, rms_period);
         PGX_LAUNCH_CHECK("k_env_detect");
     }
     if (one_pole) {

@@ -40,6 +40,8 @@ def ratio_to_db(ratio):
 
 
 class DynamicsPE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
+    _LOOK_AHEAD_SAFE = True            # look_ahead.py: an element-wise function of its two inputs, no state
     AUTO = "auto"
 
     def __init__(self, source: ProcessingElement, envelope: ProcessingElement, threshold: float = -20.0,

@@ -16,6 +16,7 @@ from enum import Enum
 
 import numpy as np
 
+from . import look_ahead as _look_ahead
 from ._kernels import DeviceBuffer, check, lib, new_output
 from .extent import Extent
 from .processing_element import ProcessingElement
@@ -28,11 +29,14 @@ class DetectionMode(Enum):
 
 
 class EnvelopePE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _LOOK_AHEAD_SAFE = True            # look_ahead.py; the RMS detector is block-local (see the condition)
     _STATE_FIELDS = ("_state", "_state_channels")
 
-    def _look_ahead_condition(self) -> bool:
-        return self._mode == DetectionMode.PEAK
+    def _look_ahead_block_sensitive(self) -> bool:
+        # the RMS detector is block-local in the reference (uniform_filter1d restarts at every block edge): a
+        # look-ahead window may still render several blocks at once if it tells us where the caller's edges are
+        return self._mode == DetectionMode.RMS
 
     def __init__(self, source: ProcessingElement, attack: float = 0.01, release: float = 0.1,
                  lookahead: float = 0.0, mode: DetectionMode = DetectionMode.PEAK):
@@ -93,8 +97,9 @@ class EnvelopePE(ProcessingElement):
             self._scratch_buf = DeviceBuffer((need // 8,), np.float64)
         attack_coeff, release_coeff, one_pole, window = self._coeffs
         out = new_output(duration, ch)
+        period = _look_ahead.current_period() if window else 0
         check(lib().pgx_envelope(out.ptr, src.dev.ptr, duration, ch, attack_coeff, release_coeff,
-                                 one_pole, window, self._state.ptr, self._scratch_buf.ptr),
+                                 one_pole, window, period, self._state.ptr, self._scratch_buf.ptr),
               "pgx_envelope")
         return Snippet(start, out)
 

@@ -12,6 +12,7 @@ from .snippet import Snippet
 
 
 class GainPE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _READ_AHEAD_SAFE = True
 
     def __init__(self, source: ProcessingElement, gain=1.0):

@@ -54,6 +54,12 @@ def _busy() -> bool:
     return getattr(_tls, "busy", False)
 
 
+def current_period() -> int:
+    """Frames per caller block while a window of a block-sensitive sub-graph is being rendered (else 0): PEs whose
+    reference arithmetic restarts at block edges (EnvelopePE's RMS detector) cut their work there."""
+    return getattr(_tls, "period", 0)
+
+
 def _subtree(pe, seen, out):
     if id(pe) in seen:
         return
@@ -86,7 +92,31 @@ def capable(pe) -> bool:
                   and any(getattr(n, "_STATE_FIELDS", None) is not None for n in nodes)
                   and not _read_ahead.eligible(pe))
         pe.__dict__["_la_ok"] = cached
+        # block-sensitive PEs (arithmetic that restarts at the caller's block edges) are told the block length
+        # while a window renders; that only works if everything above them hands (start, duration) down
+        # unchanged, which a PE declares with `_PASSES_BLOCKS` -- otherwise the sub-graph stays block by block
+        sens, seen = _sensitive_below(pe, {})
+        if sens and not seen:
+            cached = pe.__dict__["_la_ok"] = False
+        pe.__dict__["_la_sensitive"] = bool(sens and cached)
     return cached
+
+
+def _sensitive_below(pe, memo):
+    """(does the sub-graph under pe hold a block-sensitive PE, do all PEs above those pass blocks through)."""
+    if id(pe) in memo:
+        return memo[id(pe)]
+    f = getattr(pe, "_look_ahead_block_sensitive", None)
+    own = f is not None and bool(f())
+    any_below, ok = False, True
+    for child in pe.inputs():
+        s, o = _sensitive_below(child, memo)
+        any_below = any_below or s
+        ok = ok and o
+    if any_below and not getattr(pe, "_PASSES_BLOCKS", False):
+        ok = False
+    memo[id(pe)] = (own or any_below, ok)
+    return memo[id(pe)]
 
 
 # ------------------------------------------------------------------------------------ snapshots
@@ -122,7 +152,7 @@ def restore_snapshot(snap) -> None:
 
 # ------------------------------------------------------------------------------------ windows
 class _Window:
-    __slots__ = ("first", "end", "buf", "served", "snap", "nodes")
+    __slots__ = ("first", "end", "buf", "served", "snap", "nodes", "block")     # block: 0, or the only block size served
 
 
 def render(pe, start: int, duration: int):
@@ -136,7 +166,7 @@ def render(pe, start: int, duration: int):
         settle(owner)
     win = d.get("_la_win")
     if win is not None:
-        if start == win.served and start + duration <= win.end:
+        if start == win.served and start + duration <= win.end and (not win.block or duration == win.block):
             win.served = start + duration
             d["_la_last"] = win.served                # the pull after the window's last block continues the stream
             from .snippet import Snippet
@@ -158,11 +188,14 @@ def render(pe, start: int, duration: int):
         if n is not pe and n.__dict__.get("_la_win") is not None:      # level down) is closed first
             settle(n)
     snap = take_snapshot(nodes)
+    block = duration if d.get("_la_sensitive") else 0
     _tls.busy = True
+    _tls.period = block
     try:
         big = pe._render(start, duration * max(2, min(AHEAD_BLOCKS, AHEAD_FRAMES // duration)))
     finally:
         _tls.busy = False
+        _tls.period = 0
     if not big.on_device:                             # host-side graph: nothing to gain, nothing was assumed
         restore_snapshot(snap)
         _tls.busy = True
@@ -172,7 +205,7 @@ def render(pe, start: int, duration: int):
             _tls.busy = False
     win = _Window()
     win.first, win.end, win.buf = start, start + big.duration, big.dev
-    win.served, win.snap, win.nodes = start + duration, snap, nodes
+    win.served, win.snap, win.nodes, win.block = start + duration, snap, nodes, block
     d["_la_win"] = win
     for n in nodes:
         if n is not pe:
@@ -194,10 +227,12 @@ def settle(owner) -> None:
     if win.served > win.first:
         was = _busy()
         _tls.busy = True
+        _tls.period = win.block
         try:
             owner._render(win.first, win.served - win.first)
         finally:
             _tls.busy = was
+            _tls.period = 0
 
 
 def before_direct_access(pe) -> None:

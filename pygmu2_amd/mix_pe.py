@@ -20,6 +20,7 @@ from .snippet import Snippet
 
 
 class MixPE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _READ_AHEAD_SAFE = True
 
     def __init__(self, *inputs: ProcessingElement):

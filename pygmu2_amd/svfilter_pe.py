@@ -73,6 +73,7 @@ def svf_coefficients(mode: BiquadMode, freq: float, q: float, gain_db: float, sa
 
 
 class SVFilterPE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _LOOK_AHEAD_SAFE = True            # look_ahead.py
     _STATE_FIELDS = ("_state", "_state_channels")
 

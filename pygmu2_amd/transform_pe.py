@@ -26,6 +26,7 @@ from .snippet import Snippet
 
 
 class TransformPE(ProcessingElement):
+    _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _READ_AHEAD_SAFE = True            # named element-wise chains only (see the condition)
 
     def _read_ahead_condition(self) -> bool:

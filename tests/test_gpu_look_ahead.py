@@ -151,9 +151,9 @@ def test_graphs_that_must_not_look_ahead():
     pg.set_sample_rate(SR)
     src = pg.SinePE(220.0)
     assert not look_ahead.capable(pg.GainPE(src, 0.5))                               # pure: read-ahead's business
-    assert not look_ahead.capable(pg.EnvelopePE(src, mode=pg.DetectionMode.RMS))     # block-local RMS window
+    assert look_ahead.capable(pg.EnvelopePE(src, mode=pg.DetectionMode.RMS))         # block-local RMS: told the period
     assert not look_ahead.capable(pg.TransformPE(pg.BiquadPE(src, 500.0, 1.0), func=lambda x: x * 2.0))
-    assert not look_ahead.capable(pg.CompressorPE(src))                              # CachePE inside
+    assert look_ahead.capable(pg.CompressorPE(src))                                  # CachePE over a pure source
     fm = pg.SinePE(frequency=pg.GainPE(pg.SinePE(3.0), 50.0), phase=0.5)           # the reference re-adds the offset
     assert not look_ahead.capable(fm) and look_ahead.capable(pg.SinePE(frequency=pg.GainPE(pg.SinePE(3.0), 50.0)))
     bank = pg.MixPE(*[pg.BlitSawPE(100.0 + i) for i in range(6)])
@@ -178,3 +178,46 @@ def test_autowah_matches_the_oracle_through_look_ahead():
                           gain=1.0), SR)
     want = np.concatenate([g.render(i * 1024, 1024) for i in range(40)])
     assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+
+
+def _compressor():
+    src = pg.MixPE(pg.SinePE(330.0), pg.SinePE(331.3))                       # beating: a level that moves (pure)
+    c = pg.CompressorPE(pg.GainPE(src, 0.7), threshold=-18.0, ratio=4.0, attack=0.004, release=0.06)
+    return c, {"filter": c}
+
+
+def _limiter():
+    lim = pg.LimiterPE(pg.GainPE(pg.SinePE(220.0), 1.4), ceiling=-3.0)
+    return lim, {"filter": lim}
+
+
+@pytest.mark.parametrize("script", ["stream", "seek_back_and_forth", "restart", "block_44100"])
+@pytest.mark.parametrize("graph", ["compressor", "limiter"])
+def test_side_chain_processors_stream_through_windows(graph, script):
+    """CompressorPE's RMS detector restarts at every block edge in the reference; a window renders many blocks at
+    once and tells the detector where the caller's edges are.  LimiterPE: peak detection with look-ahead."""
+    make = {"compressor": _compressor, "limiter": _limiter}[graph]
+    steps = SCRIPTS[script]
+    got, root = run(make, steps, ahead=True)
+    assert look_ahead.capable(root)
+    want, _ = run(make, steps, ahead=False)
+    close(got, want, 2e-6)
+
+
+def test_block_sensitive_graphs_need_blocks_passed_through():
+    pg.set_sample_rate(SR)
+    comp = pg.CompressorPE(pg.SinePE(300.0))
+    assert look_ahead.capable(comp) and comp.__dict__["_la_sensitive"]
+    cropped = pg.CropPE(pg.CompressorPE(pg.SinePE(300.0)), 100, 50_000)      # CropPE re-cuts the blocks it pulls
+    assert not look_ahead.capable(cropped)
+    stateful_src = pg.CompressorPE(pg.BiquadPE(pg.SinePE(300.0), 800.0, 1.0))     # the CachePE would show
+    assert not look_ahead.capable(stateful_src)
+    # a window of a block-sensitive graph serves only the block size it was opened with
+    r = pg.NullRenderer(SR); r.set_source(comp); r.start()
+    for i in range(4):
+        comp.render(i * 1024, 1024)
+    assert comp.__dict__["_la_win"].block == 1024
+    comp.render(4096, 500)                                   # another block size: the old window is settled ...
+    win = comp.__dict__["_la_win"]
+    assert win.block == 500 and win.first == 4096            # ... and the stream goes on in windows of the new one
+    r.stop()
