@@ -1142,6 +1142,7 @@ struct SawBqShared {
     V2 tot[2][kWaves];
     M2 pstep[6];        // A^(8 * 2^k)
     M2 pwave;           // A^(8 * 64)
+    M2 m16[64], m32[64];
 };
 __global__ void __launch_bounds__(kWaves * 64)
 k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx_blitsaw_params *params,
@@ -1166,11 +1167,26 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
         sh.pwave = q;
     }
     __syncthreads();
-    M2 mlane = m_identity();                                      // A^(8 * lane)
+    // per-lane powers: A^(8*lane) (carry-in of the wave -> lane); A^(8*((lane&15)+1)) and A^(8*((lane&31)+1)) for
+    // the two cross-row steps of the DPP scan.  The latter two wait in LDS (8 doubles per lane would not fit next
+    // to the oscillator's registers)
+    M2 mlane = m_identity(), m16 = m_identity(), m32 = m_identity();
+    {
+        const int a16 = (lane & 15) + 1, a32 = (lane & 31) + 1;
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-        if (lane & (1 << k)) mlane = mm(sh.pstep[k], mlane);
+        for (int k = 0; k < 6; ++k) {
+            const M2 pk = sh.pstep[k];
+            if (lane & (1 << k)) mlane = mm(pk, mlane);
+            if (a16 & (1 << k)) m16 = mm(pk, m16);
+            if (a32 & (1 << k)) m32 = mm(pk, m32);
+        }
+    }
+    if (wave == 0) {
+        sh.m16[lane] = m16;
+        sh.m32[lane] = m32;
+    }
     const M2 pwave = sh.pwave;
+    __syncthreads();
 
     const double phase0 = saw_state[inst * 2 + 0];
     double carry_sum = 0.0;
@@ -1254,12 +1270,13 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
             ez.x = __builtin_fma(na1, yy, __builtin_fma(b1, x, ez.y));
             ez.y = __builtin_fma(na2, yy, b2 * x);
         }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const V2 o = shfl_up_v2(ez, 1 << k);
-            const M2 pk = sh.pstep[k];
-            if (lane >= (1 << k)) ez = mv_add_fma(pk, o, ez);
-        }
+        // inclusive scan over the wave on DPP moves, as k_biquad_settled does it
+        ez = mv_add_fma(sh.pstep[0], dpp_v2<0x111, 0xf>(ez), ez);
+        ez = mv_add_fma(sh.pstep[1], dpp_v2<0x112, 0xf>(ez), ez);
+        ez = mv_add_fma(sh.pstep[2], dpp_v2<0x114, 0xf>(ez), ez);
+        ez = mv_add_fma(sh.pstep[3], dpp_v2<0x118, 0xf>(ez), ez);
+        ez = mv_add_fma(sh.m16[lane], dpp_v2<0x142, 0xa>(ez), ez);
+        ez = mv_add_fma(sh.m32[lane], dpp_v2<0x143, 0xc>(ez), ez);
         if (lane == 63) sh.tot[parity & 1][wave] = ez;
         __syncthreads();
         V2 cw = carry_z, fold = carry_z;
@@ -1269,8 +1286,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
             if (w + 1 == wave) cw = fold;                         // this wave's carry-in
         }
         carry_z = fold;
-        V2 ex = shfl_up_v2(ez, 1);
-        if (lane == 0) ex = V2{0.0, 0.0};
+        const V2 ex = dpp_v2<0x138, 0xf>(ez);                     // the lane before, 0 for lane 0
         const V2 zin = mv_add_fma(mlane, cw, ex);
         V2 z = zin;
         float yf[kSawT];
