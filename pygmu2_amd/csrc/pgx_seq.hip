@@ -70,6 +70,43 @@ __device__ __forceinline__ void ladder_store(double *st, const LadderState &s);
 
 constexpr int kLadderChunk = 8;
 
+// A lane walks its own stretch of the stream, so a wave's loads are 64 different cache lines whatever their width:
+// what counts is the number of load instructions (each occupies the CU's one address unit for 64 cycles).  Mono
+// streams are fetched and stored 16 bytes at a time (two instructions per chunk instead of eight); the addresses
+// are only 4-byte aligned, which global memory instructions accept.
+struct __attribute__((packed, aligned(4))) LadderF4 {
+    float v[4];
+};
+__device__ __forceinline__ void ladder_load8(const LadderConsts &c, int64_t base, float (&x)[kLadderChunk]) {
+    if (c.channels == 1) {
+        const LadderF4 a = *reinterpret_cast<const LadderF4 *>(c.x + base);
+        const LadderF4 b = *reinterpret_cast<const LadderF4 *>(c.x + base + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = a.v[j];
+            x[4 + j] = b.v[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kLadderChunk; ++j) x[j] = c.x[(base + j) * c.channels + c.ch];
+    }
+}
+__device__ __forceinline__ void ladder_store8(const LadderConsts &c, int64_t base, const float (&y)[kLadderChunk]) {
+    if (c.channels == 1) {
+        LadderF4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a.v[j] = y[j];
+            b.v[j] = y[4 + j];
+        }
+        *reinterpret_cast<LadderF4 *>(c.o + base) = a;
+        *reinterpret_cast<LadderF4 *>(c.o + base + 4) = b;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kLadderChunk; ++j) c.o[(base + j) * c.channels + c.ch] = y[j];
+    }
+}
+
 // Samples [i0, i1); output is written from `emit_from` on; when `snap` is given the state on entering
 // sample `emit_from` is stored there (i0 <= emit_from <= i1).
 // Input is fetched a chunk ahead and output stored a chunk at a time: the recurrence is latency
@@ -160,22 +197,15 @@ __device__ __forceinline__ void ladder_advance_impl(const LadderConsts &c, Ladde
         int64_t base = a;
         if (b - a >= kLadderChunk) {
             float xn[kLadderChunk];
-#pragma unroll
-            for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + j) * c.channels + c.ch];
+            ladder_load8(c, base, xn);
             for (; base + kLadderChunk <= b; base += kLadderChunk) {
                 float xc[kLadderChunk], yc[kLadderChunk];
 #pragma unroll
                 for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
-                if (base + 2 * kLadderChunk <= b) {
-#pragma unroll
-                    for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + kLadderChunk + j) * c.channels + c.ch];
-                }
+                if (base + 2 * kLadderChunk <= b) ladder_load8(c, base + kLadderChunk, xn);
 #pragma unroll
                 for (int j = 0; j < kLadderChunk; ++j) yc[j] = sample(base + j, xc[j]);
-                if (emit) {
-#pragma unroll
-                    for (int j = 0; j < kLadderChunk; ++j) c.o[(base + j) * c.channels + c.ch] = yc[j];
-                }
+                if (emit) ladder_store8(c, base, yc);
             }
         }
         for (; base < b; ++base) {
@@ -279,16 +309,12 @@ __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderSt
     int64_t base = i0;
     if (i1 - i0 >= kLadderChunk) {
         float xn[kLadderChunk];
-#pragma unroll
-        for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + j) * c.channels + c.ch];
+        ladder_load8(c, base, xn);
         for (; base + kLadderChunk <= i1; base += kLadderChunk) {
             float xc[kLadderChunk];
 #pragma unroll
             for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
-            if (base + 2 * kLadderChunk <= i1) {
-#pragma unroll
-                for (int j = 0; j < kLadderChunk; ++j) xn[j] = c.x[(base + kLadderChunk + j) * c.channels + c.ch];
-            }
+            if (base + 2 * kLadderChunk <= i1) ladder_load8(c, base + kLadderChunk, xn);
 #pragma unroll
             for (int j = 0; j < kLadderChunk; ++j) sample(xc[j]);
         }
@@ -350,12 +376,12 @@ k_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int
 
 // One lane per (chain, segment).  warm[chain][seg] = state on entering the segment's first output
 // sample, ends[chain][seg] = state after its last one.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
                   int channels, double sr, const pgx_ladder_params *params, const float *freq,
                   const float *resonance, const float *drive, const double *state, int64_t settle,
                   int64_t accurate, int64_t seg_len, int nseg, double *warm, double *ends) {
-    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t chains = (int64_t)batch * channels;
     if (t >= chains * nseg) return;
     const int chain = (int)(t / nseg), seg = (int)(t - (int64_t)chain * nseg);
@@ -601,6 +627,8 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
     double *ends = warm + (size_t)chains * p.nseg * 9;
     int *fallbacks = (int *)(ends + (size_t)chains * p.nseg * 9);
     const int64_t lanes = (int64_t)chains * p.nseg;
+    // one wave per workgroup, two per CU: 256-thread workgroups with 64 Ki lanes (a wave on every SIMD, half the
+    // exact samples per lane) measure the same 0.33 ms per C4 block, 64-thread ones with 64 Ki lanes 0.46
     hipLaunchKernelGGL(k_ladder_segments, dim3((unsigned)pgx::ceil_div(lanes, 64)), dim3(64), 0, pgx::stream(), out,
                        out_stride, in, in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
                        (const double *)state, settle_frames,
