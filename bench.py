@@ -781,6 +781,7 @@ def main():
         # the filter kernel as the C2 steps launch it: look-ahead renders `ahead` 1 M-frame steps per launch
         from pygmu2_amd import look_ahead
         ahead = max(2, min(look_ahead.AHEAD_BLOCKS, look_ahead.AHEAD_FRAMES // 1_000_000)) if look_ahead.enabled() else 1
+        # (steady state: a stream's first windows are 4 and 16 steps long)
         result["roofline"] = biquad_kernel_roofline(pg, 1_000_000 * ahead, 100)
         result["roofline"]["steps_per_launch"] = ahead
         result["roofline_one_step"] = biquad_kernel_roofline(pg, 1_000_000, 200)

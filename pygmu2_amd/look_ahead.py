@@ -34,7 +34,9 @@ import numpy as np
 from . import read_ahead as _read_ahead
 
 SMALL_BLOCK = 1 << 20       # pulls up to this many frames are served from a look-ahead window
-AHEAD_BLOCKS = 64           # at most this many blocks per window ...
+FIRST_WINDOW_BLOCKS = 8     # the first window of a stream; every further one is WINDOW_GROWTH times longer, up to
+WINDOW_GROWTH = 8
+AHEAD_BLOCKS = 64           # ... at most this many blocks per window ...
 AHEAD_FRAMES = 1 << 24      # ... and about this many frames (1 M-frame pulls: 16 blocks per window)
 
 _tls = threading.local()
@@ -177,6 +179,7 @@ def render(pe, start: int, duration: int):
     sequential = d.get("_la_last") == start
     d["_la_last"] = start + duration
     if not sequential:
+        d["_la_grow"] = FIRST_WINDOW_BLOCKS           # a new stream: start small again
         return None
     from .snippet import Snippet
     nodes = d.get("_la_nodes")                        # graphs are static: the walk is done once
@@ -192,7 +195,12 @@ def render(pe, start: int, duration: int):
     _tls.busy = True
     _tls.period = block
     try:
-        big = pe._render(start, duration * max(2, min(AHEAD_BLOCKS, AHEAD_FRAMES // duration)))
+        # slow start: a stream that stops after a few blocks has not paid for 64; one that keeps going reaches
+        # the full window with its second refill (8, then 64 blocks)
+        grow = d.get("_la_grow", FIRST_WINDOW_BLOCKS)
+        d["_la_grow"] = grow * WINDOW_GROWTH
+        blocks = max(2, min(grow, AHEAD_BLOCKS, AHEAD_FRAMES // duration))
+        big = pe._render(start, duration * blocks)
     finally:
         _tls.busy = False
         _tls.period = 0

@@ -23,7 +23,9 @@ import os
 import threading
 
 SMALL_BLOCK = 1 << 20       # requests up to this many frames are served from a resident window
-AHEAD_BLOCKS = 64           # at most this many blocks per refill ...
+FIRST_WINDOW_BLOCKS = 8     # the first refill of a stream; every further one is WINDOW_GROWTH times longer, up to
+WINDOW_GROWTH = 8
+AHEAD_BLOCKS = 64           # ... at most this many blocks per refill ...
 AHEAD_FRAMES = 1 << 24      # ... and about this many frames (64 MB per channel: a 44 100-frame pull refills 64
                             # blocks at a time, a 1 M-frame pull 16: launches of that size leave the ~4 us floor
                             # of a launch behind and stream at HBM rate)
@@ -76,10 +78,13 @@ def render(pe, start: int, duration: int):
     sequential = d.get("_ra_last") == start
     d["_ra_last"] = start + duration
     if not sequential:
+        d["_ra_grow"] = FIRST_WINDOW_BLOCKS
         return None             # first pull / random access: render normally, remember where it ended
+    grow = d.get("_ra_grow", FIRST_WINDOW_BLOCKS)      # slow start: 8, then 64 blocks (see look_ahead.py)
+    d["_ra_grow"] = grow * WINDOW_GROWTH
     _tls.busy = True
     try:
-        big = pe._render(start, duration * ahead_blocks(duration))
+        big = pe._render(start, duration * max(2, min(grow, ahead_blocks(duration))))
     finally:
         _tls.busy = False
     if not big.on_device:

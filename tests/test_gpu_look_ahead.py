@@ -125,8 +125,14 @@ def test_streams_really_come_from_windows_and_states_roll_back():
     for i in range(5):
         flt.render(i * 1024, 1024)
     win = flt.__dict__.get("_la_win")
-    assert win is not None and win.first == 1024 and win.end == 1024 + 64 * 1024 and win.served == 5 * 1024
-    ahead_state = flt._state.to_host().copy()             # the state 64 blocks ahead
+    assert win is not None and win.first == 1024 and win.end == 1024 + look_ahead.FIRST_WINDOW_BLOCKS * 1024
+    assert win.served == 5 * 1024
+    for i in range(5, 30):                                    # slow start: the next window is 64 blocks long
+        flt.render(i * 1024, 1024)
+    win = flt.__dict__.get("_la_win")
+    first = 1 + look_ahead.FIRST_WINDOW_BLOCKS
+    assert win.first == first * 1024 and win.end == (first + 64) * 1024 and win.served == 30 * 1024
+    ahead_state = flt._state.to_host().copy()             # the state at the end of the window
     look_ahead.settle(flt)
     assert "_la_win" not in flt.__dict__
     settled = flt._state.to_host().copy()
@@ -137,7 +143,7 @@ def test_streams_really_come_from_windows_and_states_roll_back():
         r2 = pg.NullRenderer(SR)
         r2.set_source(ref)
         r2.start()
-        for i in range(5):
+        for i in range(30):
             ref.render(i * 1024, 1024)
         want = ref._state.to_host().copy()
         r2.stop()
@@ -218,6 +224,7 @@ def test_block_sensitive_graphs_need_blocks_passed_through():
         comp.render(i * 1024, 1024)
     assert comp.__dict__["_la_win"].block == 1024
     comp.render(4096, 500)                                   # another block size: the old window is settled ...
+    comp.render(4596, 500)
     win = comp.__dict__["_la_win"]
-    assert win.block == 500 and win.first == 4096            # ... and the stream goes on in windows of the new one
+    assert win.block == 500 and win.first in (4096, 4596)    # ... and the stream goes on in windows of the new one
     r.stop()
