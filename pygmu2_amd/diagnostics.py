@@ -11,6 +11,7 @@ import threading
 from collections import defaultdict
 
 _tls = threading.local()
+_ACTIVE = 0          # threads with diagnostics on: ProcessingElement.render looks no further while this is 0
 
 
 def _state():
@@ -23,12 +24,19 @@ def _state():
 
 
 def enable(pull_counts: bool = True, timing: bool = True) -> None:
+    global _ACTIVE
     s = _state()
+    if not s["enabled"]:
+        _ACTIVE += 1
     s["enabled"], s["pulls"], s["timing"] = True, bool(pull_counts), bool(timing)
 
 
 def disable() -> None:
-    _state()["enabled"] = False
+    global _ACTIVE
+    s = _state()
+    if s["enabled"]:
+        _ACTIVE -= 1
+    s["enabled"] = False
 
 
 def reset() -> None:

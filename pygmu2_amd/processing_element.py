@@ -21,6 +21,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import device as _dev
+from . import diagnostics as _diag
 from . import look_ahead as _look_ahead
 from . import read_ahead as _read_ahead
 from .config import get_sample_rate, handle_error
@@ -68,9 +69,24 @@ class ProcessingElement(ABC):
 
     # ------------------------------------------------------------------ rendering
     def render(self, start: int, duration: int) -> Snippet:
-        if duration < 0:
-            raise ValueError(f"duration must be >= 0, got {duration}")
-        diag = is_enabled()
+        if duration <= 0:
+            if duration < 0:
+                raise ValueError(f"duration must be >= 0, got {duration}")
+        elif not _diag._ACTIVE:
+            # the two hot exits first: the next block of a stream served from a resident window
+            d = self.__dict__
+            win = d.get("_la_win")                       # look-ahead window of a stateful sub-graph
+            if win is not None:
+                end = start + duration
+                if start == win.served and end <= win.end and (not win.block or duration == win.block):
+                    win.served = d["_la_last"] = end
+                    return Snippet.window_rows(start, win.buf, start - win.first, duration)
+            else:
+                win = d.get("_ra_win")                   # read-ahead window of a pure sub-graph: (first, end, buffer)
+                if win is not None and win[0] <= start and start + duration <= win[1]:
+                    d["_ra_last"] = start + duration
+                    return Snippet.window_rows(start, win[2], start - win[0], duration)
+        diag = is_enabled() if _diag._ACTIVE else False
         if diag and pull_count_enabled():
             record_pull(self)
         if duration == 0:
@@ -85,7 +101,7 @@ class ProcessingElement(ABC):
         # a PE that is not eligible skips the call altogether)
         if duration <= _RA_LIMIT:
             d = self.__dict__
-            win = d.get("_ra_win")                       # resident window of a pure sub-graph: (first, end, buffer)
+            win = d.get("_ra_win")
             if win is not None and win[0] <= start and start + duration <= win[1]:
                 d["_ra_last"] = start + duration
                 return Snippet.window_rows(start, win[2], start - win[0], duration)
