@@ -381,6 +381,9 @@ k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_st
                   int channels, double sr, const pgx_ladder_params *params, const float *freq,
                   const float *resonance, const float *drive, const double *state, int64_t settle,
                   int64_t accurate, int64_t seg_len, int nseg, double *warm, double *ends) {
+    // a latency-bound wave: when a throughput-bound kernel shares the chip (the next block's oscillators, rendered
+    // beside this kernel) its instructions go first
+    __builtin_amdgcn_s_setprio(3);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t chains = (int64_t)batch * channels;
     if (t >= chains * nseg) return;

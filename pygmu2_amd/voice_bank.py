@@ -36,6 +36,7 @@ from .snippet import Snippet
 from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
+PREFETCH_LADDER_INPUT = True  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
@@ -211,6 +212,12 @@ class _BiquadNode(_Node):
 
 
 class _LadderNode(_Node):
+    """Bank of LadderPEs.  The ladder kernel is latency-bound (two waves per CU, most of the chip idle) and its
+    input, a bank of scalar oscillators, is a pure function of time plus a few carried numbers -- so while block k
+    goes through the ladder on the (high-priority) side stream, the oscillators of block k+1 are rendered on the
+    main one.  The speculation is undone exactly if the next pull is not the next block: the oscillator states
+    are snapshot before it and copied back."""
+
     def __init__(self, pes, children):
         super().__init__(pes, children)
         rec = np.zeros(self.k, dtype=_dev.LADDER_PARAMS)
@@ -223,8 +230,18 @@ class _LadderNode(_Node):
         settles = [pe._settle_frames() for pe in pes]
         self.settle = 0 if min(settles) == 0 else max(settles)     # one warm-up length for the batch
         self.accurate = max(pe._accurate_frames() for pe in pes) if self.settle else 0
+        self.ahead = None          # (start, n, input buffer, (state copy, last_end)) rendered ahead of the caller
+
+    def _forget_ahead(self, restore: bool) -> None:
+        ahead, self.ahead = self.ahead, None
+        if ahead is not None and restore:
+            src = self.children["source"]
+            saved, last_end = ahead[3]
+            check(lib().pgx_memcpy_d2d(src.state.ptr, saved.ptr, saved.nbytes), "pgx_memcpy_d2d")
+            src.last_end = last_end
 
     def reset(self):
+        self._forget_ahead(restore=False)            # the oscillators start over anyway
         super().reset()
         if self.state is not None:
             self.state.zero_()
@@ -233,18 +250,45 @@ class _LadderNode(_Node):
         return self.children["source"].channels()
 
     def render(self, start, n):
-        x = self.children["source"].render(start, n)
+        L = lib()
+        src = self.children["source"]
+        x = None
+        if self.ahead is not None:
+            if self.ahead[0] == start and self.ahead[1] == n:
+                x, self.ahead = self.ahead[2], None
+            else:
+                self._forget_ahead(restore=True)
+        if x is None:
+            x = src.render(start, n)
         ch = x.shape[2]
         if self.state is None:
             self.state = DeviceBuffer((self.k, ch, 9), np.float64, zero=True)
         out = DeviceBuffer((self.k, n, ch), np.float32)
-        L = lib()
         need = L.pgx_ladder_workspace_bytes(self.k, n, ch, self.settle)
         if need and (self.ws is None or self.ws.nbytes < need):
             self.ws = DeviceBuffer((need,), np.uint8, zero=True)
-        check(L.pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
-                           None, None, None, self.state.ptr, self.settle, self.accurate,
-                           ptr(self.ws) if need else None), "pgx_ladder")
+
+        def ladder():
+            check(L.pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
+                               None, None, None, self.state.ptr, self.settle, self.accurate,
+                               ptr(self.ws) if need else None), "pgx_ladder")
+
+        speculate = (PREFETCH_LADDER_INPUT and isinstance(src, (_SuperSawNode, _BlitSawNode)) and n >= 4096
+                     and not L.pgx_stream_is_forked())
+        if not speculate:
+            ladder()
+            return out
+        saved = DeviceBuffer(src.state.shape, src.state.dtype)
+        check(L.pgx_memcpy_d2d(saved.ptr, src.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
+        snapshot = (saved, src.last_end)
+        check(L.pgx_stream_fork(), "pgx_stream_fork")              # side stream: behind x and the snapshot
+        try:
+            ladder()
+            check(L.pgx_stream_select(0), "pgx_stream_select")
+            nxt = src.render(start + n, n)                         # main stream, next to the ladder
+        finally:
+            check(L.pgx_stream_join(), "pgx_stream_join")          # whatever follows on the main stream waits for the ladder
+        self.ahead = (start + n, n, nxt, snapshot)
         return out
 
 

@@ -55,10 +55,15 @@ def test_c4_bank_supersaw_ladder():
         return pg.LadderPE(pg.SuperSawPE(55.0 * 2 ** (i / 12.0), voices=7, detune_cents=20.0, seed=i),
                            frequency=1200.0, resonance=0.3, mode=pg.LadderMode.LP24, drive=1.0, oversample=2)
 
-    blocks = [(0, 4096), (4096, 4096)]
+    # from 4096 frames on the bank renders the next block's oscillators beside this block's ladder: the third
+    # block is a seek and the fifth another length, so that speculation is rolled back twice
+    blocks = [(0, 4096), (4096, 4096), (30000, 4096), (34096, 4096), (38192, 5000), (43192, 5000)]
     banked = pg.MixPE(*[voice(i) for i in range(6)])
     got_bank = _render_blocks(banked, 48000, blocks)
     assert banked._bank
+    again = _render_blocks(banked, 48000, blocks)               # stop/start in between: the same samples again
+    for a, b in zip(got_bank, again):
+        assert np.array_equal(a, b)
     plain = pg.MixPE(*[voice(i) for i in range(6)])
     plain._bank = False
     got_plain = _render_blocks(plain, 48000, blocks)
