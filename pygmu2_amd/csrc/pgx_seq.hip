@@ -630,9 +630,25 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
     double *ends = warm + (size_t)chains * p.nseg * 9;
     int *fallbacks = (int *)(ends + (size_t)chains * p.nseg * 9);
     const int64_t lanes = (int64_t)chains * p.nseg;
-    // one wave per workgroup, two per CU: 256-thread workgroups with 64 Ki lanes (a wave on every SIMD, half the
-    // exact samples per lane) measure the same 0.33 ms per C4 block, 64-thread ones with 64 Ki lanes 0.46
-    hipLaunchKernelGGL(k_ladder_segments, dim3((unsigned)pgx::ceil_div(lanes, 64)), dim3(64), 0, pgx::stream(), out,
+    // (64-thread workgroups, two per CU, and 256-thread ones -- a wave on every SIMD of half the CUs -- measure the
+    // same; 64-thread ones with 64 Ki lanes are a third slower: they are not spread over the SIMDs)
+    static const int wg = getenv("PGX_LADDER_WG") ? atoi(getenv("PGX_LADDER_WG")) : 256;
+    static const int lds_claim = getenv("PGX_LADDER_LDS") ? atoi(getenv("PGX_LADDER_LDS")) : 160 * 1024;
+    const unsigned groups = (unsigned)pgx::ceil_div(lanes, wg);
+    // The lanes are dependent float64 chains: a wave wants a SIMD to itself.  Up to 128 workgroups each claim a
+    // whole CU's LDS (never touched), so a throughput-bound kernel launched beside this one -- the next block's
+    // oscillators (voice_bank.py) -- gets the other CUs instead of sharing these SIMDs' issue slots.
+    size_t lds = 0;
+    if (wg == 256 && groups <= 128 && lds_claim > 0) {
+        lds = (size_t)lds_claim;
+        static bool allowed = false;
+        if (!allowed && lds > 64 * 1024) {
+            PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ladder_segments),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            allowed = true;
+        }
+    }
+    hipLaunchKernelGGL(k_ladder_segments, dim3(groups), dim3(wg), lds, pgx::stream(), out,
                        out_stride, in, in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
                        (const double *)state, settle_frames,
                        accurate_frames > 0 && accurate_frames < settle_frames ? accurate_frames : settle_frames,

@@ -214,9 +214,9 @@ class _BiquadNode(_Node):
 class _LadderNode(_Node):
     """Bank of LadderPEs.  The ladder kernel is latency-bound (two waves per CU, most of the chip idle) and its
     input, a bank of scalar oscillators, is a pure function of time plus a few carried numbers -- so while block k
-    goes through the ladder on the (high-priority) side stream, the oscillators of block k+1 are rendered on the
-    main one.  The speculation is undone exactly if the next pull is not the next block: the oscillator states
-    are snapshot before it and copied back."""
+    goes through the ladder on the main stream, the oscillators of block k+1 are rendered on the side stream.
+    The speculation is undone exactly if the next pull is not the next block: the oscillator states are
+    snapshot before it and copied back."""
 
     def __init__(self, pes, children):
         super().__init__(pes, children)
@@ -278,16 +278,19 @@ class _LadderNode(_Node):
         if not speculate:
             ladder()
             return out
-        saved = DeviceBuffer(src.state.shape, src.state.dtype)
-        check(L.pgx_memcpy_d2d(saved.ptr, src.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
-        snapshot = (saved, src.last_end)
-        check(L.pgx_stream_fork(), "pgx_stream_fork")              # side stream: behind x and the snapshot
+        # The ladder stays on the main stream, in front of everything else of this block: no cross-stream wait on
+        # the chain ladder -> finish -> mix -> next ladder, and its waves are placed before the oscillators' are.
+        check(L.pgx_stream_fork(), "pgx_stream_fork")              # side stream: behind x
         try:
-            ladder()
             check(L.pgx_stream_select(0), "pgx_stream_select")
-            nxt = src.render(start + n, n)                         # main stream, next to the ladder
+            ladder()
+            check(L.pgx_stream_select(1), "pgx_stream_select")
+            saved = DeviceBuffer(src.state.shape, src.state.dtype)
+            check(L.pgx_memcpy_d2d(saved.ptr, src.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
+            snapshot = (saved, src.last_end)
+            nxt = src.render(start + n, n)                         # side stream, next to the ladder
         finally:
-            check(L.pgx_stream_join(), "pgx_stream_join")          # whatever follows on the main stream waits for the ladder
+            check(L.pgx_stream_join(), "pgx_stream_join")          # what follows the ladder also follows the oscillators
         self.ahead = (start + n, n, nxt, snapshot)
         return out
 
