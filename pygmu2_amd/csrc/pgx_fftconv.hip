@@ -29,7 +29,9 @@ namespace {
 constexpr int kFBlock = 256;
 constexpr double kTwoPi = 6.283185307179586;
 
-struct cplx {
+// 16-byte aligned: one ds_read_b128 / ds_write_b128 per element (consecutive lanes: conflict-free), where two
+// 8-byte accesses at a 16-byte lane stride run into each other's banks
+struct alignas(16) cplx {
     double x, y;
 };
 // (explicit FMAs: the transforms are not bound to a reference operation order, only to its float64 accuracy --
