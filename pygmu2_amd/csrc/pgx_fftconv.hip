@@ -79,13 +79,15 @@ __device__ __forceinline__ void fill_stage_twiddles(cplx *st, const cplx *g, int
 // Stockham autosort between two LDS images (`a` holds the input, `b` is scratch): one barrier per stage.
 // `st`: the stage tables above.  All 256 threads take part; the input must be visible (barrier) on entry;
 // returns the image that holds the result, visible to every thread.
+// Stages with sub-transform length 2^lns_from <= Ns < 2^lns_to only (lns_from even): `a` then holds the output
+// of the stages before them.
 template <int TILE>
-__device__ cplx *lds_fft(cplx *a, cplx *b, const cplx *st, int lm, int stride) {
+__device__ cplx *lds_fft_stages(cplx *a, cplx *b, const cplx *st, int lm, int stride, int lns_from, int lns_to) {
     const int tid = threadIdx.x;
     constexpr int U4 = TILE / 4 / kFBlock;                     // radix-4 butterflies per thread
     constexpr int U2 = TILE / 2 / kFBlock;                     // radix-2 butterflies per thread
     cplx *src = a, *dst = b;
-    for (int lns = 0; lns < lm;) {
+    for (int lns = lns_from; lns < lns_to;) {
         const int Ns = 1 << lns;
         const cplx *tws = st + (Ns - 1);
         if (lm - lns >= 2) {
@@ -130,6 +132,65 @@ __device__ cplx *lds_fft(cplx *a, cplx *b, const cplx *st, int lm, int stride) {
         dst = t;
     }
     return src;
+}
+
+template <int TILE>
+__device__ cplx *lds_fft(cplx *a, cplx *b, const cplx *st, int lm, int stride) {
+    return lds_fft_stages<TILE>(a, b, st, lm, stride, 0, lm);
+}
+
+// The first Stockham stage (radix 4, Ns = 1: no twiddles) on values a thread already holds: x[j + t*q], t = 0..3,
+// q = M/4, come in, the four outputs go to positions 4j + t.
+__device__ __forceinline__ void first_stage(const cplx &x0, const cplx &x1, const cplx &x2, const cplx &x3, cplx *at4j) {
+    const cplx s0 = cadd(x0, x2), s1 = csub(x0, x2), s2 = cadd(x1, x3), s3 = mul_neg_i(csub(x1, x3));
+    at4j[0] = cadd(s0, s2);
+    at4j[1] = cadd(s1, s3);
+    at4j[2] = csub(s0, s2);
+    at4j[3] = csub(s1, s3);
+}
+
+// One sequence of M = TILE = 2^lm points per workgroup, thread tid holding x[tid + u*256] in v[u] (the order the
+// row pass loads them in): DFT with the first and the last stage in registers.  Those are the butterflies whose
+// operands / results are exactly the thread's own elements, so of the lm/2 LDS round trips (write, barrier,
+// read) two disappear.  `a`, `b`: the two LDS images (contents irrelevant; nobody may still be reading `a`).
+// Returns with X[tid + u*256] in v[u]; the image last read is returned (the other one is free to write).
+template <int TILE>
+__device__ cplx *tile_fft_regs(cplx (&v)[TILE / kFBlock], cplx *a, cplx *b, const cplx *st, int lm) {
+    constexpr int PT = TILE / kFBlock, U4 = PT / 4, U2 = PT / 2;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int bf = 0; bf < U4; ++bf)
+        first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], a + 4 * (tid + bf * kFBlock));
+    __syncthreads();
+    const int last = (lm & 1) ? lm - 1 : lm - 2;                // lns of the final stage
+    const cplx *src = lds_fft_stages<TILE>(a, b, st, lm, TILE, 2, last);
+    const int Ns = 1 << last;
+    const cplx *tws = st + (Ns - 1);
+    if (lm & 1) {                                               // radix 2, Ns = q = M/2: k = j, outputs j, j + q
+#pragma unroll
+        for (int bf = 0; bf < U2; ++bf) {
+            const int j = tid + bf * kFBlock;
+            const cplx x0 = src[j];
+            const cplx c1 = cmul(src[j + Ns], tws[j]);
+            v[bf] = cadd(x0, c1);
+            v[bf + U2] = csub(x0, c1);
+        }
+    } else {                                                    // radix 4, Ns = q = M/4: k = j, outputs j + t*q
+#pragma unroll
+        for (int bf = 0; bf < U4; ++bf) {
+            const int j = tid + bf * kFBlock;
+            const cplx x0 = src[j];
+            const cplx c1 = cmul(src[j + Ns], tws[j]);
+            const cplx c2 = cmul(src[j + 2 * Ns], tws[Ns + j]);
+            const cplx c3 = cmul(src[j + 3 * Ns], tws[2 * Ns + j]);
+            const cplx s0 = cadd(x0, c2), s1 = csub(x0, c2), s2 = cadd(c1, c3), s3 = mul_neg_i(csub(c1, c3));
+            v[bf] = cadd(s0, s2);
+            v[bf + U4] = cadd(s1, s3);
+            v[bf + 2 * U4] = csub(s0, s2);
+            v[bf + 3 * U4] = csub(s1, s3);
+        }
+    }
+    return const_cast<cplx *>(src);
 }
 
 // Where the real sequences come from / go to.
@@ -222,13 +283,18 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
         }
     }
     fill_stage_twiddles(tw, tb.t1, g.l1);
+    {
+        // the thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT: the operands of PT/4
+        // first-stage butterflies, done before anything goes to LDS
+        constexpr int U4 = PT / 4;
+        cplx *colbase = buf + (tid & (CW - 1)) * stride;
+        const int j0 = tid >> lcw, jstep = N1 / PT;
 #pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * kFBlock;
-        buf[(e & (CW - 1)) * stride + (e >> lcw)] = v[u];
+        for (int bf = 0; bf < U4; ++bf)
+            first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], colbase + 4 * (j0 + bf * jstep));
     }
     __syncthreads();
-    const cplx *res = lds_fft<TILE>(buf, alt, tw, g.l1, stride);
+    const cplx *res = lds_fft_stages<TILE>(buf, alt, tw, g.l1, stride, 2, g.l1);
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
         const int e = tid + u * kFBlock;
@@ -279,27 +345,37 @@ k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *
         }
     }
     fill_stage_twiddles(tw, tb.t2, g.l2);
+    if (FULL && N2 == TILE) {
+        // one row per workgroup: first and last stage of both transforms in registers (tile_fft_regs)
+        cplx *read_last = tile_fft_regs<TILE>(v, buf, alt, tw, g.l2);
 #pragma unroll
-    for (int u = 0; u < PT; ++u) buf[tid + u * kFBlock] = v[u];
-    __syncthreads();
-    cplx *res = lds_fft<TILE>(buf, alt, tw, g.l2, N2);
-    if (!FULL) {
-#pragma unroll
-        for (int u = 0; u < PT; ++u) wk[tid + u * kFBlock] = res[tid + u * kFBlock];
-        return;
-    }
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * kFBlock;
-        res[e] = cconj(cmul(res[e], hv[u]));                       // own elements only: no barrier needed before
-    }
-    __syncthreads();
-    const cplx *fin = lds_fft<TILE>(res, res == buf ? alt : buf, tw, g.l2, N2);
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * kFBlock;
+        for (int u = 0; u < PT; ++u) v[u] = cconj(cmul(v[u], hv[FULL ? u : 0]));
+        tile_fft_regs<TILE>(v, read_last == buf ? alt : buf, read_last, tw, g.l2);
         // conj() completes the inverse row transform; the conjugate twiddle undoes step (1)'s
-        wk[e] = cmul(cconj(fin[e]), cconj(bigtw[u]));
+#pragma unroll
+        for (int u = 0; u < PT; ++u) wk[tid + u * kFBlock] = cmul(cconj(v[u]), cconj(bigtw[FULL ? u : 0]));
+    } else {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) buf[tid + u * kFBlock] = v[u];
+        __syncthreads();
+        cplx *res = lds_fft<TILE>(buf, alt, tw, g.l2, N2);
+        if (!FULL) {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) wk[tid + u * kFBlock] = res[tid + u * kFBlock];
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int e = tid + u * kFBlock;
+            res[e] = cconj(cmul(res[e], hv[FULL ? u : 0]));       // own elements only: no barrier needed before
+        }
+        __syncthreads();
+        const cplx *fin = lds_fft<TILE>(res, res == buf ? alt : buf, tw, g.l2, N2);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int e = tid + u * kFBlock;
+            wk[e] = cmul(cconj(fin[e]), cconj(bigtw[FULL ? u : 0]));
+        }
     }
     if (hist_dst != nullptr) {
         const int64_t total = (g.L - 1) * g.out_ch;
