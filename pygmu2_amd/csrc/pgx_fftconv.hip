@@ -149,40 +149,31 @@ __device__ __forceinline__ void first_stage(const cplx &x0, const cplx &x1, cons
     at4j[3] = csub(s1, s3);
 }
 
-// One sequence of M = TILE = 2^lm points per workgroup, thread tid holding x[tid + u*256] in v[u] (the order the
-// row pass loads them in): DFT with the first and the last stage in registers.  Those are the butterflies whose
-// operands / results are exactly the thread's own elements, so of the lm/2 LDS round trips (write, barrier,
-// read) two disappear.  `a`, `b`: the two LDS images (contents irrelevant; nobody may still be reading `a`).
-// Returns with X[tid + u*256] in v[u]; the image last read is returned (the other one is free to write).
-template <int TILE>
-__device__ cplx *tile_fft_regs(cplx (&v)[TILE / kFBlock], cplx *a, cplx *b, const cplx *st, int lm) {
-    constexpr int PT = TILE / kFBlock, U4 = PT / 4, U2 = PT / 2;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int bf = 0; bf < U4; ++bf)
-        first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], a + 4 * (tid + bf * kFBlock));
-    __syncthreads();
+// The last Stockham stage (Ns = q: k = j) into registers.  A thread that will consume X[j0 + u*jstep], u < PT,
+// jstep = M/PT, of a sequence computes exactly the butterflies j = j0 + bf*jstep whose outputs those are.
+template <int PT>
+__device__ __forceinline__ void last_stage(const cplx *seq, const cplx *st, int lm, int j0, int jstep, cplx (&v)[PT]) {
+    constexpr int U4 = PT / 4, U2 = PT / 2;
     const int last = (lm & 1) ? lm - 1 : lm - 2;                // lns of the final stage
-    const cplx *src = lds_fft_stages<TILE>(a, b, st, lm, TILE, 2, last);
     const int Ns = 1 << last;
     const cplx *tws = st + (Ns - 1);
-    if (lm & 1) {                                               // radix 2, Ns = q = M/2: k = j, outputs j, j + q
+    if (lm & 1) {                                               // radix 2: outputs j, j + M/2
 #pragma unroll
         for (int bf = 0; bf < U2; ++bf) {
-            const int j = tid + bf * kFBlock;
-            const cplx x0 = src[j];
-            const cplx c1 = cmul(src[j + Ns], tws[j]);
+            const int j = j0 + bf * jstep;
+            const cplx x0 = seq[j];
+            const cplx c1 = cmul(seq[j + Ns], tws[j]);
             v[bf] = cadd(x0, c1);
             v[bf + U2] = csub(x0, c1);
         }
-    } else {                                                    // radix 4, Ns = q = M/4: k = j, outputs j + t*q
+    } else {                                                    // radix 4: outputs j + t * M/4
 #pragma unroll
         for (int bf = 0; bf < U4; ++bf) {
-            const int j = tid + bf * kFBlock;
-            const cplx x0 = src[j];
-            const cplx c1 = cmul(src[j + Ns], tws[j]);
-            const cplx c2 = cmul(src[j + 2 * Ns], tws[Ns + j]);
-            const cplx c3 = cmul(src[j + 3 * Ns], tws[2 * Ns + j]);
+            const int j = j0 + bf * jstep;
+            const cplx x0 = seq[j];
+            const cplx c1 = cmul(seq[j + Ns], tws[j]);
+            const cplx c2 = cmul(seq[j + 2 * Ns], tws[Ns + j]);
+            const cplx c3 = cmul(seq[j + 3 * Ns], tws[2 * Ns + j]);
             const cplx s0 = cadd(x0, c2), s1 = csub(x0, c2), s2 = cadd(c1, c3), s3 = mul_neg_i(csub(c1, c3));
             v[bf] = cadd(s0, s2);
             v[bf + U4] = cadd(s1, s3);
@@ -190,7 +181,25 @@ __device__ cplx *tile_fft_regs(cplx (&v)[TILE / kFBlock], cplx *a, cplx *b, cons
             v[bf + 3 * U4] = csub(s1, s3);
         }
     }
-    return const_cast<cplx *>(src);
+}
+
+// DFT of the sequences of a tile with the first and the last stage in registers: those are the butterflies whose
+// operands / results are the thread's own elements x[j0 + u*jstep] (u < PT, jstep = M/PT) of the sequence at
+// `seq_off`, so of the lm/2 LDS round trips (write, barrier, read) two disappear.  `a`, `b`: the two LDS images
+// (contents irrelevant; nobody may still be reading `a`), `stride` between sequences.  Returns the image last
+// read (the other one is free to write), with X[j0 + u*jstep] in v[u].
+template <int TILE>
+__device__ cplx *tile_fft_regs(cplx (&v)[TILE / kFBlock], cplx *a, cplx *b, const cplx *st, int lm, int stride,
+                               int seq_off, int j0, int jstep) {
+    constexpr int PT = TILE / kFBlock, U4 = PT / 4;
+#pragma unroll
+    for (int bf = 0; bf < U4; ++bf)
+        first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], a + seq_off + 4 * (j0 + bf * jstep));
+    __syncthreads();
+    const int last = (lm & 1) ? lm - 1 : lm - 2;
+    cplx *src = lds_fft_stages<TILE>(a, b, st, lm, stride, 2, last);
+    last_stage<PT>(src + seq_off, st, lm, j0, jstep, v);
+    return src;
 }
 
 // Where the real sequences come from / go to.
@@ -283,24 +292,15 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
         }
     }
     fill_stage_twiddles(tw, tb.t1, g.l1);
-    {
-        // the thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT: the operands of PT/4
-        // first-stage butterflies, done before anything goes to LDS
-        constexpr int U4 = PT / 4;
-        cplx *colbase = buf + (tid & (CW - 1)) * stride;
-        const int j0 = tid >> lcw, jstep = N1 / PT;
-#pragma unroll
-        for (int bf = 0; bf < U4; ++bf)
-            first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], colbase + 4 * (j0 + bf * jstep));
-    }
-    __syncthreads();
-    const cplx *res = lds_fft_stages<TILE>(buf, alt, tw, g.l1, stride, 2, g.l1);
+    // the thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT -- in the time domain and, in
+    // the same registers, in the frequency domain
+    tile_fft_regs<TILE>(v, buf, alt, tw, g.l1, stride, (tid & (CW - 1)) * stride, tid >> lcw, N1 / PT);
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
         const int e = tid + u * kFBlock;
         const int c = e & (CW - 1), k1 = e >> lcw;
         const int64_t i2 = col0 + c;
-        const cplx r = res[c * stride + k1];
+        const cplx r = v[u];
         if (MODE != 2) {
             wk[((int64_t)k1 << g.l2) + i2] = cmul(r, bigtw[u]);
         } else {
@@ -347,10 +347,10 @@ k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *
     fill_stage_twiddles(tw, tb.t2, g.l2);
     if (FULL && N2 == TILE) {
         // one row per workgroup: first and last stage of both transforms in registers (tile_fft_regs)
-        cplx *read_last = tile_fft_regs<TILE>(v, buf, alt, tw, g.l2);
+        cplx *read_last = tile_fft_regs<TILE>(v, buf, alt, tw, g.l2, TILE, 0, tid, kFBlock);
 #pragma unroll
         for (int u = 0; u < PT; ++u) v[u] = cconj(cmul(v[u], hv[FULL ? u : 0]));
-        tile_fft_regs<TILE>(v, read_last == buf ? alt : buf, read_last, tw, g.l2);
+        tile_fft_regs<TILE>(v, read_last == buf ? alt : buf, read_last, tw, g.l2, TILE, 0, tid, kFBlock);
         // conj() completes the inverse row transform; the conjugate twiddle undoes step (1)'s
 #pragma unroll
         for (int u = 0; u < PT; ++u) wk[tid + u * kFBlock] = cmul(cconj(v[u]), cconj(bigtw[FULL ? u : 0]));
