@@ -213,6 +213,7 @@ struct ConvGeom {
     int64_t npairs;       // ceil(nblocks / 2)
     int src_ch, out_ch;
     int hist_zero;        // the overlap history is all zeros (fresh stream): its buffer is not read
+    int mixed;            // one filter for every channel: any two (channel, block) items may share a transform
 };
 
 // Twiddle tables, made once per filter next to its spectrum (pgx_convolve_fft_prepare):
@@ -245,6 +246,34 @@ __device__ __forceinline__ double conv_input(const ConvGeom &g, const float *x, 
     return (double)x[i * g.src_ch + (g.src_ch == 1 ? 0 : ch)];
 }
 
+// The two real sequences packed into transform `pair` as real and imaginary part.  The filter is real, so they
+// never mix.  With one filter for all channels the items (channel, block), numbered ch*nblocks + b, are paired as
+// they come -- a single 65 537-frame stereo block is one transform, not two half-empty ones; with a filter per
+// channel a transform holds blocks 2p and 2p+1 of one channel.  b >= nblocks: an empty slot.
+struct PairItems {
+    int ch0, ch1;
+    int64_t b0, b1;
+};
+__device__ __forceinline__ PairItems pair_items(const ConvGeom &g, int64_t pair) {
+    PairItems it;
+    if (g.mixed) {
+        const int64_t q0 = 2 * pair, q1 = q0 + 1;
+        it.ch0 = (int)(q0 / g.nblocks);
+        it.b0 = q0 - (int64_t)it.ch0 * g.nblocks;
+        it.ch1 = (int)(q1 / g.nblocks);
+        it.b1 = q1 - (int64_t)it.ch1 * g.nblocks;
+        if (it.ch1 >= g.out_ch) {
+            it.ch1 = it.ch0;
+            it.b1 = g.nblocks;
+        }
+    } else {
+        it.ch0 = it.ch1 = (int)(pair / g.npairs);
+        it.b0 = 2 * (pair - (int64_t)it.ch0 * g.npairs);
+        it.b1 = it.b0 + 1;
+    }
+    return it;
+}
+
 // MODE 0: forward, input = packed signal blocks; MODE 1: forward, input = filter taps (spectrum
 // preparation); MODE 2: inverse, output = float32 samples.
 template <int MODE, int TILE>
@@ -263,8 +292,9 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
     const int64_t pair = blockIdx.y;
     const int64_t col0 = (int64_t)blockIdx.x * CW;
     cplx *wk = work + pair * g.N;
-    const int ch = (MODE == 1) ? (int)pair : (int)(pair / g.npairs);
-    const int64_t p = (MODE == 1) ? 0 : pair - (int64_t)ch * g.npairs;
+    const int ch = (int)pair;                                      // MODE 1: the filter channel
+    PairItems it{};
+    if (MODE != 1) it = pair_items(g, pair);
     const double inv_n = 1.0 / (double)g.N;
 
     // everything that comes from HBM is requested first: the inputs, then the twiddles used at the very end
@@ -275,7 +305,7 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
         const int c = e & (CW - 1), i1 = e >> lcw;
         const int64_t pos = ((int64_t)i1 << g.l2) + col0 + c;
         if (MODE == 0) {
-            v[u] = cplx{conv_input(g, x, hist, 2 * p, ch, pos), conv_input(g, x, hist, 2 * p + 1, ch, pos)};
+            v[u] = cplx{conv_input(g, x, hist, it.b0, it.ch0, pos), conv_input(g, x, hist, it.b1, it.ch1, pos)};
         } else if (MODE == 1) {
             v[u] = cplx{pos < g.L ? (double)h[pos * fir_ch + ch] : 0.0, 0.0};
         } else {
@@ -307,10 +337,10 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
             // natural order: k1 is the row i1 of the time-domain block
             const int64_t pos = ((int64_t)k1 << g.l2) + i2;
             if (pos < g.L - 1) continue;                           // the wrapped-around part of overlap-save
-            const int64_t o0 = 2 * p * g.V + pos - (g.L - 1);
-            if (o0 < g.n) out[o0 * g.out_ch + ch] = (float)(r.x * inv_n);
-            const int64_t o1 = o0 + g.V;
-            if (2 * p + 1 < g.nblocks && o1 < g.n) out[o1 * g.out_ch + ch] = (float)(-r.y * inv_n);   // conj
+            const int64_t o0 = it.b0 * g.V + pos - (g.L - 1);
+            if (o0 < g.n) out[o0 * g.out_ch + it.ch0] = (float)(r.x * inv_n);
+            const int64_t o1 = it.b1 * g.V + pos - (g.L - 1);
+            if (it.b1 < g.nblocks && o1 < g.n) out[o1 * g.out_ch + it.ch1] = (float)(-r.y * inv_n);   // conj
         }
     }
 }
@@ -515,7 +545,7 @@ int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, in
     ConvGeom g{};
     PGX_CHECK_ARG(spectrum && h && fir_len >= 1 && fir_channels >= 1, "pgx_convolve_fft_prepare: bad argument");
     PGX_CHECK_ARG(fft_geometry(fft_size, fir_len, g), "pgx_convolve_fft_prepare: unsupported fft size");
-    g.n = 0; g.nblocks = 0; g.npairs = 1; g.src_ch = 1; g.out_ch = fir_channels; g.hist_zero = 0;
+    g.n = 0; g.nblocks = 0; g.npairs = 1; g.src_ch = 1; g.out_ch = fir_channels; g.hist_zero = 0; g.mixed = 0;
     cplx *H = (cplx *)spectrum;
     return fft_tile(fft_size) == 2048 ? launch_prepare<2048>(H, g, h, fir_channels)
                                       : launch_prepare<1024>(H, g, h, fir_channels);
@@ -539,7 +569,8 @@ int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, co
     g.src_ch = src_channels;
     g.out_ch = out_channels;
     g.hist_zero = hist_is_zero ? 1 : 0;
-    const int64_t pairs = g.npairs * out_channels;
+    g.mixed = fir_channels == 1 ? 1 : 0;
+    const int64_t pairs = g.mixed ? (g.nblocks * out_channels + 1) / 2 : g.npairs * out_channels;
     PGX_CHECK_ARG(pairs <= 65535, "pgx_convolve_fft: block too long for one call");
     cplx *work = (cplx *)workspace;
     float *hist_new = (float *)(work + pairs * g.N);
