@@ -962,8 +962,11 @@ __device__ __forceinline__ double saw_phase_at(double phase0, double chunk_base,
 // phase sum and the integrator level; both chains are replayed exactly as the single workgroup would run them,
 // so the output is the same bit for bit.  SEG = 1 (reduce): workgroup (inst, s) replays the phase chain up to
 // its first tile -- every full tile adds the same per-wave sums -- and records each wave's zero-state integrator
-// response (what block_scan_scalar_affine_wide folds).  SEG = 2 (apply): folds the recorded responses of the
-// tiles before it, then renders its tiles like SEG = 0.  Workspace per oscillator: {phase0, y0, wave responses}.
+// response (what block_scan_scalar_affine_wide folds).  k_blitsaw_chain then folds those responses in order, once
+// (one wave per oscillator: cn = lam_wave * cn + t, 8 steps per tile -- every segment replaying its own prefix
+// made the apply pass quadratic in the stream length: 890 us of a 990 us SuperSaw window of 2.8 M frames), and
+// SEG = 2 (apply) renders its tiles like SEG = 0 from the carries of its segment.  Workspace per oscillator:
+// {phase0, y0, wave responses[tiles * NW], integrator carry[tiles], phase-sum carry[nseg]}.
 template <bool STREAMS, int NW, int SEG>
 __global__ void __launch_bounds__(NW * 64)
 k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, const pgx_blitsaw_params *params,
@@ -1013,7 +1016,11 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
 
     constexpr int kTile = NW * 64 * kSawT;
     const int first_tile = seg * tiles_per_seg;
-    if (SEG && first_tile > 0) {
+    // workspace of one oscillator: {phase0, y0, wave responses[tiles * NW], carry_y[tiles], carry_sum[nseg]}
+    const int64_t all_tiles = SEG ? (n + kTile - 1) / kTile : 0;
+    double *tile_y = SEG ? wsi + 2 + all_tiles * NW : nullptr;
+    double *seg_sum = SEG ? tile_y + all_tiles : nullptr;
+    if (SEG == 1 && first_tile > 0) {
         // phase chain of the tiles before this segment: block_excl_sum_wide's carry, one add per group of waves
         double run = 0.0;
 #pragma unroll
@@ -1032,15 +1039,11 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         for (int tile = 0; tile < first_tile; ++tile)
 #pragma unroll
             for (int g = 0; g < NW / kWaves; ++g) carry_sum = carry_sum + tot[g];
-        if (SEG == 2) {
-            // integrator chain: cn = lam_wave * cn + t over every wave of every earlier tile, in order
-            const int64_t prev = (int64_t)first_tile * NW;
-            for (int64_t i0 = 0; i0 < prev; i0 += 64) {
-                const double mine = (i0 + lane < prev) ? wsi[2 + i0 + lane] : 0.0;
-                const int cnt = (prev - i0 < 64) ? (int)(prev - i0) : 64;
-                for (int i = 0; i < cnt; ++i) carry_y = lam_wave * carry_y + readlane_f64(mine, i);
-            }
-        }
+    }
+    if (SEG == 1 && tid == 0) seg_sum[seg] = carry_sum;       // the apply pass starts from it
+    if (SEG == 2) {
+        carry_sum = seg_sum[seg];
+        carry_y = tile_y[first_tile];                          // k_blitsaw_chain: the integrator chain, folded once
     }
     const int64_t seg_begin = SEG ? (int64_t)first_tile * kTile : 0;
     const int64_t seg_end = SEG ? ((seg_begin + (int64_t)tiles_per_seg * kTile < n) ? seg_begin + (int64_t)tiles_per_seg * kTile : n) : n;
@@ -1124,6 +1127,40 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     if (SEG != 1 && have_final) {
         state[inst * 2 + 0] = final_phase;
         state[inst * 2 + 1] = final_y;
+    }
+}
+
+// The integrator chain over the recorded wave responses of one oscillator (see k_blitsaw, SEG): the carry on
+// entering every tile, in the operation order of the single-workgroup path.  One wave per oscillator; the
+// responses come 64 at a time (8 tiles), the next 64 in flight while these are folded; the 64 steps of a chunk
+// are straight-line code (steps past the end fold zeros into a carry nobody reads).
+template <int NW>
+__global__ void __launch_bounds__(64)
+k_blitsaw_chain(const pgx_blitsaw_params *params, double *ws, int64_t ws_stride, int64_t tiles) {
+    static_assert(NW == 8, "a chunk of 64 responses is 8 whole tiles");
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    double *wsi = ws + (int64_t)inst * ws_stride;
+    const double *resp = wsi + 2;
+    double *tile_y = wsi + 2 + tiles * NW;
+    double lam = params[inst].leak;
+#pragma unroll
+    for (int s = 1; s < kSawT; s <<= 1) lam = lam * lam;      // leak^T
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lam = lam * lam;              // ... ^64: one wave's frames (k_blitsaw's lam_wave)
+    double c = wsi[1];
+    const int64_t total = tiles * NW;
+    double cur = lane < total ? resp[lane] : 0.0;
+    for (int64_t i0 = 0; i0 < total; i0 += 64) {
+        const double nxt = (i0 + 64 + lane < total) ? resp[i0 + 64 + lane] : 0.0;
+        double keep = 0.0;                                    // lane k: the carry on entering tile i0/8 + k
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            if ((i & 7) == 0) keep = (lane == (i >> 3)) ? c : keep;
+            c = lam * c + readlane_f64(cur, i);
+        }
+        const int64_t tile = (i0 >> 3) + lane;
+        if (lane < 8 && tile < tiles) tile_y[tile] = keep;
+        cur = nxt;
     }
 }
 
@@ -1459,7 +1496,7 @@ struct SawPlan {
 SawPlan saw_plan(int batch, int64_t n, bool streams) {
     constexpr int64_t tile = kSawWideWaves * 64 * kSawT;
     SawPlan p{1, 0, (n + tile - 1) / tile};
-    if (streams || batch >= 128 || p.tiles < 3 || p.tiles > 2048) return p;
+    if (streams || batch >= 128 || p.tiles < 3 || p.tiles > 65536) return p;
     p.tiles_per_seg = (int)((p.tiles + 255) / 256);
     p.nseg = (int)((p.tiles + p.tiles_per_seg - 1) / p.tiles_per_seg);
     return p;
@@ -2629,7 +2666,7 @@ int pgx_biquad_varying(float *out, const float *in, int64_t n, int channels, dou
 size_t pgx_blitsaw_workspace_bytes(int batch, int64_t n, int streams) {
     if (batch <= 0 || n <= 0) return 0;
     const SawPlan p = saw_plan(batch, n, streams != 0);
-    return p.nseg > 1 ? (size_t)batch * (2 + (size_t)p.tiles * kSawWideWaves) * sizeof(double) : 0;
+    return p.nseg > 1 ? (size_t)batch * (2 + (size_t)p.tiles * (kSawWideWaves + 1) + (size_t)p.nseg) * sizeof(double) : 0;
 }
 
 int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channels, double sample_rate,
@@ -2648,10 +2685,13 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
     hipLaunchKernelGGL((k_blitsaw<S, NWAVES, SEG>), GRID, dim3(NWAVES * 64), 0, pgx::stream(), out, out_stride, \
                        n, channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state,  \
                        (double *)workspace, ws_stride, plan.tiles_per_seg)
-    const int64_t ws_stride = 2 + plan.tiles * kSawWideWaves;
+    const int64_t ws_stride = 2 + plan.tiles * (kSawWideWaves + 1) + (int64_t)plan.nseg;
     if (workspace && plan.nseg > 1) {        // long streams of a few oscillators: several workgroups each
         PGX_SAW_LAUNCH(false, kSawWideWaves, 1, dim3(batch, plan.nseg));
         PGX_LAUNCH_CHECK("k_blitsaw<reduce>");
+        hipLaunchKernelGGL(k_blitsaw_chain<kSawWideWaves>, dim3(batch), dim3(64), 0, pgx::stream(), params,
+                           (double *)workspace, ws_stride, plan.tiles);
+        PGX_LAUNCH_CHECK("k_blitsaw_chain");
         PGX_SAW_LAUNCH(false, kSawWideWaves, 2, dim3(batch, plan.nseg));
     } else if (streams && wide) PGX_SAW_LAUNCH(true, kSawWideWaves, 0, dim3(batch));
     else if (streams) PGX_SAW_LAUNCH(true, kWaves, 0, dim3(batch));
