@@ -61,18 +61,38 @@ __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + 
 
 // ------------------------------------------------------------------------------------------
 // float64 sine / cosine for the oscillator kernels.
-// Cody-Waite reduction by pi with a 33+33+53-bit split (q*PI_A and q*PI_B are exact for |q| < 2^20)
-// followed by the Taylor polynomials on |r| <= pi/2 (degree 21 / 22: truncation < 2e-18).
-// Error ~1-2 ulp, like the libm / SVML routines behind the reference's np.sin; arguments beyond
-// 3e6 rad (where the split stops being exact) fall back to the ocml routine.
+// Cody-Waite reduction by pi with a 33+33+53-bit split, each step one fused multiply-add: x - q*PI_A is exact
+// (a multiple of 2^-31 below 4 in magnitude) for |q| < 2^31, the two further steps each round once at the size
+// of the reduced argument.  Then the Taylor polynomials on |r| <= pi/2 (degree 21 / 22: truncation < 2e-18).
+// Error ~1-2 ulp, like the libm / SVML routines behind the reference's np.sin (checked on the CPU against sinl
+// on 5e7 random arguments per decade up to 4e9 rad: 2.2e-16 absolute, no float32 result differing from libm's);
+// arguments beyond kSinFastRange = 2e9 rad (a 440 Hz tone after 200 hours) fall back to the ocml routine.
+constexpr double kSinFastRange = 2.0e9;
 #ifdef __HIPCC__
+// a / b, correctly rounded, for a divisor whose reciprocal y = RN(1/b) the caller made once (Markstein: a
+// faithful quotient corrected by its exact fused residual times a correctly rounded reciprocal rounds like the
+// division; the first correction makes q faithful, the second rounds it).  Five multiply-adds instead of the
+// IEEE sequence around v_rcp_f64; 5.9e9 numerators against 16 sample rates on the CPU: no difference from `/`.
+__device__ __forceinline__ double pgx_div_by(double a, double b, double y) {
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
 __device__ __forceinline__ double pgx_reduce_pi(double x, int &qi) {
     const double PI_A = 0x1.921fb54400000p+1, PI_B = 0x1.0b4611a600000p-33, PI_C = 0x1.3198a2e037073p-68;
-    const double q = rint(x * 0x1.45f306dc9c883p-2);
+    // q = rint(x / pi) by the add-and-subtract of 1.5 * 2^52 (the sum has no fraction bits left: it rounds to
+    // the nearest-even integer exactly as rint does, for |x / pi| < 2^51), its parity from the sum's low word --
+    // two full-rate adds where v_rndne_f64 and v_cvt_i32_f64 run at a quarter of the rate
+    const double MAGIC = 0x1.8p+52;
+    const double qm = x * 0x1.45f306dc9c883p-2 + MAGIC;
+    const double q = qm - MAGIC;
     double r = __builtin_fma(-q, PI_A, x);
     r = __builtin_fma(-q, PI_B, r);
     r = __builtin_fma(-q, PI_C, r);
-    qi = (int)q;                                                 // |q| < 2^20 on the fast range
+    qi = __double2loint(qm);                                     // q mod 2^32 (|q| < 2^31): only its parity is used
     return r;
 }
 __device__ __forceinline__ double pgx_sin_poly(double r) {       // sin(r), |r| <= pi/2
@@ -160,13 +180,13 @@ __device__ __forceinline__ double pgx_tanh(double x) {
 }
 
 __device__ __forceinline__ double pgx_sin(double x) {
-    if (!(fabs(x) < 3.0e6)) return sin(x);
+    if (!(fabs(x) < kSinFastRange)) return sin(x);
     int qi;
     const double r = pgx_reduce_pi(x, qi);
     const double v = pgx_sin_poly(r);
     return (qi & 1) ? -v : v;
 }
-// The same routine for callers that guarantee |x| < 3e6: without the fallback branch the code is one basic
+// The same routine for callers that guarantee |x| < kSinFastRange: without the fallback branch the code is one basic
 // block, so the compiler interleaves several evaluations (the oscillators evaluate 16 per thread and tile; with
 // the branch each one ran as a lone dependent chain).  Same bits as pgx_sin on that range.
 __device__ __forceinline__ double pgx_sin_bounded(double x) {
@@ -175,7 +195,7 @@ __device__ __forceinline__ double pgx_sin_bounded(double x) {
     const double v = pgx_sin_poly(r);
     return (qi & 1) ? -v : v;
 }
-__device__ __forceinline__ void pgx_sincos_bounded(double x, double &sn, double &cs) {   // |x| < 3e6 (or NaN)
+__device__ __forceinline__ void pgx_sincos_bounded(double x, double &sn, double &cs) {   // |x| < kSinFastRange (or NaN)
     int qi;
     const double r = pgx_reduce_pi(x, qi);
     const double a = pgx_sin_poly(r), b = pgx_cos_poly(r);
@@ -183,7 +203,7 @@ __device__ __forceinline__ void pgx_sincos_bounded(double x, double &sn, double 
     cs = (qi & 1) ? -b : b;
 }
 __device__ __forceinline__ void pgx_sincos(double x, double &sn, double &cs) {
-    if (!(fabs(x) < 3.0e6)) {
+    if (!(fabs(x) < kSinFastRange)) {
         sn = sin(x);
         cs = cos(x);
         return;

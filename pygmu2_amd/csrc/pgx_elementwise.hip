@@ -117,20 +117,22 @@ __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride,
     const pgx_sine_params p = params[blockIdx.y];
     float *o = out + (int64_t)blockIdx.y * out_stride;
     const bool aligned = is_aligned16(o);
+    const double inv_sr = 1.0 / sr;                              // t = n / sr below: pgx_div_by, same roundings
     int64_t n_elems = n * channels;
     int64_t stride = (int64_t)gridDim.x * kBlock * kVec;
     for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kVec; e < n_elems; e += stride) {
         float v[4];
         if (channels == 1) {
-            // mono: four phases first; while they are all below the fast range of the sine (18 minutes of a
+            // mono: four phases first; while they are all below the fast range of the sine (200 hours of a
             // 440 Hz tone) the four evaluations are one basic block and interleave -- same bits as pgx_sin
             double ph[4];
             bool fast = true;
-#pragma unroll
+            const double n0 = (double)(start + e);               // frame indices are exact in float64: one
+#pragma unroll                                                   // conversion, then exact additions
             for (int j = 0; j < 4; ++j) {
-                const double t = (double)(start + e + j) / sr;
+                const double t = pgx::pgx_div_by(n0 + (double)j, sr, inv_sr);
                 ph[j] = p.phase0 + p.w * t;
-                fast = fast && (fabs(ph[j]) < 3.0e6);
+                fast = fast && (fabs(ph[j]) < pgx::kSinFastRange);
             }
             if (fast) {
 #pragma unroll
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(kBlock) k_sine(float *out, int64_t out_stride,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!have) {
-                double t = (double)(start + f) / sr;
+                double t = pgx::pgx_div_by((double)(start + f), sr, inv_sr);
                 double ph = p.phase0 + p.w * t;
                 cur = (float)(p.amp * pgx::pgx_sin(ph));
                 if (has_gain) cur = cur * post_gain;

@@ -70,6 +70,13 @@ class LoopPE(ProcessingElement):
     def is_pure(self) -> bool:
         return True
 
+    # every output frame is a gather by its absolute index into a region that, under a pure source, is rendered
+    # once: small sequential pulls are served from read-ahead windows
+    _READ_AHEAD_SAFE = True
+
+    def _read_ahead_condition(self) -> bool:
+        return _subtree_pure(self._source)
+
     def channel_count(self) -> int | None:
         return self._source.channel_count()
 

@@ -48,6 +48,13 @@ class WindowPE(ProcessingElement):
     def is_pure(self) -> bool:
         return True
 
+    # max / min of a window do not depend on how the stream is cut into blocks (the float64 sums of mean / RMS are
+    # grouped by 64-frame blocks counted from the request's start: equal only to rounding): read-ahead for those
+    _READ_AHEAD_SAFE = True
+
+    def _read_ahead_condition(self) -> bool:
+        return self._mode in (WindowMode.MAX, WindowMode.MIN)
+
     def channel_count(self) -> int | None:
         return self._source.channel_count()
 

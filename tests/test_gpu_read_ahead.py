@@ -24,10 +24,19 @@ def _pull(pe, requests):
     return out
 
 
-@pytest.mark.parametrize("graph", ["c1", "hello"])
+def _loop():
+    return pg.LoopPE(pg.CropPE(pg.SinePE(440.0), 0, 4410), crossfade_seconds=0.01)
+
+
+def _window_max():
+    return pg.WindowPE(pg.GainPE(pg.SinePE(3.0), pg.SinePE(441.0)), window=0.05)
+
+
+@pytest.mark.parametrize("graph", ["c1", "hello", "loop", "window_max"])
 def test_read_ahead_is_sample_identical(graph):
     pg.set_sample_rate(44100)
-    make = (lambda: pg.GainPE(pg.SinePE(440.0, 1.0, 0.0, channels=2), gain=0.5)) if graph == "c1" else _hello
+    make = {"c1": lambda: pg.GainPE(pg.SinePE(440.0, 1.0, 0.0, channels=2), gain=0.5), "hello": _hello,
+            "loop": _loop, "window_max": _window_max}[graph]
     seq = [(i * 1024, 1024) for i in range(200)]
     seq += [(204800, 17), (204817, 1000), (100, 64), (164, 64), (228, 4096), (8 * 44100 - 100, 512)]
     read_ahead.set_enabled(True)
@@ -48,6 +57,8 @@ def test_read_ahead_skips_stateful_and_index_quirk_graphs():
     assert not read_ahead.eligible(pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707))
     assert not read_ahead.eligible(pg.GainPE(pg.IdentityPE(), 2.0))
     assert not read_ahead.eligible(pg.SinePE(frequency=pg.SinePE(5.0)))
+    assert not read_ahead.eligible(pg.WindowPE(pg.SinePE(440.0), mode=pg.WindowMode.RMS))    # block-grouped sums
+    assert not read_ahead.eligible(pg.LoopPE(pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707), 0, 1000))
     # stateful chain streamed in small blocks still matches one big render within the budget
     a = pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707)
     parts = _pull(a, [(i * 512, 512) for i in range(40)])
