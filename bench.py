@@ -81,8 +81,10 @@ def spawn_ranks(n: int) -> int:
     failed = 0
     try:
         for line in iter(out0.readline, b""):            # rank 0's JSON line (and nothing else) goes to stdout
-            sys.stdout.write(line.decode("utf-8", "replace"))
-            sys.stdout.flush()
+            text = line.decode("utf-8", "replace")
+            dest = sys.stdout if text.lstrip().startswith("{") else sys.stderr     # (a library's banner: stderr)
+            dest.write(text)
+            dest.flush()
         deadline = time.time() + 600
         for p in procs:
             try:
@@ -98,6 +100,9 @@ def spawn_ranks(n: int) -> int:
 
 
 # ----------------------------------------------------------------------------- the ranks' control plane
+RCCL_INIT_TIMEOUT = float(os.environ.get("PGX_BENCH_RCCL_TIMEOUT", "180"))
+
+
 class Dist:
     """World / rank from the launcher's environment.  world > 1: the c10d store the launcher provides
     carries the communicator id (and, in a dry run, the whole report); RCCL carries everything else."""
@@ -110,6 +115,8 @@ class Dist:
         self.dry_run = dry_run
         self.store = None
         self._barriers = 0
+        self.collective = "rccl"             # "store" after a failed communicator build (connect)
+        self.collective_error = None
         if self.enabled:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             from torch.distributed import rendezvous
@@ -117,17 +124,51 @@ class Dist:
 
     def connect(self):
         """After device init: build the RCCL communicator (every rank).  Returns the ranks seen by an
-        all-reduce of ones on it."""
+        all-reduce of ones on it.  If the communicator cannot be built on every rank within RCCL_INIT_TIMEOUT
+        seconds (a rank's error, or peers stuck in the bootstrap) all ranks agree through the store to go on
+        without it: barrier and max-over-ranks then ride on the store, the replica workload is measured as
+        usual and the sharded mixes, which need the collective, are reported as unavailable."""
         if not self.enabled:
             return 1
         if self.dry_run:
             return int(self._store_sum("ranks_seen", 1))
+        import threading
         from pygmu2_amd import comm
-        if self.rank == 0:
-            self.store.set("pgx_comm_id", comm.unique_id())
-        ident = self.store.get("pgx_comm_id")
-        comm.init(self.rank, self.world, bytes(ident))
-        return int(round(comm.reduce_scalar(1.0, "sum")))
+        outcome = {}
+
+        def build():
+            try:
+                if self.rank == 0:
+                    self.store.set("pgx_comm_id", comm.unique_id())
+                ident = self.store.get("pgx_comm_id")
+                comm.init(self.rank, self.world, bytes(ident))
+                outcome["seen"] = int(round(comm.reduce_scalar(1.0, "sum")))
+            except Exception as e:                                  # noqa: BLE001 - reported, then agreed on
+                outcome["error"] = f"{type(e).__name__}: {e}"
+
+        # RCCL greets with a version banner on stdout: stdout carries the one JSON line, so the file descriptor
+        # points at stderr while the communicator is built (nothing else prints meanwhile: the rank waits here)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            t = threading.Thread(target=build, daemon=True)
+            t.start()
+            t.join(RCCL_INIT_TIMEOUT)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        ok = "seen" in outcome and outcome["seen"] == self.world
+        if not ok and "error" not in outcome:
+            outcome["error"] = "timed out" if t.is_alive() else f"saw {outcome.get('seen')} of {self.world} ranks"
+        all_ok = self._store_sum("rccl_ok", 1 if ok else 0) == self.world
+        if all_ok:
+            return outcome["seen"]
+        self.collective = "store"
+        self.collective_error = outcome.get("error", "a peer could not build the communicator")
+        print(f"[bench] rank {self.rank}: RCCL communicator unavailable ({self.collective_error}); "
+              f"barriers go through the store", file=sys.stderr, flush=True)
+        return int(self._store_sum("ranks_seen", 1))
 
     def _store_sum(self, key, value):
         self.store.add(key, int(value))
@@ -136,13 +177,19 @@ class Dist:
         while int(self.store.add(key + "_n", 0)) < self.world:
             if time.time() - t0 > 300:
                 raise RuntimeError(f"rank {self.rank}: peers never arrived at {key}")
-            time.sleep(0.002)
+            time.sleep(0.0005)
         return int(self.store.add(key, 0))
+
+    def _store_max(self, key, value):
+        """max of one float over the ranks through the store (microsecond resolution)."""
+        self.store.set(f"{key}_r{self.rank}", repr(float(value)))
+        self._store_sum(key + "_in", 0)
+        return max(float(self.store.get(f"{key}_r{r}").decode()) for r in range(self.world))
 
     def barrier(self):
         if not self.enabled:
             return
-        if self.dry_run:
+        if self.dry_run or self.collective == "store":
             self._barriers += 1
             self._store_sum(f"barrier{self._barriers}", 0)
             return
@@ -152,6 +199,9 @@ class Dist:
     def max_over_ranks(self, value: float) -> float:
         if not self.enabled or self.dry_run:
             return value
+        if self.collective == "store":
+            self._barriers += 1
+            return self._store_max(f"max{self._barriers}", value)
         from pygmu2_amd import comm
         return comm.reduce_scalar(value, "max")
 
@@ -161,7 +211,8 @@ class Dist:
         if not self.dry_run:
             from pygmu2_amd import comm
             self.barrier()
-            comm.destroy()
+            if self.collective == "rccl":
+                comm.destroy()
         # rank 0 may be hosting the store (bench.py's own spawner): it leaves last
         if self.rank != 0:
             self.store.add("pgx_done", 1)
@@ -721,6 +772,14 @@ def main():
     from pygmu2_amd import device
     device.ensure_init()
     ranks_seen = dist.connect()
+    if dist.enabled and dist.collective != "rccl" and args.workload in SHARDED:
+        if dist.rank == 0:
+            print(json.dumps({"metric": "Msamples/s rendered (benchmark_pes.py metric: output frames / wall second)",
+                              "value": None, "unit": "Msamples/s", "n_gpus": dist.world, "n_ranks_seen": ranks_seen,
+                              "error": f"workload {args.workload} needs the RCCL communicator: "
+                                       f"{dist.collective_error}"}), flush=True)
+        dist.shutdown()
+        sys.exit(1)
 
     n_gpus = max(1, dist.world)
     with_cpu = not args.no_cpu and n_gpus == 1
@@ -765,7 +824,12 @@ def main():
         if "cpu_baseline" in extra_primary:
             result["cpu_baseline"] = extra_primary["cpu_baseline"]
 
-    if not sharded and not args.no_extras:
+    if dist.enabled:
+        result["collective"] = dist.collective
+    if not sharded and not args.no_extras and dist.enabled and dist.collective != "rccl":
+        note = {"error": f"no RCCL communicator ({dist.collective_error}): the sharded mixes were not run"}
+        result["voice_mix"], result["supersaw_mix"] = dict(note), dict(note)
+    elif not sharded and not args.no_extras:
         # collectives: every rank takes part.  The sharded mixes ride along in the default line.
         result["voice_mix"] = mix_entry(pg, dist, "c5", 10, 2, with_cpu and dist.rank == 0)
         result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 6, 2, with_cpu and dist.rank == 0)

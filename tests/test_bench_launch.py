@@ -47,3 +47,23 @@ def test_parent_reports_a_failed_rank():
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"], timeout=300)
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_device_print_one_line_with_or_without_the_communicator():
+    """Two real ranks.  On a box with one GPU both land on device 0 and RCCL refuses the communicator: the ranks
+    must agree to carry on with store barriers, measure the replica workload and say that the sharded mixes were
+    not run; on a box with two GPUs the communicator exists.  Either way stdout is exactly one JSON line (RCCL's
+    greeting banner goes to stderr)."""
+    p = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu"], env={"PGX_BENCH_RCCL_TIMEOUT": "60"},
+             timeout=400)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["value"] > 0
+    assert d["collective"] in ("rccl", "store")
+    if d["collective"] == "store":
+        assert "error" in d["voice_mix"] and "error" in d["supersaw_mix"]
+    else:
+        assert d["voice_mix"]["n_ranks"] == 2 and d["voice_mix"]["value"] > 0
