@@ -36,7 +36,8 @@ from .snippet import Snippet
 from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
-PREFETCH_LADDER_INPUT = True  # _LadderNode: next block's oscillators beside this block's ladder
+PREFETCH_LADDER_INPUT = True
+PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
@@ -120,6 +121,11 @@ class _BlitSawNode(_Node):
 
 
 class _SuperSawNode(_Node):
+    """Bank of SuperSawPEs.  From FUSED_SUPERSAW_MIN instances on: one launch, voices summed on chip.  Below
+    (a rank's share of a sharded mix): the oscillators of all instances in one launch (`_voices`), then the
+    ordered voice sum.  When the node feeds the bank's mix directly VoiceBank pipelines the two (see
+    VoiceBank._supersaw_pipelined): `ahead` then holds the oscillator samples of the block after the last one."""
+
     def __init__(self, pes):
         super().__init__(pes, {})
         self.nv = len(pes[0]._oscillators)
@@ -129,33 +135,70 @@ class _SuperSawNode(_Node):
         self.amp = DeviceBuffer.from_host(np.array([float(pe._amplitude) for pe in pes], dtype=np.float64))
         self.ch = pes[0]._channels
         self.last_end = None
+        self.ahead = None            # (start, n, voices buffer, (state copy, last_end))
+
+    def fused(self) -> bool:
+        return self.k >= FUSED_SUPERSAW_MIN and self.nv <= 16
+
+    def _forget_ahead(self, restore: bool) -> None:
+        ahead, self.ahead = self.ahead, None
+        if ahead is not None and restore:
+            saved, last_end = ahead[3]
+            check(lib().pgx_memcpy_d2d(self.state.ptr, saved.ptr, saved.nbytes), "pgx_memcpy_d2d")
+            self.last_end = last_end
 
     def reset(self):
+        self._forget_ahead(restore=False)
         self.last_end = None
 
     def channels(self):
         return self.ch
 
-    def render(self, start, n):
-        L = lib()
+    def _voices(self, start, n):
+        """[instances * voices][n] float32 oscillator samples, on the current stream."""
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
-        if self.k >= FUSED_SUPERSAW_MIN and self.nv <= 16:
+        voices = DeviceBuffer((self.k * self.nv, n), np.float32)
+        ws = blitsaw_workspace(self, self.k * self.nv, n, False)
+        check(lib().pgx_blitsaw(voices.ptr, n, self.k * self.nv, n, 1, self.sr, self.params.ptr,
+                                None, 0, None, 0, None, 0, self.state.ptr, ptr(ws)), "pgx_blitsaw")
+        self.last_end = start + n
+        return voices
+
+    def take_voices(self, start, n):
+        """The oscillator samples of (start, n): the ones rendered ahead if they are these, else rendered now
+        (after the states went back to where the caller's last block left them)."""
+        if self.ahead is not None:
+            if self.ahead[0] == start and self.ahead[1] == n:
+                voices, self.ahead = self.ahead[2], None
+                return voices
+            self._forget_ahead(restore=True)
+        return self._voices(start, n)
+
+    def render_ahead(self, start, n) -> None:
+        saved = DeviceBuffer(self.state.shape, self.state.dtype)
+        check(lib().pgx_memcpy_d2d(saved.ptr, self.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
+        snapshot = (saved, self.last_end)
+        self.ahead = (start, n, self._voices(start, n), snapshot)
+
+    def sum_voices(self, voices, n):
+        out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        check(lib().pgx_supersaw_sum(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, voices.ptr,
+                                     self.amp.ptr, None, 0), "pgx_supersaw_sum")
+        return out
+
+    def render(self, start, n):
+        L = lib()
+        if self.fused():
             # enough instances to fill the chip with one wave per oscillator: voices summed on chip
+            if self.last_end is None or start != self.last_end:
+                self.state.upload(self.init_state)
             out = DeviceBuffer((self.k, n, self.ch), np.float32)
             check(L.pgx_supersaw_bank(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
                                       self.params.ptr, self.state.ptr, self.amp.ptr), "pgx_supersaw_bank")
             self.last_end = start + n
             return out
-        voices = DeviceBuffer((self.k * self.nv, n), np.float32)
-        ws = blitsaw_workspace(self, self.k * self.nv, n, False)
-        check(L.pgx_blitsaw(voices.ptr, n, self.k * self.nv, n, 1, self.sr, self.params.ptr,
-                            None, 0, None, 0, None, 0, self.state.ptr, ptr(ws)), "pgx_blitsaw")
-        out = DeviceBuffer((self.k, n, self.ch), np.float32)
-        check(L.pgx_supersaw_sum(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, voices.ptr,
-                                 self.amp.ptr, None, 0), "pgx_supersaw_sum")
-        self.last_end = start + n
-        return out
+        return self.sum_voices(self.take_voices(start, n), n)
 
 
 class _BiquadNode(_Node):
@@ -469,6 +512,9 @@ class VoiceBank:
 
     def render_mix(self, start: int, duration: int) -> Snippet:
         root = self.root
+        if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and not root.fused() and duration >= 4096
+                and not lib().pgx_stream_is_forked()):
+            return self._supersaw_pipelined(start, duration)
         if isinstance(root, _GainNode) and root.gains is None:
             # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix.  The gain
             # sub-graph (envelopes: few, latency-bound waves) and the signal sub-graph (oscillators and
@@ -502,6 +548,33 @@ class VoiceBank:
         check(lib().pgx_mix_batch(out.ptr, stacked.ptr, duration * ch, self.k, duration * ch),
               "pgx_mix_batch")
         return Snippet(start, out)
+
+
+def _supersaw_pipelined(self, start: int, n: int) -> Snippet:
+    """A small bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8).  The
+    oscillators are the long pole (69 of 94 us) and depend on nothing but time and two carried numbers each, so they
+    own the main stream, one block ahead: block k's voice sum and mix run on the side stream beside block k+1's
+    oscillators.  Nothing on the main stream ever waits for the side stream to catch up (the join at the end is
+    enqueued behind the oscillators, which outlast sum + mix): a cross-stream wait that has to wake a stalled
+    queue costs ~16 us on this part, a whole launch.  A pull that is not the next block copies the oscillator
+    states back (take_voices).  What follows on the library stream -- the all-reduce of this block, a read-back --
+    runs behind the next block's oscillators: one block of latency, no throughput."""
+    root, L = self.root, lib()
+    voices = root.take_voices(start, n)
+    check(L.pgx_stream_fork(), "pgx_stream_fork")                  # side stream: behind this block's oscillators
+    try:
+        stacked = root.sum_voices(voices, n)
+        ch = stacked.shape[2]
+        out = DeviceBuffer((n, ch), np.float32)
+        check(L.pgx_mix_batch(out.ptr, stacked.ptr, n * ch, self.k, n * ch), "pgx_mix_batch")
+        check(L.pgx_stream_select(0), "pgx_stream_select")
+        root.render_ahead(start + n, n)                            # main stream
+    finally:
+        check(L.pgx_stream_join(), "pgx_stream_join")
+    return Snippet(start, out)
+
+
+VoiceBank._supersaw_pipelined = _supersaw_pipelined
 
 
 def try_build_bank(inputs):
