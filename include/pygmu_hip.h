@@ -336,7 +336,9 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
                 const float *amp, int64_t amp_stride,
                 const float *m, int64_t m_stride,
                 double *state /* [batch][2] */,
-                void *workspace /* pgx_blitsaw_workspace_bytes, or NULL: one workgroup per instance */);
+                void *workspace /* pgx_blitsaw_workspace_bytes, or NULL: one workgroup per instance */,
+                double *state_backup /* NULL, or [batch][2]: receives the state on entry -- the snapshot of a caller
+                                        that renders a block ahead of its stream and may have to take it back */);
 /* A long stream of a few scalar-parameter oscillators is rendered by several workgroups per oscillator
  * (two passes that replay the single workgroup's carry chains: same bits).  0 = not applicable. */
 size_t pgx_blitsaw_workspace_bytes(int batch, int64_t n, int streams /* any of freq/amp/m is a stream */);

@@ -99,7 +99,7 @@ class BlitSawPE(ProcessingElement):
         ws = blitsaw_workspace(self, 1, duration, bool(f_buf or a_buf or m_buf))
         check(L.pgx_blitsaw(out.ptr, 0, 1, duration, self._channels, float(self.sample_rate),
                             self._params.ptr, ptr(f_buf), 0, ptr(a_buf), 0, ptr(m_buf), 0,
-                            self._state.ptr, ptr(ws)), "pgx_blitsaw")
+                            self._state.ptr, ptr(ws), None), "pgx_blitsaw")
         self._last_render_end = start + duration
         return Snippet(start, out)
 

@@ -971,7 +971,7 @@ template <bool STREAMS, int NW, int SEG>
 __global__ void __launch_bounds__(NW * 64)
 k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, const pgx_blitsaw_params *params,
           const float *freq, int64_t freq_stride, const float *amp, int64_t amp_stride, const float *mstream,
-          int64_t m_stride, double *state, double *ws, int64_t ws_stride, int tiles_per_seg) {
+          int64_t m_stride, double *state, double *ws, int64_t ws_stride, int tiles_per_seg, double *state_backup) {
     static_assert(!(STREAMS && SEG), "segments need scalar parameters");
     __shared__ SawShared sh;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -993,6 +993,10 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
     if (SEG == 1 && seg == 0 && tid == 0) {                       // the apply pass must not read what it overwrites
         wsi[0] = phase0;
         wsi[1] = carry_y;
+    }
+    if (SEG != 2 && state_backup != nullptr && seg == 0 && tid == 0) {   // the caller's snapshot of a speculative render
+        state_backup[inst * 2 + 0] = phase0;
+        state_backup[inst * 2 + 1] = carry_y;
     }
 
     // powers of leak for the affine scan
@@ -2671,7 +2675,8 @@ size_t pgx_blitsaw_workspace_bytes(int batch, int64_t n, int streams) {
 
 int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channels, double sample_rate,
                 const pgx_blitsaw_params *params, const float *freq, int64_t freq_stride, const float *amp,
-                int64_t amp_stride, const float *m, int64_t m_stride, double *state, void *workspace) {
+                int64_t amp_stride, const float *m, int64_t m_stride, double *state, void *workspace,
+                double *state_backup) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && params && state && channels >= 1 && sample_rate > 0, "pgx_blitsaw: bad argument");
@@ -2684,7 +2689,7 @@ int pgx_blitsaw(float *out, int64_t out_stride, int batch, int64_t n, int channe
 #define PGX_SAW_LAUNCH(S, NWAVES, SEG, GRID)                                                                   \
     hipLaunchKernelGGL((k_blitsaw<S, NWAVES, SEG>), GRID, dim3(NWAVES * 64), 0, pgx::stream(), out, out_stride, \
                        n, channels, sample_rate, params, freq, freq_stride, amp, amp_stride, m, m_stride, state,  \
-                       (double *)workspace, ws_stride, plan.tiles_per_seg)
+                       (double *)workspace, ws_stride, plan.tiles_per_seg, state_backup)
     const int64_t ws_stride = 2 + plan.tiles * (kSawWideWaves + 1) + (int64_t)plan.nseg;
     if (workspace && plan.nseg > 1) {        // long streams of a few oscillators: several workgroups each
         PGX_SAW_LAUNCH(false, kSawWideWaves, 1, dim3(batch, plan.nseg));

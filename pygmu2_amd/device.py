@@ -106,7 +106,7 @@ _SIGNATURES = [
     ("pgx_envelope_scratch_bytes", _Z, [_L, _I]),
     ("pgx_envelope", _I, [_P, _P, _L, _I, _D, _D, _I, _I, _L, _P, _P]),
     ("pgx_transform", _I, [_P, _P, _L, _P, _I]),
-    ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P, _P]),
+    ("pgx_blitsaw", _I, [_P, _L, _I, _L, _I, _D, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P]),
     ("pgx_blitsaw_workspace_bytes", _Z, [_I, _L, _I]),
     ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
     ("pgx_blitsaw_biquad_bank", _I, [_P, _L, _I, _L, _D, _P, _P, _P, _P]),

@@ -168,7 +168,7 @@ class SuperSawPE(ProcessingElement):
         voices = DeviceBuffer((nv, duration), np.float32)
         ws = blitsaw_workspace(self, nv, duration, f_buf is not None)
         check(L.pgx_blitsaw(voices.ptr, duration, nv, duration, 1, sr, self._params.ptr,
-                            ptr(f_buf), f_stride, None, 0, None, 0, self._state.ptr, ptr(ws)), "pgx_blitsaw")
+                            ptr(f_buf), f_stride, None, 0, None, 0, self._state.ptr, ptr(ws), None), "pgx_blitsaw")
 
         a_s, a_buf = self._control_stream(self._amplitude, start, duration)
         if self._amp_scalar is None:

@@ -115,7 +115,7 @@ class _BlitSawNode(_Node):
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
         ws = blitsaw_workspace(self, self.k, n, False)
         check(lib().pgx_blitsaw(out.ptr, n * self.ch, self.k, n, self.ch, self.sr, self.params.ptr,
-                                None, 0, None, 0, None, 0, self.state.ptr, ptr(ws)), "pgx_blitsaw")
+                                None, 0, None, 0, None, 0, self.state.ptr, ptr(ws), None), "pgx_blitsaw")
         self.last_end = start + n
         return out
 
@@ -154,14 +154,15 @@ class _SuperSawNode(_Node):
     def channels(self):
         return self.ch
 
-    def _voices(self, start, n):
-        """[instances * voices][n] float32 oscillator samples, on the current stream."""
+    def _voices(self, start, n, backup=None):
+        """[instances * voices][n] float32 oscillator samples, on the current stream.  backup: a buffer that
+        receives the states on entry (written by the oscillator kernel itself: no extra launch)."""
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
         voices = DeviceBuffer((self.k * self.nv, n), np.float32)
         ws = blitsaw_workspace(self, self.k * self.nv, n, False)
         check(lib().pgx_blitsaw(voices.ptr, n, self.k * self.nv, n, 1, self.sr, self.params.ptr,
-                                None, 0, None, 0, None, 0, self.state.ptr, ptr(ws)), "pgx_blitsaw")
+                                None, 0, None, 0, None, 0, self.state.ptr, ptr(ws), ptr(backup)), "pgx_blitsaw")
         self.last_end = start + n
         return voices
 
@@ -177,9 +178,8 @@ class _SuperSawNode(_Node):
 
     def render_ahead(self, start, n) -> None:
         saved = DeviceBuffer(self.state.shape, self.state.dtype)
-        check(lib().pgx_memcpy_d2d(saved.ptr, self.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
-        snapshot = (saved, self.last_end)
-        self.ahead = (start, n, self._voices(start, n), snapshot)
+        last_end = self.last_end
+        self.ahead = (start, n, self._voices(start, n, backup=saved), (saved, last_end))
 
     def sum_voices(self, voices, n):
         out = DeviceBuffer((self.k, n, self.ch), np.float32)

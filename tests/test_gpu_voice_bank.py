@@ -134,10 +134,10 @@ def test_wide_blitsaw_workgroups_reproduce_the_bank_kernel_bit_for_bit():
     for n in blocks:
         bank = device.DeviceBuffer((len(freqs), n, 1), np.float32)
         device.check(lib.pgx_blitsaw(bank.ptr, n, len(freqs), n, 1, sr, params.ptr, None, 0, None, 0, None, 0,
-                                     state_bank.ptr, None))
+                                     state_bank.ptr, None, None))
         one = device.DeviceBuffer((1, n, 1), np.float32)
         device.check(lib.pgx_blitsaw(one.ptr, n, 1, n, 1, sr, one_params.ptr, None, 0, None, 0, None, 0,
-                                     state_one.ptr, None))
+                                     state_one.ptr, None, None))
         assert np.array_equal(bank.to_host()[pick], one.to_host()[0]), n
         # several workgroups per oscillator (two passes over a workspace): the same chains replayed
         need = lib.pgx_blitsaw_workspace_bytes(3, n, 0)
@@ -145,7 +145,7 @@ def test_wide_blitsaw_workgroups_reproduce_the_bank_kernel_bit_for_bit():
         ws = device.DeviceBuffer((max(need, 8),), np.uint8)
         seg = device.DeviceBuffer((3, n, 1), np.float32)
         device.check(lib.pgx_blitsaw(seg.ptr, n, 3, n, 1, sr, seg_params.ptr, None, 0, None, 0, None, 0,
-                                     state_seg.ptr, ws.ptr if need else None))
+                                     state_seg.ptr, ws.ptr if need else None, None))
         assert np.array_equal(seg.to_host()[1], one.to_host()[0]), n
         assert np.array_equal(seg.to_host()[0], bank.to_host()[pick - 1]), n
         assert np.array_equal(seg.to_host()[2], bank.to_host()[pick + 1]), n
