@@ -33,6 +33,7 @@ constexpr int kIdle = 0, kAttack = 1, kDecay = 2, kSustain = 3, kRelease = 4;
 constexpr double kTwo52 = 4503599627370496.0;        // 2^52
 constexpr double kTwo53 = 9007199254740992.0;        // 2^53
 constexpr int kGroupChunks = 8;                       // fast path granularity: 8 x 64 samples
+constexpr int kParWaves = 8;                          // k_adsr_walk_par: stretches of a block walked at once
 constexpr int kWideWalkBatch = 128;                   // up to here an envelope gets a whole workgroup (see k_adsr_walk)
 
 // ------------------------------------------------------------------------------------------------
@@ -323,7 +324,12 @@ __device__ __forceinline__ int adsr_run_length(const AdsrCtx &c, bool triggered,
     }
     const double a = (c.dir > 0) ? (c.lim - c.env) : (c.env - c.lim);      // exact, >= 0
     const double b = fabs(c.dq);
-    double q = floor(a / b);
+    // the quotient only has to be within one of the truth below `cap` (< 2^31): a Newton-refined reciprocal
+    // (relative error ~2^-50) instead of the IEEE division sequence on this dependent chain
+    double y = __builtin_amdgcn_rcp(b);
+    y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+    double q = floor(a * y);
+    if (!(q < 4.0e9)) return cap;                                          // far beyond any cap
     const double r = __builtin_fma(-q, b, a);                              // exact: |r| < 2b
     if (r < 0.0) q -= 1.0;
     else if (r >= b) q += 1.0;
@@ -457,6 +463,211 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_adsr_walk_par: several waves per gated envelope, each walking its own stretch of the block.
+//
+// Between two gate edges the level does not wander for ever: an attack reaches 1, decays to the sustain
+// level and STAYS there (exactly `sustain_level`: the clamp assigns it), a release reaches exactly 0 and
+// idles.  So if the stretch before an edge is at least as long as that takes from ANY level -- a bound of
+// span / |slope| + 8 steps per phase, far above what the rounding of the running sum can add -- the state
+// the edge finds is known without walking there: (sustain, S) after an attack edge, (idle, 0) after a
+// release edge.  Such an edge is an independent start.  Every wave of the workgroup lists the block's edges
+// the same way (one memory round trip: lane l reads the masks of the 512-sample groups l and l + 64), picks
+// the independent starts, and wave j walks from start j to start j + 1 exactly as k_adsr_walk does (same
+// run arithmetic, same literal steps): the samples are the sequential walk's, bit for bit, whatever the
+// partition.  Edges that are not independent starts stay inside the stretch of the wave before them.  C5's
+// envelopes (2 Hz gate, 10 / 100 / 200 ms) have four to five independent starts per 48 000-frame block.
+// A group holding more than one edge (a gate faster than ~90 Hz) sends the whole envelope down the
+// sequential walk in wave 0 -- k_adsr_walk's edge search, masks fetched from memory.
+// ------------------------------------------------------------------------------------------------
+constexpr long long kNeverSettles = 1ll << 40;
+constexpr int kParMaxGroups = 128;                      // 65 536 frames
+
+__device__ __forceinline__ long long adsr_settle_steps(double span, double rate) {
+    if (!(rate > 0.0) || !(span >= 0.0)) return kNeverSettles;
+    const double q = span / rate;
+    if (!(q < 1e12)) return kNeverSettles;
+    return (long long)q + 8;
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
+                const pgx_adsr_params *params, const unsigned long long *masks,
+                const unsigned long long *group_bits, const float *last_gate, double *state) {
+    __shared__ int e_pos[WAVES][kParMaxGroups + 2];
+    __shared__ unsigned char e_att[WAVES][kParMaxGroups + 2];
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_s_setprio(3);
+    const int j = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int inst = blockIdx.x;
+    const pgx_adsr_params p = params[inst];
+    float *o = out + (int64_t)inst * out_stride;
+    double *st = state + (int64_t)inst * 3;
+    const unsigned long long *mk = masks + (int64_t)inst * nchunks * 2;
+    const unsigned long long *gb = group_bits + (int64_t)inst * gwords;
+    const int s0 = (int)st[0];
+    const double env0 = st[1];
+    __syncthreads();                         // every wave has read the carried state before one overwrites it
+
+    const int n32 = (int)n, nch32 = (int)nchunks, gw32 = (int)gwords;
+    const int ngroups = (nch32 + kGroupChunks - 1) / kGroupChunks;
+
+    // ---- the block's edges, one round trip ----
+    int pos_e[2] = {0, 0};
+    bool has_e[2] = {false, false}, att_e[2] = {false, false};
+    bool crowded = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int g = lane + 64 * h;
+        if (g < ngroups && ((gb[g >> 6] >> (g & 63)) & 1ull)) {
+            int count = 0;
+#pragma unroll
+            for (int c = 0; c < kGroupChunks; ++c) {
+                const int chunk = g * kGroupChunks + c;
+                if (chunk < nch32) {
+                    const unsigned long long am = mk[(int64_t)chunk * 2], rm = mk[(int64_t)chunk * 2 + 1];
+                    const unsigned long long m = am | rm;
+                    if (m) {
+                        count += __popcll(m);
+                        const int bit = __ffsll((long long)m) - 1;
+                        pos_e[h] = chunk * 64 + bit;
+                        att_e[h] = ((am >> bit) & 1ull) != 0ull;
+                    }
+                }
+            }
+            has_e[h] = count == 1 && pos_e[h] < n32;
+            crowded = crowded || count > 1;
+        }
+    }
+    const bool sequential = __ballot(crowded) != 0ull;
+    const unsigned long long m0 = __ballot(has_e[0]), m1 = __ballot(has_e[1]);
+    const int ne0 = __popcll(m0), ne = ne0 + __popcll(m1);
+    int *my_pos = e_pos[j];
+    unsigned char *my_att = e_att[j];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (has_e[0]) { const int k = __popcll(m0 & below); my_pos[k] = pos_e[0]; my_att[k] = att_e[0] ? 1 : 0; }
+    if (has_e[1]) { const int k = ne0 + __popcll(m1 & below); my_pos[k] = pos_e[1]; my_att[k] = att_e[1] ? 1 : 0; }
+    if (lane == 0) { my_pos[ne] = n32; my_att[ne] = 0; }
+    __builtin_amdgcn_s_waitcnt(0);           // (wave-private LDS rows: the wave reads back what it wrote)
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- independent starts: which stretch is this wave's ----
+    // steps until the level is pinned (sustain after an attack edge, idle after a release edge), from the level the
+    // stretch starts at when that is known -- the carried level, S after a settled attack, 0 after a settled
+    // release -- else from the worst case
+    const double S = p.sustain_level;
+    const bool tame = S >= 0.0 && S <= 1.0;
+    const long long bD = tame ? adsr_settle_steps(1.0 - S, -p.decay_dvdt) : kNeverSettles;
+    auto attack_from = [&](double level) -> long long {
+        const long long a = adsr_settle_steps(level < 1.0 ? 1.0 - level : 0.0, p.attack_dvdt);
+        return (a < kNeverSettles && bD < kNeverSettles) ? a + bD + 4 : kNeverSettles;
+    };
+    auto release_from = [&](double level) -> long long { return adsr_settle_steps(level, -p.release_dvdt) + 2; };
+    const double top = S > 1.0 ? S : 1.0;                 // no level ever exceeds it
+    int seg_start = 0, seg_end = n32, first_edge = 0;
+    AdsrCtx c;
+    c.s = s0;
+    c.env = env0;
+    c.ends_at = 0;
+    bool mine = j == 0;
+    if (sequential) {
+        if (j != 0) return;
+    } else {
+        const bool sane0 = env0 >= 0.0 && env0 <= top;
+        bool prev_up = s0 == kAttack || s0 == kDecay || s0 == kSustain;
+        long long need = !sane0 ? kNeverSettles
+                         : s0 == kAttack ? attack_from(env0)
+                         : s0 == kDecay ? (tame ? adsr_settle_steps(env0 > S ? env0 - S : 0.0, -p.decay_dvdt) + 2 : kNeverSettles)
+                         : s0 == kRelease ? release_from(env0) : 2;
+        int prev_pos = 0, starts = 1;
+        for (int k = 0; k < ne; ++k) {
+            const int pos = __builtin_amdgcn_readfirstlane(my_pos[k]);
+            const bool att = __builtin_amdgcn_readfirstlane((int)my_att[k]) != 0;
+            const bool settled = (long long)(pos - prev_pos) >= need;
+            if (settled && starts < WAVES) {
+                if (starts == j) {
+                    mine = true;
+                    seg_start = pos;
+                    first_edge = k;
+                    c.s = prev_up ? kSustain : kIdle;
+                    c.env = prev_up ? S : 0.0;
+                } else if (starts == j + 1) {
+                    seg_end = pos;
+                }
+                ++starts;
+            }
+            // the level this edge starts from: pinned if the stretch before it settled, else anything up to `top`
+            const double from = settled ? (prev_up ? S : 0.0) : (att ? 0.0 : top);
+            prev_pos = pos;
+            prev_up = att;
+            need = att ? attack_from(from) : release_from(from);
+        }
+        if (!mine) return;
+    }
+    c.have = false;
+    c.dir = 0;
+    c.dq = 0.0;
+    c.lim = 0.0;
+
+    // ---- the walk of [seg_start, seg_end): k_adsr_walk's loop ----
+    bool edge_attack = false;
+    int next_k = first_edge;                 // list mode: index of the next edge at or after the position
+    int next_edge;
+    if (sequential) {
+        next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, 0, edge_attack, lane);
+    } else {
+        next_edge = __builtin_amdgcn_readfirstlane(my_pos[next_k]);
+        edge_attack = __builtin_amdgcn_readfirstlane((int)my_att[next_k]) != 0;
+        if (next_edge > seg_end) next_edge = seg_end;
+    }
+    int pos = seg_start;
+    while (pos < seg_end) {
+        if (pos == next_edge) {                                   // gate edge on this sample
+            c.s = edge_attack ? kAttack : kRelease;
+            c.have = false;
+            if (sequential) {
+                next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, pos + 1, edge_attack, lane);
+            } else {
+                ++next_k;
+                next_edge = __builtin_amdgcn_readfirstlane(my_pos[next_k]);      // my_pos[ne] = n
+                edge_attack = __builtin_amdgcn_readfirstlane((int)my_att[next_k]) != 0;
+                if (next_edge > seg_end) next_edge = seg_end;
+            }
+        }
+        const long long now = (long long)start + pos;
+        if (!c.have) c.have = adsr_derive(c, p, false, now);
+        if (c.have) {
+            const int room = next_edge - pos;                     // >= 1
+            const int cnt = adsr_run_length(c, false, now, room + 1);
+            const int take = cnt < room ? cnt : room;
+            const double env = c.env, dq = c.dq;
+            float *dst = o + pos;
+            for (int t = lane; t < take; t += 64) dst[t] = (float)(env + (double)t * dq);
+            c.env = env + (double)take * dq;
+            pos += take;
+            if (cnt <= room) {
+                if (pos < seg_end && pos != next_edge) {
+                    if (lane == 0) o[pos] = (float)c.env;
+                    adsr_step(c, p, false, (long long)start + pos);
+                    pos += 1;
+                } else {
+                    c.have = false;
+                }
+            }
+            continue;
+        }
+        if (lane == 0) o[pos] = (float)c.env;                      // literal step for one sample
+        adsr_step(c, p, false, now);
+        pos += 1;
+    }
+    if (seg_end == n32 && lane == 0) {                            // the wave that walked to the block's end
+        st[0] = (double)c.s;
+        st[1] = c.env;
+        st[2] = (double)last_gate[inst];
+    }
+}
+
 struct AdsrWs {
     unsigned long long *masks;
     unsigned long long *group_bits;
@@ -501,7 +712,16 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
         int rc = pgx_stream_fork();
         if (rc != PGX_OK) return rc;
     }
-    if (batch <= kWideWalkBatch)
+    static const bool par_on = !(getenv("PGX_ADSR_PAR") && atoi(getenv("PGX_ADSR_PAR")) == 0);
+    // (a bank that fills the chip with one wave per envelope gains nothing from eight: 512 envelopes 0.187 -> 0.196 ms
+    // per C5 block; a rank's 64: walk 100 -> 60 us)
+    static const int par_max_batch = getenv("PGX_ADSR_PAR_MAX_BATCH") ? atoi(getenv("PGX_ADSR_PAR_MAX_BATCH")) : kWideWalkBatch;
+    if (MODE != 1 && par_on && batch <= par_max_batch && pgx::ceil_div(w.nchunks, kGroupChunks) <= kParMaxGroups)
+        hipLaunchKernelGGL(k_adsr_walk_par<kParWaves>, dim3(batch), dim3(kParWaves * 64), 0, pgx::stream(), out,
+                           out_stride, batch, start, n, w.nchunks, w.gwords, params,
+                           (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
+                           (const float *)w.last_gate, state);
+    else if (batch <= kWideWalkBatch)
         hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 4>), dim3(batch), dim3(256), 0, pgx::stream(), out, out_stride,
                            batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
                            (const unsigned long long *)w.group_bits, (const float *)w.last_gate, state);

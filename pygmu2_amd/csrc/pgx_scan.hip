@@ -1500,7 +1500,8 @@ struct SawPlan {
 SawPlan saw_plan(int batch, int64_t n, bool streams) {
     constexpr int64_t tile = kSawWideWaves * 64 * kSawT;
     SawPlan p{1, 0, (n + tile - 1) / tile};
-    if (streams || batch >= 128 || p.tiles < 3 || p.tiles > 65536) return p;
+    static const int seg_max_batch = getenv("PGX_SAW_SEG_MAX_BATCH") ? atoi(getenv("PGX_SAW_SEG_MAX_BATCH")) : 128;
+    if (streams || batch >= seg_max_batch || p.tiles < 3 || p.tiles > 65536) return p;
     p.tiles_per_seg = (int)((p.tiles + 255) / 256);
     p.nseg = (int)((p.tiles + p.tiles_per_seg - 1) / p.tiles_per_seg);
     return p;

@@ -56,14 +56,38 @@ def _triggers(rng, k, n):
     return t
 
 
-@pytest.mark.parametrize("triggered", [False, True], ids=["gated", "triggered"])
-def test_adsr_batch_bit_exact_random(triggered):
+def _gates_sparse(rng, k, n):
+    """Gates that stay put for hundreds to tens of thousands of samples: stretches long enough for the envelope to
+    settle (independent starts of k_adsr_walk_par) next to ones that are not, a few crowded spots, odd levels."""
+    g = np.zeros((k, n), np.float32)
+    for i in range(k):
+        pos, level = 0, float(rng.integers(0, 2))
+        top = [900, 5000, 14000, 30000][rng.integers(0, 4)]
+        while pos < n:
+            run = int(rng.integers(1, 30)) if rng.random() < 0.04 else int(rng.integers(200, top))
+            g[i, pos:pos + run] = level
+            pos += run
+            level = 1.0 - level if rng.random() < 0.95 else [0.5, 2.0, -1.0][rng.integers(0, 3)]
+    return g
+
+
+@pytest.mark.parametrize("case", ["gated", "triggered", "gated_small_bank_sparse_gates"])
+def test_adsr_batch_bit_exact_random(case):
     lib = device.ensure_init()
+    triggered = case == "triggered"
     rng = np.random.default_rng(1234 + int(triggered))
-    k, n = 192, 20000
-    rec = _params(rng, k, triggered)
-    ctl = _triggers(rng, k, n) if triggered else _gates(rng, k, n)
-    blocks = [1, 63, 64, 65, 1000, 4097, 129, 7000]
+    if case == "gated_small_bank_sparse_gates":
+        # up to 128 envelopes and 65 536 frames a gated envelope is walked by eight waves from its independent starts
+        rng = np.random.default_rng(99)
+        k, n = 96, 150000
+        rec = _params(rng, k, False)
+        ctl = _gates_sparse(rng, k, n)
+        blocks = [48000, 48000, 1, 4097, 30000, 65536 - 48000]
+    else:
+        k, n = 192, 20000
+        rec = _params(rng, k, triggered)
+        ctl = _triggers(rng, k, n) if triggered else _gates(rng, k, n)
+        blocks = [1, 63, 64, 65, 1000, 4097, 129, 7000]
     blocks.append(n - sum(blocks))
     assert blocks[-1] > 0
 
