@@ -692,7 +692,7 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
                 int64_t n, const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
                 void *workspace, bool detach_walk = false) {
     AdsrWs w = adsr_ws(workspace, batch, n);
-    PGX_HIP(hipMemsetAsync(w.group_bits, 0, w.bits_bytes, pgx::stream()));
+    if (int rc = pgx_memset(w.group_bits, 0, w.bits_bytes)) return rc;
     if (MODE == 2) {
         const int64_t edge_waves = (int64_t)batch * pgx::ceil_div(w.nchunks, 64);
         hipLaunchKernelGGL(k_adsr_edges_sparse, dim3((unsigned)pgx::ceil_div(edge_waves, 4)), dim3(256), 0,

@@ -53,6 +53,11 @@ __global__ void __launch_bounds__(256) k_copy_words(uint32_t *dst, const uint32_
         dst[i] = src[i];
 }
 
+__global__ void __launch_bounds__(256) k_fill_words(uint32_t *dst, uint32_t value, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < words && i < ((size_t)blockIdx.x + 1) * 1024; i += 256)
+        dst[i] = value;
+}
+
 size_t size_class(size_t bytes) {
     size_t c = 256;
     while (c < bytes) c <<= 1;
@@ -288,6 +293,14 @@ int pgx_memset(void *dptr, int byte_value, size_t bytes) {
     PGX_REQUIRE_INIT();
     if (bytes == 0) return PGX_OK;
     PGX_CHECK_ARG(dptr != nullptr, "pgx_memset: null pointer");
+    if (bytes <= (1u << 20) && bytes % 4 == 0 && (uintptr_t)dptr % 4 == 0) {     // small: a launch of our own (see
+        const uint32_t b = (uint32_t)(byte_value & 0xff);                         // pgx_memcpy_d2d)
+        const size_t words = bytes / 4;
+        hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((words + 1023) / 1024)), dim3(256), 0, rt().current,
+                           (uint32_t *)dptr, b * 0x01010101u, words);
+        PGX_LAUNCH_CHECK("k_fill_words");
+        return PGX_OK;
+    }
     PGX_HIP(hipMemsetAsync(dptr, byte_value, bytes, rt().current));
     return PGX_OK;
 }

@@ -2834,7 +2834,7 @@ int pgx_envelope(float *out, const float *in, int64_t n, int channels, double at
             double *mw = scratch + (size_t)(n + (n + kEnvBlock - 1) / kEnvBlock) * channels;
             double *pa_buf = mw, *pb_buf = mw + 2 * (size_t)nwin * channels, *guess = mw + 4 * (size_t)nwin * channels;
             EnvMwCtl *ctl = reinterpret_cast<EnvMwCtl *>(mw + 5 * (size_t)nwin * channels);
-            PGX_HIP(hipMemsetAsync(ctl, 0, sizeof(EnvMwCtl), pgx::stream()));
+            if (int rc = pgx_memset(ctl, 0, sizeof(EnvMwCtl))) return rc;
             // (PGX_ENV_MW_ROUNDS=1 makes every block give up: the test of the fallback)
             static const int rounds_env = getenv("PGX_ENV_MW_ROUNDS") ? atoi(getenv("PGX_ENV_MW_ROUNDS")) : kEnvMwRounds;
             const int rounds = rounds_env < 1 ? 1 : (rounds_env > kEnvMwRounds ? kEnvMwRounds : rounds_env);
