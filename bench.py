@@ -283,11 +283,16 @@ def c2_graph(pg):
 def bench_c2(pg, dist, steps, warmup, frames=1_000_000):
     pe, r = c2_graph(pg)
     keep = {}
-    origin = (warmup + 1000) * frames                  # the timed steps start away from the warm-up steps: every
-                                                       # frame of the timed region is rendered inside it
+    # The timed steps start away from the warm-up stream: every frame of the timed region is rendered inside it (a
+    # window opened during the warm-up is never served from).  The seek itself -- the old stream's window settled,
+    # one render outside any window -- is the warm-up's last step: the timed region is one sequential stream.
+    origin = (warmup + 1000) * frames
 
     def step(i):
-        pos = i * frames if i < warmup else origin + (i - warmup) * frames
+        if i < warmup - 1:
+            pos = i * frames
+        else:
+            pos = origin + (i - warmup) * frames       # i = warmup - 1: the block just before the timed ones
         keep["s"] = pe.render(pos, frames)             # stays in HBM
 
     dt = timed_steps(dist, step, steps, warmup)
@@ -307,7 +312,8 @@ def bench_c2_with_d2h(pg, steps, warmup, frames=1_000_000):
         state = {"prev": None, "sum": 0.0}
 
         def step(i):
-            s = pe.render((i if i < warmup else i + 1000) * frames, frames)      # timed steps start cold
+            s = pe.render((i if i < warmup - 1 else i + 1000) * frames, frames)  # timed steps: a stream of their own
+                                                                                 # (the seek is the last warm-up step)
             if mode == "sync":
                 state["sum"] += float(s.data[-1, 0])
                 return

@@ -62,7 +62,8 @@ def device_rates(spec, modes=("sync", "pipelined", "block_by_block")):
     sync: wait for the device after every render; pipelined: wait once after the 50 renders; block_by_block:
     pipelined with read-ahead / look-ahead switched off (every render is its own launch sequence).
     The timed renders start away from the warm-up renders, so every frame of the timed region is rendered
-    inside it (a look-ahead window opened during the warm-up is never served from)."""
+    inside it (a look-ahead window opened during the warm-up is never served from); the last warm-up render is the
+    block just before them."""
     import pygmu2_amd as pg
     from pygmu2_amd import device, look_ahead, read_ahead
     import spec_build
@@ -77,10 +78,11 @@ def device_rates(spec, modes=("sync", "pipelined", "block_by_block")):
             r = pg.NullRenderer(sample_rate=SR)
             r.set_source(pe)
             r.start()
-            for i in range(WARM):
-                keep = pe.render(i * N, N)
-            device.synchronize()
             first = (WARM + 1000) * N
+            for i in range(WARM - 1):
+                keep = pe.render(i * N, N)
+            keep = pe.render(first - N, N)          # the seek (old window settled, one render outside any window)
+            device.synchronize()                    # belongs to the warm-up: the timed renders are one stream
             if mode == "sync":
                 times = []
                 for i in range(RUNS):
