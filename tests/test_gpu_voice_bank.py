@@ -153,6 +153,37 @@ def test_wide_blitsaw_workgroups_reproduce_the_bank_kernel_bit_for_bit():
     assert np.array_equal(state_bank.to_host()[pick], state_one.to_host()[0])
 
 
+def test_blitsaw_long_stream_in_segments_is_the_single_workgroup_stream():
+    """A 3 M-frame stream of a few oscillators (what a look-ahead window of 64 x 44 100-frame blocks hands the
+    kernel): 733 tiles in 245 segments, the integrator chain folded by k_blitsaw_chain over 92 chunks of 64 wave
+    responses -- against one workgroup per oscillator walking all tiles, bit for bit, states included, with a
+    second block carried across and the state snapshot (state_backup) of the segmented form checked."""
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+    sr = 44100.0
+    rec = np.zeros(3, dtype=device.BLITSAW_PARAMS)
+    for i, f in enumerate((440.0, 61.7, 3520.0)):
+        rec[i] = (f, 0.8, 0.999, 0.0)
+    params = device.upload_structs(rec)
+    st_seg = device.DeviceBuffer((3, 2), np.float64, zero=True)
+    st_one = device.DeviceBuffer((3, 2), np.float64, zero=True)
+    for n in (3_000_000, 70_001):
+        need = lib.pgx_blitsaw_workspace_bytes(3, n, 0)
+        assert need > 0
+        ws = device.DeviceBuffer((need,), np.uint8)
+        before = st_seg.to_host().copy()
+        backup = device.DeviceBuffer((3, 2), np.float64, zero=True)
+        seg = device.DeviceBuffer((3, n, 1), np.float32)
+        device.check(lib.pgx_blitsaw(seg.ptr, n, 3, n, 1, sr, params.ptr, None, 0, None, 0, None, 0, st_seg.ptr,
+                                     ws.ptr, backup.ptr))
+        one = device.DeviceBuffer((3, n, 1), np.float32)
+        device.check(lib.pgx_blitsaw(one.ptr, n, 3, n, 1, sr, params.ptr, None, 0, None, 0, None, 0, st_one.ptr,
+                                     None, None))
+        assert np.array_equal(seg.to_host(), one.to_host()), n
+        assert np.array_equal(st_seg.to_host(), st_one.to_host()), n
+        assert np.array_equal(backup.to_host(), before), n
+
+
 @pytest.mark.parametrize("voices,channels", [(7, 1), (3, 2), (1, 1), (16, 1)])
 def test_supersaw_bank_summed_on_chip_is_the_two_launch_path_bit_for_bit(voices, channels, monkeypatch):
     """pgx_supersaw_bank (voices accumulated inside the oscillator kernel, no intermediate) against
