@@ -113,6 +113,27 @@ again = solo.render(0, 256).data
 assert np.array_equal(first, again) and np.array_equal(first, pg.SinePE(frequency=300.0).render(0, 256).data)
 idle = ShardedMixPE([pg.SinePE(frequency=300.0), pg.SinePE(frequency=500.0)], 2, 3, reducer=RcclReducer())
 assert not np.any(idle.render(0, 128).data)
+# a rank's share of the sharded SuperSaw mix at 8 ranks: 64 instances, oscillators one block ahead on the main
+# stream, voice sum + mix on the side stream, the all-reduce of every block behind the next block's oscillators;
+# a seek in the middle takes the block rendered ahead back
+from pygmu2_amd.sharding import supersaw_voice, shard_indices
+mine = list(shard_indices(512, 0, 8))
+share = ShardedMixPE([supersaw_voice(pg, i) for i in range(512)], 0, 8, reducer=RcclReducer())
+assert len(share.owned) == 64
+pulls = [(0, 48000), (48000, 48000), (96000, 48000), (500000, 48000), (548000, 4096), (552096, 48000)]
+r = pg.NullRenderer(48000); r.set_source(share); r.start()
+got = [share.render(s, n).data.copy() for s, n in pulls]
+r.stop()
+from pygmu2_amd import look_ahead
+plain64 = pg.MixPE(*[supersaw_voice(pg, i) for i in mine])
+plain64._bank = False                # per-voice rendering, no bank, no overlap ...
+look_ahead.set_enabled(False)        # ... and block by block: a window cuts the phase sums differently (1 ulp here and there)
+r = pg.NullRenderer(48000); r.set_source(plain64); r.start()
+want64 = [plain64.render(s, n).data.copy() for s, n in pulls]
+r.stop()
+look_ahead.set_enabled(True)
+for x, y in zip(got, want64):
+    assert np.array_equal(x, y), float(np.max(np.abs(x - y)))
 comm.destroy()
 assert not comm.initialised()
 assert "torch" not in sys.modules
