@@ -510,6 +510,29 @@ class VoiceBank:
     def reset(self) -> None:
         self.root.reset()
 
+    def _supersaw_pipelined(self, start: int, n: int) -> Snippet:
+        """A small bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8).  The
+        oscillators are the long pole (69 of 94 us) and depend on nothing but time and two carried numbers each, so they
+        own the main stream, one block ahead: block k's voice sum and mix run on the side stream beside block k+1's
+        oscillators.  Nothing on the main stream ever waits for the side stream to catch up (the join at the end is
+        enqueued behind the oscillators, which outlast sum + mix): a cross-stream wait that has to wake a stalled
+        queue costs ~16 us on this part, a whole launch.  A pull that is not the next block copies the oscillator
+        states back (take_voices).  What follows on the library stream -- the all-reduce of this block, a read-back --
+        runs behind the next block's oscillators: one block of latency, no throughput."""
+        root, L = self.root, lib()
+        voices = root.take_voices(start, n)
+        check(L.pgx_stream_fork(), "pgx_stream_fork")                  # side stream: behind this block's oscillators
+        try:
+            stacked = root.sum_voices(voices, n)
+            ch = stacked.shape[2]
+            out = DeviceBuffer((n, ch), np.float32)
+            check(L.pgx_mix_batch(out.ptr, stacked.ptr, n * ch, self.k, n * ch), "pgx_mix_batch")
+            check(L.pgx_stream_select(0), "pgx_stream_select")
+            root.render_ahead(start + n, n)                            # main stream
+        finally:
+            check(L.pgx_stream_join(), "pgx_stream_join")
+        return Snippet(start, out)
+
     def render_mix(self, start: int, duration: int) -> Snippet:
         root = self.root
         if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and not root.fused() and duration >= 4096
@@ -548,33 +571,6 @@ class VoiceBank:
         check(lib().pgx_mix_batch(out.ptr, stacked.ptr, duration * ch, self.k, duration * ch),
               "pgx_mix_batch")
         return Snippet(start, out)
-
-
-def _supersaw_pipelined(self, start: int, n: int) -> Snippet:
-    """A small bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8).  The
-    oscillators are the long pole (69 of 94 us) and depend on nothing but time and two carried numbers each, so they
-    own the main stream, one block ahead: block k's voice sum and mix run on the side stream beside block k+1's
-    oscillators.  Nothing on the main stream ever waits for the side stream to catch up (the join at the end is
-    enqueued behind the oscillators, which outlast sum + mix): a cross-stream wait that has to wake a stalled
-    queue costs ~16 us on this part, a whole launch.  A pull that is not the next block copies the oscillator
-    states back (take_voices).  What follows on the library stream -- the all-reduce of this block, a read-back --
-    runs behind the next block's oscillators: one block of latency, no throughput."""
-    root, L = self.root, lib()
-    voices = root.take_voices(start, n)
-    check(L.pgx_stream_fork(), "pgx_stream_fork")                  # side stream: behind this block's oscillators
-    try:
-        stacked = root.sum_voices(voices, n)
-        ch = stacked.shape[2]
-        out = DeviceBuffer((n, ch), np.float32)
-        check(L.pgx_mix_batch(out.ptr, stacked.ptr, n * ch, self.k, n * ch), "pgx_mix_batch")
-        check(L.pgx_stream_select(0), "pgx_stream_select")
-        root.render_ahead(start + n, n)                            # main stream
-    finally:
-        check(L.pgx_stream_join(), "pgx_stream_join")
-    return Snippet(start, out)
-
-
-VoiceBank._supersaw_pipelined = _supersaw_pipelined
 
 
 def try_build_bank(inputs):
