@@ -26,8 +26,8 @@ SMALL_BLOCK = 1 << 20       # requests up to this many frames are served from a 
 FIRST_WINDOW_BLOCKS = 8     # the first refill of a stream; every further one is WINDOW_GROWTH times longer, up to
 WINDOW_GROWTH = 8
 AHEAD_BLOCKS = 64           # ... at most this many blocks per refill ...
-AHEAD_FRAMES = 1 << 24      # ... and about this many frames (64 MB per channel: a 44 100-frame pull refills 64
-                            # blocks at a time, a 1 M-frame pull 16: launches of that size leave the ~4 us floor
+AHEAD_FRAMES = 1 << 25      # ... and about this many frames (128 MB per channel: a 44 100-frame pull refills 64
+                            # blocks at a time, a 1 M-frame pull 32: launches of that size leave the ~4 us floor
                             # of a launch behind and stream at HBM rate)
 
 _tls = threading.local()

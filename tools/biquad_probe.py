@@ -10,7 +10,7 @@ from pygmu2_amd.biquad_pe import rbj_coefficients, settle_frames
 
 lib = device.ensure_init()
 pg.set_sample_rate(44100)
-for frames, reps in ((1_000_000, 5), (16_000_000, 5), (1 << 26, 3)):
+for frames, reps in ((1_000_000, 5), (16_000_000, 5), (33_000_000, 5), (1 << 26, 3)):
     x = pg.SinePE(440.0).render(0, frames).dev
     out = device.DeviceBuffer((frames, 1), np.float32)
     c = rbj_coefficients(pg.BiquadMode.LOWPASS, 1000.0, 0.707, 0.0, 44100.0)
