@@ -358,6 +358,30 @@ def event_avg_ms(launch, launches, warm=3):
     return e1.elapsed_ms_since(e0) / launches
 
 
+def sine_kernel_roofline(pg, frames, launches, start):
+    """The other launch of a C2 window: pgx_sine_render at the window's size, at the stream position the timed
+    steps are at (the argument of the sine grows with time).  Priced against HBM like everything else (4 B per
+    frame written), though float64 issue is what bounds it."""
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+    pg.set_sample_rate(44100)
+    pe = pg.SinePE(frequency=440.0)
+    out = device.DeviceBuffer((frames, 1), np.float32)
+    params = pe._pure_params()
+
+    def launch():
+        device.check(lib.pgx_sine_render(out.ptr, 0, 1, start, frames, 1, 44100.0, params.ptr))
+
+    ms = event_avg_ms(launch, launches)
+    algo = 4.0 * frames
+    return {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel": "k_sine (pgx_sine_render, mono)", "frames_per_launch": frames,
+            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 6),
+            "note": "float64-issue bound, not HBM: ~30 float64-class instructions per sample "
+                    f"({frames / (ms * 1e-3) / 1e9:.0f} Gsamples/s); listed because it is the other half of a C2 window"}
+
+
 def biquad_kernel_roofline(pg, frames, launches, settled=True):
     """HIP-event timing of the pgx_biquad_const entry point alone (input resident in HBM).
 
@@ -850,6 +874,7 @@ def main():
         # (steady state: a stream's first windows are 4 and 16 steps long)
         result["roofline"] = biquad_kernel_roofline(pg, 1_000_000 * ahead, 100)
         result["roofline"]["steps_per_launch"] = ahead
+        result["roofline_sine"] = sine_kernel_roofline(pg, 1_000_000 * ahead, 50, (args.warmup + 1000) * 1_000_000)
         result["roofline_one_step"] = biquad_kernel_roofline(pg, 1_000_000, 200)
         result["roofline_scaled"] = biquad_kernel_roofline(pg, 1 << 26, 10)
         cases = {}
