@@ -297,8 +297,13 @@ __device__ __forceinline__ double block_scan_scalar_affine_wide(double e, const 
 // block_excl_sum_wide when every thread contributes the SAME value (a scalar-frequency oscillator on a tile
 // whose frames are all live): every wave's total is the same number, so the folds need no exchange and no
 // barrier.  Same operations in the same order as the exchanging form, hence the same bits.
-template <int NW>
-__device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &sum_carry) {
+// The two numbers block_excl_sum_wide_uniform derives from v alone: this thread's offset inside the tile and what the
+// carry advances by per group of kWaves waves.  With them a tile's prefix is `carry + offset` (groups before the
+// thread's own first advance the carry): a caller whose v never changes makes them once -- same operations, same bits.
+struct UniformPrefix {
+    double offset, tot;
+};
+__device__ __forceinline__ UniformPrefix uniform_prefix(double v) {
     const int wave = threadIdx.x >> 6;
     const double inc = wave_incl_sum_dpp(v);
     const double t = readlane_f64(inc, 63);
@@ -308,15 +313,24 @@ __device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &
         if (w < (wave & (kWaves - 1))) w_local = w_local + t;
         tot = tot + t;
     }
+    const double ex = dpp_f64_keep<0x138, 0xf>(0.0, inc);
+    return UniformPrefix{w_local + ex, tot};
+}
+template <int NW>
+__device__ __forceinline__ double block_excl_sum_wide_uniform(const UniformPrefix &u, double &sum_carry) {
+    const int wave = threadIdx.x >> 6;
     double base = sum_carry, mine_base = sum_carry;
 #pragma unroll
     for (int g = 0; g < NW / kWaves; ++g) {
         if (g == wave / kWaves) mine_base = base;
-        base = base + tot;
+        base = base + u.tot;
     }
     sum_carry = base;
-    const double ex = dpp_f64_keep<0x138, 0xf>(0.0, inc);
-    return mine_base + (w_local + ex);
+    return mine_base + u.offset;
+}
+template <int NW>
+__device__ __forceinline__ double block_excl_sum_wide_uniform(double v, double &sum_carry) {
+    return block_excl_sum_wide_uniform<NW>(uniform_prefix(v), sum_carry);
 }
 
 // block_scan_scalar_affine_wide with ONE barrier: `lds` holds two images of NW doubles used alternately
@@ -1051,6 +1065,13 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         carry_sum = seg_sum[seg];
         carry_y = tile_y[first_tile];                          // k_blitsaw_chain: the integrator chain, folded once
     }
+    UniformPrefix uni{0.0, 0.0};                               // a full tile's phase prefix, less the carry
+    if (!STREAMS) {
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) run = run + k0.inc;
+        uni = uniform_prefix(run);
+    }
     const int64_t seg_begin = SEG ? (int64_t)first_tile * kTile : 0;
     const int64_t seg_end = SEG ? ((seg_begin + (int64_t)tiles_per_seg * kTile < n) ? seg_begin + (int64_t)tiles_per_seg * kTile : n) : n;
     int parity = 0;
@@ -1076,8 +1097,10 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             run = run + (live ? kc[j].inc : 0.0);
             loc[j] = run;
         }
-        // scalar frequency, every frame of the tile live: all threads add the same increments, no exchange
-        const double chunk_base = (!STREAMS && base + kTile <= n)
+        // scalar frequency, every frame of the tile live: all threads add the same increments, no exchange -- and on
+        // an inner tile the scan of those increments is the one made before the loop (uni)
+        const double chunk_base = (!STREAMS && INNER) ? block_excl_sum_wide_uniform<NW>(uni, carry_sum)
+                                  : (!STREAMS && base + kTile <= n)
                                       ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
                                       : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
 
@@ -1393,6 +1416,13 @@ struct SsShared {
     int rot_ok[kSsMaxVoices];
     double kc[kSsMaxVoices][6];           // per voice: inc, M, P, 1/P, M/P, phase0 -- made once, not per tile
     double lam[kSsMaxVoices][8];          // per voice: leak^(8*2^k), k = 0..5, leak^(8*64)
+    // per voice and thread, made once per launch (inner tiles: every frame live, so a thread's 8 increments, their
+    // wave scan and the folds over the waves are the same numbers tile after tile -- ~70 instructions per voice and
+    // tile of the ~600), and per voice and lane the powers of the leak the integrator scan multiplies with
+    double run8[kSsMaxVoices];
+    double tot[kSsMaxVoices];
+    double offset[kSsMaxVoices][NW * 64];
+    double lane_pw[kSsMaxVoices][64][3];
 };
 // NW = 4: 2048-frame tiles, two workgroups per CU (512 instances fill the chip in one round and one workgroup's
 // barrier waits overlap the other's arithmetic); NW = 8: 4096-frame tiles for fewer instances.  Same bits.
@@ -1428,6 +1458,26 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         }
     }
     __syncthreads();
+    for (int v = 0; v < nv; ++v) {                          // the per-thread tables (all threads, every voice)
+        const double inc = sh.kc[v][0];
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) run = run + inc;
+        const UniformPrefix u = uniform_prefix(run);
+        sh.offset[v][tid] = u.offset;
+        if (tid == 0) {
+            sh.run8[v] = run;
+            sh.tot[v] = u.tot;
+        }
+        if (tid < 64) {
+            double lamp[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) lamp[k] = sh.lam[v][k];
+            const LanePowers lp = lane_powers(lamp, lane);
+            sh.lane_pw[v][lane][0] = lp.lane; sh.lane_pw[v][lane][1] = lp.p16; sh.lane_pw[v][lane][2] = lp.p32;
+        }
+    }
+    __syncthreads();
     int parity = 0;
     for (int64_t base = 0; base < n; base += kTile) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
@@ -1450,18 +1500,34 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             double lamp[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) lamp[k] = sh.lam[v][k];
-            const LanePowers lane_pw = lane_powers(lamp, lane);
+            const LanePowers lane_pw{sh.lane_pw[v][lane][0], sh.lane_pw[v][lane][1], sh.lane_pw[v][lane][2]};
             const double lam_wave = sh.lam[v][6];
             double carry_sum = sh.carry_sum[v], carry_y = sh.carry_y[v];
             double loc[kSawT];
-            double run = 0.0;
+            double chunk_base;
+            if (INNER) {
+                // every frame live: the thread's increments, their scan and the folds are this voice's table entries
+                if (!sh.rot_ok[v]) {                           // (only the per-sample Dirichlet forms read loc[1..])
+                    double run = 0.0;
 #pragma unroll
-            for (int j = 0; j < kSawT; ++j) {
-                run = run + ((INNER || f0 + j < n) ? k0.inc : 0.0);
-                loc[j] = run;
+                    for (int j = 0; j < kSawT; ++j) {
+                        run = run + k0.inc;
+                        loc[j] = run;
+                    }
+                } else {
+                    loc[0] = 0.0 + k0.inc;
+                }
+                chunk_base = block_excl_sum_wide_uniform<NW>(UniformPrefix{sh.offset[v][tid], sh.tot[v]}, carry_sum);
+            } else {
+                double run = 0.0;
+#pragma unroll
+                for (int j = 0; j < kSawT; ++j) {
+                    run = run + ((f0 + j < n) ? k0.inc : 0.0);
+                    loc[j] = run;
+                }
+                chunk_base = full ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
+                                  : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
             }
-            const double chunk_base = full ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
-                                           : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
             double xb[kSawT];
             double final_phase = 0.0, final_y = 0.0;
             const double m_over_p = sh.kc[v][4];
