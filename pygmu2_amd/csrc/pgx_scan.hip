@@ -1283,6 +1283,13 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
         lam_wave = l;
     }
     const LanePowers lane_pw = lane_powers(lamp, lane);
+    UniformPrefix uni;                                         // a full tile's phase prefix, less the carry
+    {
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSawT; ++j) run = run + k0.inc;
+        uni = uniform_prefix(run);
+    }
     int parity = 0;
     for (int64_t base = 0; base < n; base += kTile, ++parity) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
@@ -1298,7 +1305,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
             run = run + ((INNER || f0 + j < n) ? k0.inc : 0.0);
             loc[j] = run;
         }
-        const double chunk_base = (base + kTile <= n) ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
+        const double chunk_base = (base + kTile <= n) ? block_excl_sum_wide_uniform<NW>(uni, carry_sum)
                                                       : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
         double xb[kSawT];
         double final_phase = 0.0, final_y = 0.0;
