@@ -1152,7 +1152,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             y = z + xb[j];
             double a = p.amp;
             if (STREAMS && as) a = (INNER || f0 + j < n) ? (double)as[f0 + j] : 0.0;
-            yf[j] = (float)((y * 2.0) * a);
+            yf[j] = (float)(y * (2.0 * a));                       // (y * 2) * a: the doubling is exact
             if (!INNER && f0 + j == n - 1) final_y = y;
         }
         store_frames_tiled<kSawT>(ob, f0, n, channels, yf);
@@ -1336,7 +1336,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
         for (int j = 0; j < kSawT; ++j) {
             double z = leak * y;
             y = z + xb[j];
-            xf[j] = (INNER || f0 + j < n) ? (float)((y * 2.0) * p.amp) : 0.0f;       // BlitSawPE's float32 output
+            xf[j] = (INNER || f0 + j < n) ? (float)(y * (2.0 * p.amp)) : 0.0f;       // BlitSawPE's float32 output: (y * 2) * amp, the doubling exact
             if (!INNER && f0 + j == n - 1) final_y = y;
         }
         if (!INNER && f0 <= n - 1 && n - 1 < f0 + kSawT) {                // the thread that renders the last frame
@@ -1504,6 +1504,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             k0.inc = sh.kc[v][0]; k0.m = sh.kc[v][1]; k0.P = sh.kc[v][2]; k0.invP = sh.kc[v][3];
             const double phase0 = sh.kc[v][5];
             const double leak = p.leak;
+            const double amp2 = 2.0 * p.amp;
             double lamp[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) lamp[k] = sh.lam[v][k];
@@ -1566,7 +1567,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             for (int j = 0; j < kSawT; ++j) {
                 double z = leak * y;
                 y = z + xb[j];
-                acc[j] += (double)(float)((y * 2.0) * p.amp);
+                acc[j] += (double)(float)(y * amp2);           // (y * 2) * amp: doubling is exact, so 2 * amp first
                 if (!INNER && f0 + j == n - 1) final_y = y;
             }
             if (!INNER && f0 <= n - 1 && n - 1 < f0 + kSawT) {   // the thread that renders the last frame
