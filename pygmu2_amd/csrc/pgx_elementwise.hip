@@ -267,8 +267,16 @@ __global__ void __launch_bounds__(kBlock) k_mix_batch(float *out, const float *i
             }
             store4(out, e, n_elems, aligned, acc);
         } else {
-            float acc = in[e], v[8];
+            // one element per thread (blocks below 2^20 elements: a 48 000-frame block is 750 waves): 32 loads in
+            // flight per lane, as k_gain_mix_batch keeps them, or the pass is latency-bound (512 inputs: 27 us)
+            float acc = in[e], v[32];
             int b = 1;
+            for (; b + 32 <= batch; b += 32) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = in[(int64_t)(b + u) * in_stride + e];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc = acc + v[u];
+            }
             for (; b + 8 <= batch; b += 8) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = in[(int64_t)(b + u) * in_stride + e];
