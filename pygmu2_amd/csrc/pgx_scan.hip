@@ -213,12 +213,14 @@ __device__ __forceinline__ double wave_incl_sum_dpp(double v) {
 }
 // y' = lam^len * y + b: lamp[k] = lam^(T*2^k); lam16 / lam32 = lam^(T*((lane & 15) + 1)) / lam^(T*((lane & 31) + 1))
 __device__ __forceinline__ double wave_incl_affine_dpp(double e, const double (&lamp)[6], double lam16, double lam32) {
-    e = lamp[0] * dpp_f64_keep<0x111, 0xf>(0.0, e) + e;
-    e = lamp[1] * dpp_f64_keep<0x112, 0xf>(0.0, e) + e;
-    e = lamp[2] * dpp_f64_keep<0x114, 0xf>(0.0, e) + e;
-    e = lamp[3] * dpp_f64_keep<0x118, 0xf>(0.0, e) + e;
-    e = lam16 * dpp_f64_keep<0x142, 0xa>(0.0, e) + e;
-    e = lam32 * dpp_f64_keep<0x143, 0xc>(0.0, e) + e;
+    // (fused multiply-adds: these numbers only feed carries -- the samples themselves are re-run from the scanned
+    // carry-in in the reference's operation order; k_blitsaw_chain folds with the same fused step)
+    e = __builtin_fma(lamp[0], dpp_f64_keep<0x111, 0xf>(0.0, e), e);
+    e = __builtin_fma(lamp[1], dpp_f64_keep<0x112, 0xf>(0.0, e), e);
+    e = __builtin_fma(lamp[2], dpp_f64_keep<0x114, 0xf>(0.0, e), e);
+    e = __builtin_fma(lamp[3], dpp_f64_keep<0x118, 0xf>(0.0, e), e);
+    e = __builtin_fma(lam16, dpp_f64_keep<0x142, 0xa>(0.0, e), e);
+    e = __builtin_fma(lam32, dpp_f64_keep<0x143, 0xc>(0.0, e), e);
     return e;
 }
 // the per-lane powers of a scan over chunks of T samples, from lamp[k] = lam^(T*2^k)
@@ -349,12 +351,12 @@ __device__ __forceinline__ double block_scan_scalar_affine_wide1(double e, const
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         double t = img[w];
-        if (w < wave) cw = lam_wave * cw + t;
-        cn = lam_wave * cn + t;
+        if (w < wave) cw = __builtin_fma(lam_wave, cw, t);
+        cn = __builtin_fma(lam_wave, cn, t);
     }
     carry = cn;
     const double ex = dpp_f64_keep<0x138, 0xf>(0.0, inc);
-    return lp.lane * cw + ex;
+    return __builtin_fma(lp.lane, cw, ex);
 }
 
 // ================================================================================================
@@ -1138,7 +1140,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         // ---- leaky integrator y[n] = x[n] + leak*y[n-1] (blit_saw_pe.py:222-234) ----
         double e = 0.0;
 #pragma unroll
-        for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
+        for (int j = 0; j < kSawT; ++j) e = __builtin_fma(leak, e, xb[j]);   // feeds the scan only
         double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
         if (SEG == 1) {                      // the wave responses the scan just folded are still in LDS
             if (tid < NW) wsi[2 + (base / kTile) * NW + tid] = sh.aff[(parity & 1) * NW + tid];
@@ -1193,7 +1195,7 @@ k_blitsaw_chain(const pgx_blitsaw_params *params, double *ws, int64_t ws_stride,
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             if ((i & 7) == 0) keep = (lane == (i >> 3)) ? c : keep;
-            c = lam * c + readlane_f64(cur, i);
+            c = __builtin_fma(lam, c, readlane_f64(cur, i));   // block_scan_scalar_affine_wide1's fold
         }
         const int64_t tile = (i0 >> 3) + lane;
         if (lane < 8 && tile < tiles) tile_y[tile] = keep;
@@ -1330,7 +1332,7 @@ k_blitsaw_biquad(float *out, int64_t out_stride, int64_t n, double sr, const pgx
         else dirichlet(std::false_type{});
         double e = 0.0;
 #pragma unroll
-        for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
+        for (int j = 0; j < kSawT; ++j) e = __builtin_fma(leak, e, xb[j]);   // feeds the scan only
         double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) {
@@ -1561,7 +1563,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             else dirichlet(std::false_type{});
             double e = 0.0;
 #pragma unroll
-            for (int j = 0; j < kSawT; ++j) e = leak * e + xb[j];
+            for (int j = 0; j < kSawT; ++j) e = __builtin_fma(leak, e, xb[j]);   // feeds the scan only
             double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
 #pragma unroll
             for (int j = 0; j < kSawT; ++j) {
