@@ -939,13 +939,16 @@ __device__ __forceinline__ SawRot saw_rot(const SawConst &k) {
 }
 // xb[j] = blit - 1/P for the thread's 8 samples; returns nothing else: the carried phase is taken elsewhere.
 // INNER: the caller knows that all of the thread's frames are live (a tile strictly inside the block).
-template <bool INNER = false>
-__device__ __forceinline__ void saw_dirichlet_rot(double ph0, const SawConst &k0, const SawRot &rot, double m_over_p,
-                                                  int64_t f0, int64_t n, double (&xb)[kSawT]) {
-    double sd, cd, sn, cn;
-    const double theta = kPi * ph0;
-    pgx::pgx_sincos_bounded(theta, sd, cd);
-    pgx::pgx_sincos_bounded(k0.m * theta, sn, cn);
+// The singularity (|sin theta| < 1e-9: the sample takes M / P) is met when a phase comes within 3e-10 of an integer --
+// in practice the very first sample of an oscillator that starts at phase 0 -- so the quotients are formed without
+// the per-sample select and the comparisons are only OR-ed together on the scalar unit; a wave in which any lane met
+// it runs the samples again with the selects (GUARD).  Same operations either way.
+template <bool INNER, bool GUARD>
+__device__ __forceinline__ unsigned long long saw_dirichlet_rot_body(double sd, double cd, double sn, double cn,
+                                                                     const SawConst &k0, const SawRot &rot,
+                                                                     double m_over_p, int64_t f0, int64_t n,
+                                                                     double (&xb)[kSawT]) {
+    unsigned long long any = 0ull;
 #pragma unroll
     for (int j = 0; j < kSawT; ++j) {
         if (j) {
@@ -957,9 +960,24 @@ __device__ __forceinline__ void saw_dirichlet_rot(double ph0, const SawConst &k0
             sn = n2;
         }
         double blit = pgx::pgx_div_fast(sn, k0.P * sd);
-        if (fabs(sd) < 1e-9) blit = m_over_p;
+        if (GUARD) {
+            if (fabs(sd) < 1e-9) blit = m_over_p;
+        } else {
+            any |= __ballot(fabs(sd) < 1e-9);
+        }
         xb[j] = (INNER || f0 + j < n) ? (blit - k0.invP) : 0.0;
     }
+    return any;
+}
+template <bool INNER = false>
+__device__ __forceinline__ void saw_dirichlet_rot(double ph0, const SawConst &k0, const SawRot &rot, double m_over_p,
+                                                  int64_t f0, int64_t n, double (&xb)[kSawT]) {
+    double sd, cd, sn, cn;
+    const double theta = kPi * ph0;
+    pgx::pgx_sincos_bounded(theta, sd, cd);
+    pgx::pgx_sincos_bounded(k0.m * theta, sn, cn);
+    if (saw_dirichlet_rot_body<INNER, false>(sd, cd, sn, cn, k0, rot, m_over_p, f0, n, xb))
+        saw_dirichlet_rot_body<INNER, true>(sd, cd, sn, cn, k0, rot, m_over_p, f0, n, xb);
 }
 // the phase of the thread's sample j (np.mod(phase, 1.0)), j wave-divergent: for the carried state only
 // (the thread's local phase sums are re-added rather than indexed: an indexed register array moves to LDS)
