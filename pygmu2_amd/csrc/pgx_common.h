@@ -141,6 +141,16 @@ __device__ __forceinline__ double pgx_div_fast(double a, double b) {
     return __builtin_fma(__builtin_fma(-q, b, a), y, q);
 }
 
+// The same with ONE Newton step on the reciprocal: v_rcp_f64 is good to 2^-24.4 (tools/microbench/rcp_acc.hip), one
+// step to 2^-48.7, and the residual correction then leaves ~2^-97 + the final rounding: within an ulp of the
+// quotient (the second step only decides ties of the last bit).  Two instructions less on a per-sample path.
+__device__ __forceinline__ double pgx_div_fast1(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+    const double q = a * y;
+    return __builtin_fma(__builtin_fma(-q, b, a), y, q);
+}
+
 // tanh for the ladder's feedback loop: branch-free, ~45 instructions instead of libm's ~110 on the
 // critical path of a strictly sequential recurrence.  e = exp(-2|x|) by Cody-Waite reduction
 // (ln2 = hi + lo) and a degree-13 Taylor polynomial on |r| <= ln2/2, tanh = (1 - e) / (1 + e) with a

@@ -959,7 +959,7 @@ __device__ __forceinline__ unsigned long long saw_dirichlet_rot_body(double sd, 
             cn = __builtin_fma(cn, rot.cm, -(sn * rot.sm));
             sn = n2;
         }
-        double blit = pgx::pgx_div_fast(sn, k0.P * sd);
+        double blit = pgx::pgx_div_fast1(sn, k0.P * sd);
         if (GUARD) {
             if (fabs(sd) < 1e-9) blit = m_over_p;
         } else {
