@@ -99,9 +99,10 @@ sub_row("| **SuperSaw mix** 512 × SuperSawPE(7) → MixPE (`supersaw_mix`, nort
         "| **SuperSaw mix** 512 × SuperSawPE(7) → MixPE (`supersaw_mix`, north_star's scaling case) | 1.105 ms = 43.4 | "
         f"**{sm['ms_per_block']:.3f} ms = {sm['value']:.1f} Msamples/s** = {n(round(sm['oscillator_msamples_s'], -2))} "
         f"oscillator-Msamples/s | {sm['cpu_baseline']['value']:.5f} ({n(round(sm['over_cpu'], -2))}×) | `k_supersaw_bank` "
-        "372 µs (round 1: 880 + 154): voices summed on chip, branch-free sines, rotations, per-voice constants and "
-        "per-thread prefix / lane-power tables in LDS, DPP scans, inner tiles without bounds selects (§4); 52 VALU "
-        "instructions per sample (PMC; 75 before the last two) at ≈68 % VALU utilisation; then the 18 µs mix |")
+        "330 µs (round 1: 880 + 154): voices summed on chip, branch-free sines, rotations, per-voice constants and "
+        "per-thread prefix / lane-power tables in LDS, DPP scans, inner tiles without bounds selects, carries on fused "
+        "multiply-adds, no per-sample singularity select (§4); ≈46 VALU instructions per sample (75 when the round's "
+        "last series of cuts began) at ≈68 % VALU utilisation; then the 18 µs mix |")
 ab, asv = c["autowah_biquad_1024_blocks"], c["autowah_svf_1024_blocks"]
 sub_row("| autowah (`profile_biquad_vs_svfilter.py`), 1024-frame blocks through the Renderer |",
         f"| autowah (`profile_biquad_vs_svfilter.py`), 1024-frame blocks through the Renderer | 37.9 | "
