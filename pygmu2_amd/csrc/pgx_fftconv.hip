@@ -57,21 +57,36 @@ __device__ __forceinline__ cplx twiddle(int64_t m, double inv_n) {
 //   radix-4 stage Ns:  st[(Ns - 1) + (t - 1) * Ns + k]          (the stages before it hold 4^s - 1 = Ns - 1 entries)
 //   final radix-2 stage (odd lm), Ns = M/2:  st[(Ns - 1) + k] = W_M^k
 // M - 1 entries in all.  Filled from the global table g[p] = W_M^p.
+// (PER = entries per thread, M <= 256 * PER.  All loads first -- unconditional, from a clamped entry -- then the LDS
+// stores: a load inside the entry loop gets its s_waitcnt right behind it, the table then costs one memory latency per
+// entry and, the counter being in order, drags the tile / spectrum / twiddle loads issued before it along.)
+template <int PER>
 __device__ __forceinline__ void fill_stage_twiddles(cplx *st, const cplx *g, int lm) {
     const int M = 1 << lm;
-    for (int e = threadIdx.x; e < M - 1; e += kFBlock) {
+    cplx val[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        int e = threadIdx.x + k * kFBlock;
+        if (e > M - 2) e = M - 2;
         // stage of entry e: the largest Ns = 4^s with Ns - 1 <= e
         int lns = (31 - __builtin_clz(e + 1)) & ~1;
         if (lns > lm - 1) lns = lm - 1;                           // (cannot happen for e < M - 1; keeps lns in range)
         const int Ns = 1 << lns, r = e - (Ns - 1);
         int p;
         if (lm - lns >= 2) {
-            const int t = r >> lns, k = r & (Ns - 1);             // t = 0..2 -> W^(k*(t+1))
-            p = (k * (t + 1)) << (lm - 2 - lns);
+            const int t = r >> lns, k2 = r & (Ns - 1);            // t = 0..2 -> W^(k*(t+1))
+            p = (k2 * (t + 1)) << (lm - 2 - lns);
         } else {
             p = r;                                                // radix-2: W_M^k
         }
-        st[e] = g[p];
+        val[k] = g[p];
+    }
+    // (the stores are unconditional too -- surplus threads write the spare entry M - 1 of the table's M slots -- or the
+    // compiler sinks every load into its store's branch and waits for it there)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = threadIdx.x + k * kFBlock;
+        st[e < M - 1 ? e : M - 1] = val[k];
     }
 }
 
@@ -235,15 +250,23 @@ k_fft_tables(cplx *big, cplx *t1, cplx *t2, ConvGeom g) {
     }
 }
 
-// sample `pos` of overlap-save block `b` of output channel `ch`: (history | x) at b*V + pos
+// sample `pos` of overlap-save block `b` of output channel `ch`: (history | x) at b*V + pos.
+// Both candidates are loaded unconditionally (from index 0 when the sample is not theirs) and selected afterwards:
+// a load behind a branch gets its s_waitcnt at the join, i.e. immediately, and a thread's sixteen loads then run one
+// memory latency after the other (ISA of the first version: global_load_dword / s_waitcnt vmcnt(0) pairs).
 __device__ __forceinline__ double conv_input(const ConvGeom &g, const float *x, const float *hist, int64_t b, int ch,
                                              int64_t pos) {
-    if (b >= g.nblocks) return 0.0;
     const int64_t e = b * g.V + pos;                               // index into (history | x)
-    if (e < g.L - 1) return g.hist_zero ? 0.0 : (double)hist[e * g.out_ch + ch];
+    const bool block_ok = b < g.nblocks;
+    const bool in_hist = e < g.L - 1;
     const int64_t i = e - (g.L - 1);
-    if (i >= g.n) return 0.0;
-    return (double)x[i * g.src_ch + (g.src_ch == 1 ? 0 : ch)];
+    const bool from_hist = block_ok && in_hist && !g.hist_zero;
+    const bool from_x = block_ok && !in_hist && i < g.n;
+    const unsigned hv = __float_as_uint(hist[from_hist ? e * g.out_ch + ch : 0]);
+    const unsigned xv = __float_as_uint(x[from_x ? i * g.src_ch + (g.src_ch == 1 ? 0 : ch) : 0]);
+    // (bit masks, not ?: -- the compiler turns selects of loaded values back into branches around the loads)
+    const unsigned bits = (hv & (from_hist ? 0xffffffffu : 0u)) | (xv & (from_x ? 0xffffffffu : 0u));
+    return (double)__uint_as_float(bits);
 }
 
 // The two real sequences packed into transform `pair` as real and imaginary part.  The filter is real, so they
@@ -321,7 +344,7 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
             bigtw[u] = tb.big[((int64_t)k1 << g.l2) + col0 + c];
         }
     }
-    fill_stage_twiddles(tw, tb.t1, g.l1);
+    fill_stage_twiddles<(TILE / 8 + kFBlock - 1) / kFBlock>(tw, tb.t1, g.l1);        // N1 <= TILE / 8
     // the thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT -- in the time domain and, in
     // the same registers, in the frequency domain
     tile_fft_regs<TILE>(v, buf, alt, tw, g.l1, stride, (tid & (CW - 1)) * stride, tid >> lcw, N1 / PT);
@@ -374,7 +397,7 @@ k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *
             bigtw[u] = tb.big[tile0 + tid + u * kFBlock];
         }
     }
-    fill_stage_twiddles(tw, tb.t2, g.l2);
+    fill_stage_twiddles<TILE / kFBlock>(tw, tb.t2, g.l2);                           // N2 <= TILE
     if (FULL && N2 == TILE) {
         // one row per workgroup: first and last stage of both transforms in registers (tile_fft_regs)
         cplx *read_last = tile_fft_regs<TILE>(v, buf, alt, tw, g.l2, TILE, 0, tid, kFBlock);
