@@ -1897,13 +1897,29 @@ k_biquad_varying(float *out, const float *in, int64_t n, int channels, double sr
         }
         M2 cm = m_identity();
         V2 cv{0.0, 0.0};
+        // the thread's samples and control values first, unconditionally (clamped index): a load behind the bounds test
+        // is waited for at once, and the 3 x T loads of a thread then run one memory latency after the other
+        float x_in[kBvT], f_in[kBvT], q_in[kBvT];
+#pragma unroll
+        for (int j = 0; j < kBvT; ++j) {
+            const int64_t at = (f0 + j < n) ? f0 + j : n - 1;
+            x_in[j] = in[at * channels + ch];
+        }
+        if (freq) {
+#pragma unroll
+            for (int j = 0; j < kBvT; ++j) f_in[j] = freq[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (qs) {
+#pragma unroll
+            for (int j = 0; j < kBvT; ++j) q_in[j] = qs[(f0 + j < n) ? f0 + j : n - 1];
+        }
 #pragma unroll
         for (int j = 0; j < kBvT; ++j) {
             const bool live = (f0 + j < n);
-            double x = live ? (double)in[(f0 + j) * channels + ch] : 0.0;
+            double x = live ? (double)x_in[j] : 0.0;
             double f = p.freq, q = p.q;
-            if (freq) f = live ? (double)freq[f0 + j] : 1000.0;
-            if (qs) q = live ? (double)qs[f0 + j] : 1.0;
+            if (freq) f = live ? (double)f_in[j] : 1000.0;
+            if (qs) q = live ? (double)q_in[j] : 1.0;
             double b0, b1, b2, a1, a2;
             rbj(p.mode, f, q, A, sqrtA, sr, b0, b1, b2, a1, a2);
             ff[j] = (b0 * x + b1 * xm1) + b2 * xm2;
@@ -2107,14 +2123,29 @@ k_svf(float *out, const float *in, int64_t n, int channels, double sr, const pgx
         double xs[kSvT];
         M2 cm = m_identity();
         V2 cv{0.0, 0.0};
+        // samples and control values first, unconditionally (see k_biquad_varying)
+        float x_in[kSvT], f_in[kSvT], q_in[kSvT];
+#pragma unroll
+        for (int j = 0; j < kSvT; ++j) {
+            const int64_t at = (f0 + j < n) ? f0 + j : n - 1;
+            x_in[j] = in[at * channels + ch];
+        }
+        if (varying && freq) {
+#pragma unroll
+            for (int j = 0; j < kSvT; ++j) f_in[j] = freq[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (varying && qs) {
+#pragma unroll
+            for (int j = 0; j < kSvT; ++j) q_in[j] = qs[(f0 + j < n) ? f0 + j : n - 1];
+        }
 #pragma unroll
         for (int j = 0; j < kSvT; ++j) {
             const bool live = (f0 + j < n);
-            xs[j] = live ? (double)in[(f0 + j) * channels + ch] : 0.0;
+            xs[j] = live ? (double)x_in[j] : 0.0;
             if (varying) {
                 double f = p.freq, q = p.q;
-                if (freq) f = live ? (double)freq[f0 + j] : 1000.0;
-                if (qs) q = live ? (double)qs[f0 + j] : 1.0;
+                if (freq) f = live ? (double)f_in[j] : 1000.0;
+                if (qs) q = live ? (double)q_in[j] : 1.0;
                 cf[j] = svf_coef(p.mode, f, q, a_lin, sr);
             } else {
                 cf[j] = cconst;
