@@ -64,7 +64,7 @@ c3cpu = c3["cpu_oracle_msamples_s"]
 sub_row("| **C3** ConvolvePE stereo × 65 536 taps, 96 000 frames per step |",
         f"| **C3** ConvolvePE stereo × 65 536 taps, 96 000 frames per step | 1 512 (103×) | **{n(round(c3['value']))}** | "
         f"{c3cpu:.1f} ({c3['value'] / c3cpu:.0f}×) | `pgx_convolve_fft` {c3['roofline']['avg_launch_ms'] * 1e3:.1f} µs per "
-        "call (round 1: 28.4; mid-round 24.9): three passes, each the latency of ONE workgroup's life (a pass with half "
+        "call (round 1: 28.4; mid-round 24.9, 20.2): three passes, each the latency of ONE workgroup's life (a pass with half "
         "the workgroups takes as long, §4); ArrayPE hands out its rows (no copy), no history memset |")
 sub_row("| C3, 1 440 000 frames in one call |",
         f"| C3, 1 440 000 frames in one call | — | **{n(round(c3w['value'], -1))}** (`pgx_convolve_fft` "
