@@ -1105,12 +1105,26 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
         // ---- phase increment and inclusive local cumsum (blit_saw_pe.py:188-191) ----
         double loc[kSawT];
         double run = 0.0;
+        // (PE-driven frequency / M / amplitude: the thread's values first, unconditionally -- see k_sine_stateful)
+        float fs_in[STREAMS ? kSawT : 1], ms_in[STREAMS ? kSawT : 1], as_in[STREAMS ? kSawT : 1];
+        if (STREAMS && fs) {
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) fs_in[j] = fs[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (STREAMS && ms) {
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) ms_in[j] = ms[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (STREAMS && as) {
+#pragma unroll
+            for (int j = 0; j < kSawT; ++j) as_in[j] = as[(f0 + j < n) ? f0 + j : n - 1];
+        }
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) {
             const bool live = INNER || (f0 + j < n);
             if (STREAMS) {
-                double f = fs ? (live ? (double)fs[f0 + j] : 0.0) : p.freq;
-                kc[j] = saw_const(f, sr, p.m, ms != nullptr, ms ? (live ? (double)ms[f0 + j] : 1.0) : 0.0);
+                double f = fs ? (live ? (double)fs_in[j] : 0.0) : p.freq;
+                kc[j] = saw_const(f, sr, p.m, ms != nullptr, ms ? (live ? (double)ms_in[j] : 1.0) : 0.0);
             } else {
                 kc[j] = k0;
             }
@@ -1171,7 +1185,7 @@ k_blitsaw(float *out, int64_t out_stride, int64_t n, int channels, double sr, co
             double z = leak * y;
             y = z + xb[j];
             double a = p.amp;
-            if (STREAMS && as) a = (INNER || f0 + j < n) ? (double)as[f0 + j] : 0.0;
+            if (STREAMS && as) a = (INNER || f0 + j < n) ? (double)as_in[STREAMS ? j : 0] : 0.0;
             yf[j] = (float)(y * (2.0 * a));                       // (y * 2) * a: the doubling is exact
             if (!INNER && f0 + j == n - 1) final_y = y;
         }
@@ -1663,10 +1677,25 @@ k_sine_stateful(float *out, int64_t n, int channels, double sr, const pgx_sine_s
         const int64_t f0 = base + (int64_t)tid * kSinT;
         double loc[kSinT];
         double run = 0.0;
+        // the control values of the thread's frames first, unconditionally (clamped index): behind the bounds test every
+        // load is waited for at once, one memory latency per value on a kernel that is one workgroup walking the block
+        float f_in[kSinT], pm_in[kSinT], a_in[kSinT];
+        if (freq) {
+#pragma unroll
+            for (int j = 0; j < kSinT; ++j) f_in[j] = freq[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (phase_mod) {
+#pragma unroll
+            for (int j = 0; j < kSinT; ++j) pm_in[j] = phase_mod[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (amp) {
+#pragma unroll
+            for (int j = 0; j < kSinT; ++j) a_in[j] = amp[(f0 + j < n) ? f0 + j : n - 1];
+        }
 #pragma unroll
         for (int j = 0; j < kSinT; ++j) {
             double f = p.freq;
-            if (freq) f = (f0 + j < n) ? (double)freq[f0 + j] : 0.0;
+            if (freq) f = (f0 + j < n) ? (double)f_in[j] : 0.0;
             double inc = (f0 + j < n) ? (two_pi * f) / sr : 0.0;
             run = run + inc;
             loc[j] = run;
@@ -1681,10 +1710,10 @@ k_sine_stateful(float *out, int64_t n, int channels, double sr, const pgx_sine_s
         for (int j = 0; j < kSinT; ++j) {
             double ph = (chunk_base + loc[j]) + initial;             // cumsum + initial_phase (:217)
             double pm = p.phase;
-            if (phase_mod) pm = (f0 + j < n) ? (double)phase_mod[f0 + j] : 0.0;
+            if (phase_mod) pm = (f0 + j < n) ? (double)pm_in[j] : 0.0;
             ph = ph + pm;                                            // + phase_mod (:220-223)
             double a = p.amp;
-            if (amp) a = (f0 + j < n) ? (double)amp[f0 + j] : 0.0;
+            if (amp) a = (f0 + j < n) ? (double)a_in[j] : 0.0;
             yf[j] = (float)(a * pgx::pgx_sin(ph));
             if (f0 + j == n - 1) {
                 final_phase = ph;
@@ -1998,10 +2027,24 @@ k_gate_stateful(float *out, int64_t n, double sr, double freq_scalar, double dut
         const int64_t f0 = base + (int64_t)tid * kGateT;
         double loc[kGateT];
         double run = 0.0;
+        // control values first, unconditionally (see k_sine_stateful)
+        float f_in[kGateT], ph_in[kGateT], d_in[kGateT];
+        if (freq) {
+#pragma unroll
+            for (int j = 0; j < kGateT; ++j) f_in[j] = freq[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (phase) {
+#pragma unroll
+            for (int j = 0; j < kGateT; ++j) ph_in[j] = phase[(f0 + j < n) ? f0 + j : n - 1];
+        }
+        if (duty) {
+#pragma unroll
+            for (int j = 0; j < kGateT; ++j) d_in[j] = duty[(f0 + j < n) ? f0 + j : n - 1];
+        }
 #pragma unroll
         for (int j = 0; j < kGateT; ++j) {
             loc[j] = run;                                             // exclusive within the chunk
-            const double f = freq ? ((f0 + j < n) ? (double)freq[f0 + j] : 0.0) : freq_scalar;
+            const double f = freq ? ((f0 + j < n) ? (double)f_in[j] : 0.0) : freq_scalar;
             run = run + ((f0 + j < n) ? f / sr : 0.0);
         }
         double tile_total;
@@ -2012,8 +2055,8 @@ k_gate_stateful(float *out, int64_t n, double sr, double freq_scalar, double dut
         for (int j = 0; j < kGateT; ++j) {
             if (f0 + j >= n) break;
             const double b = pgx::pgx_mod1(phase0 + (chunk_base + loc[j]));
-            const double ph = pgx::pgx_mod1(b + (phase ? (double)phase[f0 + j] : phase_scalar));
-            double d = duty ? (double)duty[f0 + j] : duty_scalar;
+            const double ph = pgx::pgx_mod1(b + (phase ? (double)ph_in[j] : phase_scalar));
+            double d = duty ? (double)d_in[j] : duty_scalar;
             d = d < 0.0 ? 0.0 : (d > 1.0 ? 1.0 : d);
             out[f0 + j] = (ph < d) ? 1.0f : 0.0f;
         }
