@@ -187,6 +187,17 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
                      const double *coef /* [batch][5] */, const double *tables, int64_t settle_frames,
                      double *state /* [batch][channels][2] */, void *workspace);
 
+/* BiquadPE(SinePE) with scalar parameters, mono (biquad_pe.py:383-404 over sine_pe.py:159-175): the sine is made
+ * in registers inside the single-launch filter kernel, so the chain writes 4 B per frame and reads nothing.
+ * w = (2 pi) f, amp, phase0 as in pgx_sine_params; start = first frame of the render.  Only where
+ * pgx_biquad_sine_supported(n, settle_frames) (the settled single-launch plan applies) and the phase stays below
+ * 2e9 rad; the caller renders the two PEs separately otherwise.  A thread's first frame is k_sine's sample bit for
+ * bit, its next 15 are that (sin, cos) pair turned by w / sr: within the rounding noise of the reference's phase. */
+int pgx_biquad_sine_supported(int64_t n, int64_t settle_frames);
+int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, double w, double amp, double phase0,
+                    const double *coef /* [5] */, const double *tables, int64_t settle_frames,
+                    double *state /* [2] */);
+
 /* Time-varying coefficients: _compute_coefficients per sample (biquad_pe.py:217-335) +
  * the direct-form-I recurrence of _biquad_varying_numba (biquad_pe.py:35-62).
  * freq/q: per-sample float32 control streams (frames,1) or NULL -> scalar.
@@ -397,13 +408,28 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
 size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t settle_frames);
 
 /* ------------------------------------------------------------------ CombPE
- * _comb_process_numba (comb_pe.py:26-113).  state = {write_pos, smoothed_freq(-1 = unset)};
- * ring = (buffer_len, channels) float64, zero at reset.  delay_scratch: n int32. */
-int pgx_comb(float *out, const float *in, int64_t n, int channels, double sample_rate,
-             double freq_scalar, double fb_scalar, const float *freq, const float *fb,
+ * _comb_process_numba (comb_pe.py:26-113): y[n] = x[n] + fb[n] * y[n - D[n]].
+ * ring = [batch][2][ring_rows][channels] float64, zero at reset: the last buffer_len outputs, double buffered --
+ * a render reads half `parity` and leaves the other half current; the write position on entering a render is
+ * total_frames mod buffer_len (total_frames = frames rendered since the reset, kept by the caller).
+ *  - scalar frequency (freq == NULL; any batch): params[v].delay = clip(rint(sr / max(max(f, min_f), 1)), 1,
+ *    buffer_len - 1) (comb_pe.py:70-77 on the settled smoother), delay_min / delay_max = its range over the batch.
+ *    fb (batch == 1) optionally streams the feedback.  Up to 1024 * delay frames the render is the reference's loop
+ *    operation for operation; beyond, time segments run concurrently (carries through a float64 affine fold).
+ *  - freq != NULL (batch == 1): the smoothed frequency is carried in state[0] (-1 = unset); delays come from a
+ *    time-parallel evaluation of the one-pole (comb_pe.py:61-77), the ring runs in LDS.  ring_rows = buffer_len. */
+typedef struct {
+    double feedback;       /* scalar feedback (clamped to +-0.995 by the kernels, non-finite -> 0) */
+    int32_t delay;         /* scalar-frequency delay in frames (unused with a frequency stream) */
+    int32_t buffer_len;    /* ceil(sr / min_frequency) + 1 rows (comb_pe.py:216-218) */
+} pgx_comb_params;
+int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
+             int channels, double sample_rate, const pgx_comb_params *params /* device [batch] */,
+             int delay_min, int delay_max, const float *freq, const float *fb /* batch == 1 */,
              double min_frequency, int64_t smoothing_samples,
-             double *ring, int64_t buffer_len, double *state /* [2] */,
-             int32_t *delay_scratch, double *fb_scratch);
+             double *ring, int64_t ring_rows, int64_t total_frames, int parity,
+             double *state /* [1], frequency stream only */, void *workspace);
+size_t pgx_comb_workspace_bytes(int batch, int64_t n, int channels, int delay_max, int freq_stream);
 
 /* ------------------------------------------------------------------ envelopes / gates
  * PeriodicGate (periodic_gate.py:63-67 over function_gen_pe.py:157-193, scalar params):

@@ -18,11 +18,16 @@ import math
 import numpy as np
 
 from . import device as _dev
+from . import diagnostics as _diag
 from ._kernels import DeviceBuffer, check, lib, new_output, ptr
 from .config import handle_error
 from .extent import Extent
 from .processing_element import ProcessingElement
+from .sine_pe import SinePE
 from .snippet import Snippet
+
+FUSE_SINE_SOURCE = True        # BiquadPE(SinePE): generate the sine inside the filter kernel (pgx_biquad_sine)
+SINE_FAST_RANGE = 2.0e9        # pgx_common.h kSinFastRange: beyond it the two PEs render separately
 
 
 class BiquadMode(Enum):
@@ -114,6 +119,26 @@ def settle_frames(a1: float, a2: float, limit: int = 1 << 16) -> int:
     return 0
 
 
+def _passes_more_signal_than_rounding(coef, omega: float, horizon: int) -> bool:
+    """The fused chain's sine samples are the separate SinePE's to within the rounding noise of the reference's own
+    phase, but not always the same float32: a sample that rounds the other way is an impulse of one float32 ulp
+    (6e-8 of the amplitude) into the filter.  The filter answers it with at most 6e-8 * sum|h| while the tone comes
+    out with gain |H(e^jw)|: fusing is allowed when that leaves the error below ~1e-6 of the output's peak (a
+    high-pass far above the tone, which passes the rounding noise and little else, keeps the two-launch path whose
+    float32 sine is the reference's)."""
+    b0, b1, b2, a1, a2 = coef
+    z1 = np.exp(-1j * omega)
+    gain = abs((b0 + b1 * z1 + b2 * z1 * z1) / (1.0 + a1 * z1 + a2 * z1 * z1))
+    s0 = s1 = 0.0                                    # DF-II-T impulse response, sum of magnitudes
+    l1, x = 0.0, 1.0
+    for _ in range(max(16, min(int(horizon), 8192))):
+        y = s0 + b0 * x
+        s0, s1 = s1 + b1 * x - a1 * y, b2 * x - a2 * y
+        l1 += abs(y)
+        x = 0.0
+    return bool(np.isfinite(gain) and np.isfinite(l1) and gain >= 0.05 * l1)
+
+
 class BiquadPE(ProcessingElement):
     _PASSES_BLOCKS = True              # look_ahead.py: inputs are pulled with the caller's (duration)
     _LOOK_AHEAD_SAFE = True            # look_ahead.py: block-partition invariant, state listed below
@@ -129,6 +154,8 @@ class BiquadPE(ProcessingElement):
         self._freq_is_pe = isinstance(frequency, ProcessingElement)
         self._q_is_pe = isinstance(q, ProcessingElement)
         self._coef: DeviceBuffer | None = None        # [5] float64 (constant path)
+        self._coef_host = None
+        self._sine_fuse_ok = None                     # _passes_more_signal_than_rounding, evaluated once
         self._settle = 0                              # settle_frames of the constant section
         self._tables: DeviceBuffer | None = None      # its power tables (single-launch path)
         self._params: DeviceBuffer | None = None      # pgx_biquad_var_params (varying path)
@@ -179,7 +206,45 @@ class BiquadPE(ProcessingElement):
             self._state = DeviceBuffer((channels, per), np.float64, zero=True)
             self._state_channels = channels
 
+    def _prepare_constant(self, L, sr: float) -> None:
+        if self._coef is None:
+            coef = rbj_coefficients(self._mode, self._frequency, self._q, self._gain_db, sr)
+            self._coef = DeviceBuffer.from_host(np.asarray(coef, dtype=np.float64))
+            self._coef_host = tuple(float(c) for c in coef)
+            self._settle = settle_frames(coef[3], coef[4])
+            if self._settle:
+                self._tables = DeviceBuffer((L.pgx_biquad_table_doubles(),), np.float64)
+                check(L.pgx_biquad_tables(self._tables.ptr, self._coef.ptr, 1), "pgx_biquad_tables")
+
+    def _render_sine_source(self, start: int, duration: int):
+        """BiquadPE(SinePE) with scalar parameters, mono, long block: the sine is generated inside the filter kernel
+        (pgx_biquad_sine): one launch, 4 B per frame.  None when the chain does not qualify."""
+        src = self._source
+        if (not FUSE_SINE_SOURCE or self._freq_is_pe or self._q_is_pe or type(src) is not SinePE
+                or src._has_pe_inputs() or src._channels != 1 or _diag.is_enabled()):
+            return None
+        L = lib()
+        sr = float(self.sample_rate)
+        self._prepare_constant(L, sr)
+        if not self._settle or not L.pgx_biquad_sine_supported(duration, self._settle):
+            return None
+        w = 2.0 * np.pi * float(src._frequency)                      # sine_pe.py: (2 pi) f, left to right
+        if self._sine_fuse_ok is None:
+            self._sine_fuse_ok = _passes_more_signal_than_rounding(self._coef_host, w / sr, self._settle)
+        if not self._sine_fuse_ok:
+            return None
+        if abs(float(src._phase)) + abs(w) * ((abs(start) + duration) / sr) >= SINE_FAST_RANGE:
+            return None
+        self._ensure_state(1)
+        out = new_output(duration, 1)
+        check(L.pgx_biquad_sine(out.ptr, start, duration, sr, w, float(src._amplitude), float(src._phase),
+                                self._coef.ptr, self._tables.ptr, self._settle, self._state.ptr), "pgx_biquad_sine")
+        return Snippet(start, out)
+
     def _render(self, start: int, duration: int) -> Snippet:
+        fused = self._render_sine_source(start, duration)
+        if fused is not None:
+            return fused
         src = self._source.render(start, duration)
         ch = src.channels
         self._ensure_state(ch)
@@ -187,13 +252,7 @@ class BiquadPE(ProcessingElement):
         L = lib()
         sr = float(self.sample_rate)
         if not self._freq_is_pe and not self._q_is_pe:
-            if self._coef is None:
-                coef = rbj_coefficients(self._mode, self._frequency, self._q, self._gain_db, sr)
-                self._coef = DeviceBuffer.from_host(np.asarray(coef, dtype=np.float64))
-                self._settle = settle_frames(coef[3], coef[4])
-                if self._settle:
-                    self._tables = DeviceBuffer((L.pgx_biquad_table_doubles(),), np.float64)
-                    check(L.pgx_biquad_tables(self._tables.ptr, self._coef.ptr, 1), "pgx_biquad_tables")
+            self._prepare_constant(L, sr)
             if self._ws_key != (duration, ch):
                 self._ws_need = L.pgx_biquad_workspace_bytes(1, duration, ch, self._settle)
                 self._ws_key = (duration, ch)

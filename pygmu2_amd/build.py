@@ -24,6 +24,7 @@ SOURCES = [
     "pgx_elementwise.hip",
     "pgx_scan.hip",
     "pgx_seq.hip",
+    "pgx_comb.hip",
     "pgx_adsr.hip",
     "pgx_convolve.hip",
     "pgx_lookup.hip",

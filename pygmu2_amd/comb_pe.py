@@ -1,14 +1,17 @@
 """
 CombPE: feedback comb y[n] = x[n] + fb * y[n - D], D = round(sr / smoothed_freq)
-(comb_pe.py:124-349).  The delay line is a float64 ring buffer in HBM; the integer delay
-sequence comes from the reference's exact one-pole smoothing recurrence, then samples
-that do not reach into their own chunk are processed in parallel (pgx_comb).
+(comb_pe.py:124-349).  With a scalar frequency the delay is one integer: the comb is D independent
+first-order recurrences that run lane-parallel (and, on long renders, in concurrent time segments);
+the float64 ring only carries the last outputs from one render to the next.  With a frequency PE the
+delays come from a time-parallel evaluation of the reference's one-pole and the ring runs in LDS
+(csrc/pgx_comb.hip).
 """
 
 from __future__ import annotations
 
 import numpy as np
 
+from . import device as _dev
 from ._kernels import DeviceBuffer, check, lib, new_output, ptr
 from .extent import Extent
 from .processing_element import ProcessingElement
@@ -17,7 +20,7 @@ from .snippet import Snippet
 
 class CombPE(ProcessingElement):
     _LOOK_AHEAD_SAFE = True            # look_ahead.py
-    _STATE_FIELDS = ("_ring", "_state", "_buffer_len")
+    _STATE_FIELDS = ("_ring", "_state", "_buffer_len", "_total", "_parity")
 
     _MAX_FEEDBACK = 0.995
 
@@ -30,9 +33,13 @@ class CombPE(ProcessingElement):
         self._smoothing_samples = max(1, int(smoothing_samples))
         self._freq_is_pe = isinstance(frequency, ProcessingElement)
         self._fb_is_pe = isinstance(feedback, ProcessingElement)
-        self._ring: DeviceBuffer | None = None       # (buffer_len, C) float64
-        self._state: DeviceBuffer | None = None      # {write_pos, smoothed_freq}
+        self._ring: DeviceBuffer | None = None       # (2, buffer_len, C) float64: the half `_parity` is current
+        self._state: DeviceBuffer | None = None      # {smoothed_freq} (frequency PE only)
         self._buffer_len = 0
+        self._total = 0                              # frames rendered since the reset: write_pos = total % buffer_len
+        self._parity = 0
+        self._params: DeviceBuffer | None = None
+        self._ws: DeviceBuffer | None = None
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -60,11 +67,30 @@ class CombPE(ProcessingElement):
             ext = ext.intersection(self._feedback.extent()) or ext
         return ext
 
+    def _buffer_rows(self) -> int:
+        max_delay = int(np.ceil(self.sample_rate / self._min_frequency))      # comb_pe.py:216-218
+        return max(2, max_delay + 1)
+
+    def _scalar_delay(self) -> int:
+        """comb_pe.py:61-77 for a scalar frequency: the smoother equals its input from the first sample on."""
+        raw = max(float(self._frequency), self._min_frequency)
+        d = int(np.rint(float(self.sample_rate) / max(raw, 1.0)))             # np.round: half to even
+        return min(max(d, 1), self._buffer_rows() - 1)
+
+    def _param_record(self) -> np.ndarray:
+        rec = np.zeros(1, dtype=_dev.COMB_PARAMS)
+        rec[0] = (0.0 if self._fb_is_pe else float(self._feedback),
+                  0 if self._freq_is_pe else self._scalar_delay(), self._buffer_rows())
+        return rec
+
     def _allocate(self, channels: int) -> None:
-        max_delay = int(np.ceil(self.sample_rate / self._min_frequency))
-        self._buffer_len = max(2, max_delay + 1)
-        self._ring = DeviceBuffer((self._buffer_len, channels), np.float64, zero=True)
-        self._state = DeviceBuffer.from_host(np.array([0.0, -1.0], dtype=np.float64))
+        self._buffer_len = self._buffer_rows()
+        self._ring = DeviceBuffer((2, self._buffer_len, channels), np.float64, zero=True)
+        self._state = DeviceBuffer.from_host(np.array([-1.0], dtype=np.float64))
+        self._total = 0
+        self._parity = 0
+        if self._params is None:
+            self._params = _dev.upload_structs(self._param_record())
 
     def _on_start(self) -> None:
         self._allocate(self._source.channel_count() or 1)
@@ -76,18 +102,23 @@ class CombPE(ProcessingElement):
     def _render(self, start: int, duration: int) -> Snippet:
         src = self._source.render(start, duration)
         ch = src.channels
-        if self._ring is None or self._ring.shape[1] != ch:
+        if self._ring is None or self._ring.shape[2] != ch:
             self._allocate(ch)
         f_s, f_buf = self._control_stream(self._frequency, start, duration)
         b_s, b_buf = self._control_stream(self._feedback, start, duration)
-        delay = DeviceBuffer((duration,), np.int32)
-        fbv = DeviceBuffer((duration,), np.float64)
+        L = lib()
+        delay = 0 if self._freq_is_pe else self._scalar_delay()
+        need = L.pgx_comb_workspace_bytes(1, duration, ch, delay, 1 if self._freq_is_pe else 0)
+        if need and (self._ws is None or self._ws.nbytes < need):
+            self._ws = DeviceBuffer((need,), np.uint8)
         out = new_output(duration, ch)
-        check(lib().pgx_comb(out.ptr, src.dev.ptr, duration, ch, float(self.sample_rate),
-                             0.0 if f_s is None else f_s, 0.0 if b_s is None else b_s,
-                             ptr(f_buf), ptr(b_buf), self._min_frequency, self._smoothing_samples,
-                             self._ring.ptr, self._buffer_len, self._state.ptr, delay.ptr, fbv.ptr),
+        check(L.pgx_comb(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate), self._params.ptr,
+                         delay, delay, ptr(f_buf), ptr(b_buf), self._min_frequency, self._smoothing_samples,
+                         self._ring.ptr, self._buffer_len, self._total, self._parity, self._state.ptr,
+                         ptr(self._ws) if need else None),
               "pgx_comb")
+        self._total += duration
+        self._parity ^= 1
         return Snippet(start, out)
 
     def __repr__(self) -> str:

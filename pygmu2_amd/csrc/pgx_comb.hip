@@ -1,0 +1,452 @@
+// pgx_comb.hip -- CombPE: y[n] = x[n] + fb[n] * y[n - D[n]]  (comb_pe.py:26-113, _comb_process_numba).
+//
+// Two data paths, chosen by what drives the delay:
+//
+// (1) scalar frequency (the reference's examples/16_comb_filter.py, every bank): the one-pole smoother sits on its
+//     input from the first sample on, so D is ONE integer the host derives with the reference's expression.  A comb
+//     with a fixed delay is D independent first-order recurrences (one per residue n mod D): lane j owns the frames
+//     j, j + D, j + 2D ... of a time segment, keeps its previous output in a register and never meets another lane --
+//     no ring traffic, no barrier.  Long renders are cut into segments of m*D frames that run concurrently:
+//     k_comb_poly<REDUCE> leaves every (segment, lane)'s zero-state response Z and feedback product P, and
+//     k_comb_poly<APPLY> folds the earlier segments' (P, Z) onto the value the ring holds for the lane and then runs
+//     its frames in the reference's operation order (multiply, add; no fused multiply-add).  Up to 1024 steps per
+//     lane the render is one segment and one launch: bit for bit the reference's loop.
+//     The ring (float64, buffer_len rows) only carries the last buffer_len outputs from one render to the next.  It
+//     is double buffered ([2][rows][channels], `parity` names the half to read): lanes that finish early write the
+//     new half while late lanes still read their carry-in from the old one.
+//
+// (2) frequency from a PE: k_comb_delays turns the control stream into integer delays with a time-parallel scan of
+//     the one-pole (the literal update on each thread's samples, affine composition across threads), then
+//     k_comb_ring runs one workgroup per channel with the ring in LDS: chunks of samples that do not reach into
+//     themselves (chunk length from a sliding minimum of the delays made by k_comb_delays -- no search in the loop)
+//     are read, computed and written by the lanes at once, one barrier per chunk; samples, delays and feedback are
+//     staged through LDS tile by tile so that the chunk loop never waits for HBM.
+#include "pgx_common.h"
+
+namespace {
+
+constexpr double kMaxFeedback = 0.995;                  // comb_pe.py:32 (max_feedback passed by _render)
+constexpr int kPolySingleSteps = 1024;                  // up to this many steps per lane: one segment (exact)
+constexpr int kPolySegSteps = 64;                       // steps per lane and segment when segmented
+constexpr int kPolyMaxSeg = 512;                        // the apply pass folds up to this many (P, Z) pairs per lane
+
+__device__ __forceinline__ double comb_fb(double f) {   // comb_pe.py:87-95
+    f = isfinite(f) ? f : 0.0;
+    f = f > kMaxFeedback ? kMaxFeedback : f;
+    f = f < -kMaxFeedback ? -kMaxFeedback : f;
+    return f;
+}
+
+struct PolyPlan {
+    int64_t steps;      // steps per lane and segment (the last segment may be shorter)
+    int nseg;
+};
+__host__ __device__ inline PolyPlan poly_plan(int64_t n, int64_t d) {
+    const int64_t total = (n + d - 1) / d;              // steps of the longest chain
+    if (total <= kPolySingleSteps) return PolyPlan{total, 1};
+    int64_t m = kPolySegSteps;
+    const int64_t need = (total + kPolyMaxSeg - 1) / kPolyMaxSeg;
+    if (m < need) m = need;
+    return PolyPlan{m, (int)((total + m - 1) / m)};
+}
+
+// Workspace of one chain bundle (one voice): [nseg][D*C] pairs (P, Z) as two planes.
+__host__ __device__ inline int64_t poly_ws_doubles(int64_t n, int channels, int64_t d_max) {
+    // nseg * D <= n / steps + D  <=  n / kPolySegSteps + 2 * D
+    return 2 * (int64_t)channels * (n / kPolySegSteps + 2 * d_max + 64);
+}
+
+enum { COMB_REDUCE = 0, COMB_APPLY = 1 };
+
+template <int PASS, bool FBS>
+__global__ void __launch_bounds__(256)
+k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, int64_t n, int channels,
+            const pgx_comb_params *params, const float *fbs, double *ring, int64_t ring_rows, int64_t total_frames,
+            int parity, double *ws, int64_t ws_stride) {
+    const int voice = blockIdx.y;
+    const pgx_comb_params prm = params[voice];
+    const int64_t D = prm.delay, len = prm.buffer_len;
+    const int64_t DC = D * channels;
+    const PolyPlan plan = poly_plan(n, D);
+    const int64_t lanes_total = (int64_t)gridDim.x * 256;
+    const int64_t L = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double *P = ws + (int64_t)voice * ws_stride;
+    double *Z = P + ws_stride / 2;
+    const float *x = in + (int64_t)voice * in_stride;
+    const int64_t seg_frames = plan.steps * D;
+    const double fbc = comb_fb(prm.feedback);
+
+    if (PASS == COMB_REDUCE) {
+        if (L >= (int64_t)(plan.nseg - 1) * DC) return;           // the last segment has no successor
+        const int64_t seg = L / DC, chain = L - seg * DC;
+        const int64_t r = chain / channels;
+        const int64_t e0 = seg * seg_frames * channels + chain;   // first element of the lane
+        const int64_t f0 = seg * seg_frames + r;
+        double z = 0.0, p = 1.0;
+        constexpr int U = 8;
+        for (int64_t k0 = 0; k0 < plan.steps; k0 += U) {
+            float xv[U], fv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = (k0 + u < plan.steps) ? k0 + u : plan.steps - 1;
+                xv[u] = x[e0 + k * DC];
+                fv[u] = FBS ? fbs[f0 + k * D] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < plan.steps) {
+                    const double f = FBS ? comb_fb((double)fv[u]) : fbc;
+                    z = __builtin_fma(f, z, (double)xv[u]);       // feeds carries only: fused
+                    p *= f;
+                }
+            }
+        }
+        P[L] = p;
+        Z[L] = z;
+        return;
+    }
+
+    // ---- APPLY
+    const double *ring_old = ring + ((int64_t)voice * 2 + parity) * ring_rows * channels;
+    double *ring_new = ring + ((int64_t)voice * 2 + (parity ^ 1)) * ring_rows * channels;
+    const int64_t wp0 = total_frames % len;
+    // rows this render does not overwrite travel to the new half as they are
+    if (n < len) {
+        for (int64_t idx = L; idx < (len - n) * channels; idx += lanes_total) {
+            const int64_t row = (wp0 + n + idx / channels) % len, ch = idx % channels;
+            ring_new[row * channels + ch] = ring_old[row * channels + ch];
+        }
+    }
+    if (L >= (int64_t)plan.nseg * DC) return;
+    const int64_t seg = L / DC, chain = L - seg * DC;
+    const int64_t r = chain / channels, ch = chain - r * channels;
+    int64_t row = (wp0 + r - D) % len;
+    if (row < 0) row += len;
+    double c = ring_old[row * channels + ch];
+    for (int64_t t = 0; t < seg; ++t) c = __builtin_fma(P[t * DC + chain], c, Z[t * DC + chain]);
+
+    float *y = out + (int64_t)voice * out_stride;
+    const int64_t f0 = seg * seg_frames + r;                      // first frame of the lane
+    int64_t steps = plan.steps;
+    if (f0 >= n) steps = 0;
+    else if (f0 + (steps - 1) * D >= n) steps = (n - 1 - f0) / D + 1;
+    const int64_t keep_from = n - len;                            // frames from here on stay in the ring
+    int64_t slot = (wp0 + f0) % len;                              // ring row of the lane's current frame
+    constexpr int U = 8;
+    for (int64_t k0 = 0; k0 < steps; k0 += U) {
+        float xv[U], fv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = (k0 + u < steps) ? k0 + u : steps - 1;
+            xv[u] = x[(f0 + k * D) * channels + ch];
+            fv[u] = FBS ? fbs[f0 + k * D] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < steps) {
+                const int64_t i = f0 + (k0 + u) * D;
+                const double f = FBS ? comb_fb((double)fv[u]) : fbc;
+                const double v = (double)xv[u] + f * c;           // comb_pe.py:97 (multiply, then add)
+                y[i * channels + ch] = (float)v;
+                if (i >= keep_from) ring_new[slot * channels + ch] = v;
+                slot += D;
+                slot = slot >= len ? slot - len : slot;
+                c = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ PE-driven frequency
+constexpr int kCtlThreads = 1024, kCtlT = 4, kCtlTile = kCtlThreads * kCtlT;
+
+// One workgroup.  delay[i] = clip(rint(sr / max(sm_i, 1)), 1, len - 1) with sm the one-pole of comb_pe.py:61-68;
+// gmin / gmax[g] = min / max of the delays of samples [64 g, 64 g + 64).  state[0] = smoothed frequency (-1: unset).
+__global__ void __launch_bounds__(kCtlThreads)
+k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, double alpha, int64_t len, double *state,
+              int32_t *delay, int32_t *gmin, int32_t *gmax) {
+    __shared__ double s_wave[kCtlThreads / 64];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the homogeneous factor of kCtlT literal steps, its powers along a wave, and the factor of a whole wave
+    double at = 1.0;
+#pragma unroll
+    for (int j = 0; j < kCtlT; ++j) at = at + (0.0 - at) * alpha;
+    double pw[6];
+    pw[0] = at;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) pw[k] = pw[k - 1] * pw[k - 1];
+    const double aw = pw[5] * pw[5];                              // at^64
+    double plane = 1.0;                                           // at^lane
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (lane & (1 << k)) plane *= pw[k];
+    if (tid == 0) {
+        double c = state[0];
+        if (c < 0.0) {                                            // first sample ever: smoothed = raw (comb_pe.py:65-66)
+            c = (double)freq[0];
+            c = c < min_frequency ? min_frequency : c;
+        }
+        s_carry = c;
+    }
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += kCtlTile) {
+        const int64_t i0 = base + (int64_t)tid * kCtlT;
+        double raw[kCtlT];
+#pragma unroll
+        for (int j = 0; j < kCtlT; ++j) {
+            const int64_t i = i0 + j < n ? i0 + j : n - 1;
+            const double v = (double)freq[i];
+            raw[j] = v < min_frequency ? min_frequency : v;
+        }
+        double z = 0.0;
+#pragma unroll
+        for (int j = 0; j < kCtlT; ++j) z = z + (raw[j] - z) * alpha;
+        double v = z;                                             // inclusive scan along the wave: v_t = z_t + at v_(t-1)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double u = __shfl_up(v, 1 << k);
+            if (lane >= (1 << k)) v = __builtin_fma(pw[k], u, v);
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();
+        double c = s_carry;
+        for (int w = 0; w < wave; ++w) c = __builtin_fma(aw, c, s_wave[w]);
+        double e = __shfl_up(v, 1);
+        if (lane == 0) e = 0.0;
+        double sm = __builtin_fma(plane, c, e);                   // level on entering this thread's samples
+        int dmin = 0x7fffffff, dmax = 0;
+#pragma unroll
+        for (int j = 0; j < kCtlT; ++j) {
+            sm = sm + (raw[j] - sm) * alpha;                      // comb_pe.py:68
+            const double f = sm < 1.0 ? 1.0 : sm;
+            int64_t d = (int64_t)rint(sr / f);                    // np.round: half to even
+            d = d < 1 ? 1 : d;
+            d = d >= len ? len - 1 : d;
+            if (i0 + j < n) {
+                delay[i0 + j] = (int32_t)d;
+                dmin = min(dmin, (int)d);
+                dmax = max(dmax, (int)d);
+                if (i0 + j == n - 1) state[0] = sm;
+            }
+        }
+#pragma unroll
+        for (int s = 1; s < 64 / kCtlT; s <<= 1) {
+            dmin = min(dmin, __shfl_xor(dmin, s));
+            dmax = max(dmax, __shfl_xor(dmax, s));
+        }
+        if ((tid & (64 / kCtlT - 1)) == 0 && i0 < n) {
+            gmin[i0 >> 6] = dmin;
+            gmax[i0 >> 6] = dmax;
+        }
+        __syncthreads();                                          // s_wave / s_carry read by everyone
+        if (tid == kCtlThreads - 1) s_carry = sm;
+        __syncthreads();
+    }
+}
+
+constexpr int kRingThreads = 512, kRingTile = 2048, kRingGroups = kRingTile / 64, kRingPer = kRingTile / kRingThreads;
+
+// One workgroup per channel.  RING_LDS: the ring lives in LDS (dynamic shared memory, `len` doubles); otherwise in the
+// new half of the global ring (min_frequency so low that it does not fit).
+template <bool RING_LDS, bool FBS>
+__global__ void __launch_bounds__(kRingThreads)
+k_comb_ring(float *out, const float *in, int64_t n, int channels, const double *ring_old, double *ring_new,
+            int64_t len, int64_t wp0, const int32_t *delay, const int32_t *gmin, const int32_t *gmax,
+            const pgx_comb_params *params, const float *fbs) {
+    extern __shared__ double s_dyn[];
+    __shared__ float s_x[kRingTile];
+    __shared__ int32_t s_d[kRingTile];
+    __shared__ float s_f[FBS ? kRingTile : 1];
+    __shared__ int32_t s_gmin[kRingGroups + 16], s_gmax[kRingGroups + 16], s_chunk[kRingGroups];
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    double *ring = RING_LDS ? s_dyn : ring_new;
+    const int64_t rs = RING_LDS ? 1 : channels;                   // row stride
+    const int64_t ro = RING_LDS ? 0 : ch;
+    for (int64_t r = tid; r < len; r += kRingThreads) ring[r * rs + ro] = ring_old[r * channels + ch];
+    const double fbc = FBS ? 0.0 : comb_fb(params[0].feedback);
+    const int64_t groups_total = (n + 63) >> 6;
+    int64_t wp = wp0;
+    // a tile's samples, delays and feedback travel HBM -> registers while the tile before it is in the chunk loop
+    float xr[kRingPer], fr[kRingPer];
+    int32_t dr[kRingPer], gl = 0x7fffffff, gh = 0;
+    auto fetch = [&](int64_t tb) {
+#pragma unroll
+        for (int k = 0; k < kRingPer; ++k) {
+            int64_t i = tb + tid + k * kRingThreads;
+            i = i < n ? i : n - 1;
+            xr[k] = in[i * channels + ch];
+            dr[k] = delay[i];
+            fr[k] = FBS ? fbs[i] : 0.f;
+        }
+        int64_t g = (tb >> 6) + tid;
+        const bool live = tid < kRingGroups + 16 && g < groups_total;
+        g = g < groups_total ? g : groups_total - 1;
+        const int32_t a = gmin[g], b = gmax[g];
+        gl = live ? a : 0x7fffffff;
+        gh = live ? b : 0;
+    };
+    fetch(0);
+    for (int64_t tb = 0; tb < n; tb += kRingTile) {
+        const int tl = (int)((n - tb) < kRingTile ? (n - tb) : kRingTile);
+        __syncthreads();                                          // the previous tile's chunks are done with s_*
+#pragma unroll
+        for (int k = 0; k < kRingPer; ++k) {
+            const int idx = tid + k * kRingThreads;
+            s_x[idx] = xr[k];
+            s_d[idx] = dr[k];
+            if (FBS) s_f[idx] = fr[k];
+        }
+        if (tid < kRingGroups + 16) {
+            s_gmin[tid] = gl;
+            s_gmax[tid] = gh;
+        }
+        __syncthreads();
+        if (tb + kRingTile < n) fetch(tb + kRingTile);
+        // chunk length for a chunk that starts anywhere in group g: it covers at most kRingThreads samples = the groups
+        // g .. g + kRingThreads / 64: no sample may reach into the chunk (S <= min D) nor wrap onto a slot the chunk
+        // writes (S <= len - max D)
+        if (tid < kRingGroups) {
+            int lo = 0x7fffffff, hi = 0;
+#pragma unroll
+            for (int k = 0; k <= kRingThreads / 64; ++k) {
+                lo = min(lo, s_gmin[tid + k]);
+                hi = max(hi, s_gmax[tid + k]);
+            }
+            const int s = min(lo, (int)(len - hi));
+            s_chunk[tid] = min(max(s, 1), kRingThreads);
+        }
+        __syncthreads();
+        int p = 0;
+        while (p < tl) {
+            int S = s_chunk[p >> 6];
+            S = min(S, tl - p);
+            if (tid < S) {
+                const int i = p + tid;
+                int64_t rp = wp + tid - s_d[i];
+                rp = rp < 0 ? rp + len : rp;
+                const double f = FBS ? comb_fb((double)s_f[i]) : fbc;
+                const double v = (double)s_x[i] + f * ring[rp * rs + ro];     // comb_pe.py:97
+                out[(tb + i) * channels + ch] = (float)v;
+                int64_t w = wp + tid;
+                w = w >= len ? w - len : w;
+                ring[w * rs + ro] = v;
+            }
+            __syncthreads();
+            wp += S;
+            wp = wp >= len ? wp - len : wp;
+            p += S;
+        }
+    }
+    if (RING_LDS) {
+        __syncthreads();
+        for (int64_t r = tid; r < len; r += kRingThreads) ring_new[r * channels + ch] = ring[r];
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+size_t pgx_comb_workspace_bytes(int batch, int64_t n, int channels, int delay_max, int freq_stream) {
+    if (batch <= 0 || n <= 0 || channels <= 0) return 0;
+    if (freq_stream) return (size_t)(n + 2 * ((n + 63) / 64) + 64) * sizeof(int32_t);
+    if (delay_max < 1) return 0;
+    return (size_t)batch * (size_t)poly_ws_doubles(n, channels, delay_max) * sizeof(double);
+}
+
+int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n, int channels,
+             double sample_rate, const pgx_comb_params *params, int delay_min, int delay_max, const float *freq,
+             const float *fb, double min_frequency, int64_t smoothing_samples, double *ring, int64_t ring_rows,
+             int64_t total_frames, int parity, double *state, void *workspace) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && in && ring && channels >= 1 && sample_rate > 0 && ring_rows >= 2 && total_frames >= 0 &&
+                      (parity == 0 || parity == 1),
+                  "pgx_comb: bad argument");
+    PGX_CHECK_ARG(batch == 1 || (out_stride >= n * channels && in_stride >= n * channels),
+                  "pgx_comb: voice stride too small");
+    PGX_CHECK_ARG(batch == 1 || (!freq && !fb), "pgx_comb: per-sample control streams require batch == 1");
+    if (freq) {
+        // ---- delays from the control stream, then the ring in LDS
+        PGX_CHECK_ARG(state && workspace && smoothing_samples >= 1 && min_frequency >= 1.0,
+                      "pgx_comb: frequency stream needs state, workspace, smoothing_samples >= 1");
+        const int64_t len = ring_rows;
+        int32_t *delay = (int32_t *)workspace;
+        int32_t *gmin = delay + n, *gmax = gmin + (n + 63) / 64;
+        hipLaunchKernelGGL(k_comb_delays, dim3(1), dim3(kCtlThreads), 0, pgx::stream(), n, sample_rate, freq,
+                           min_frequency, 1.0 / (double)smoothing_samples, len, state, delay, gmin, gmax);
+        PGX_LAUNCH_CHECK("k_comb_delays");
+        const double *ring_old = ring + (int64_t)parity * ring_rows * channels;
+        double *ring_new = ring + (int64_t)(parity ^ 1) * ring_rows * channels;
+        const int64_t wp0 = total_frames % len;
+        const size_t lds = (size_t)len * sizeof(double);
+        const bool in_lds = lds <= 96 * 1024;
+        if (in_lds && lds > 32 * 1024) {
+            static bool allowed[2] = {false, false};
+            if (!allowed[fb ? 1 : 0]) {
+                const void *fn = fb ? reinterpret_cast<const void *>(k_comb_ring<true, true>)
+                                    : reinterpret_cast<const void *>(k_comb_ring<true, false>);
+                PGX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                allowed[fb ? 1 : 0] = true;
+            }
+        }
+#define PGX_RING(LDS, FBS)                                                                                        \
+    hipLaunchKernelGGL((k_comb_ring<LDS, FBS>), dim3(channels), dim3(kRingThreads), (LDS) ? lds : 0, pgx::stream(), \
+                       out, in, n, channels, ring_old, ring_new, len, wp0, (const int32_t *)delay,                \
+                       (const int32_t *)gmin, (const int32_t *)gmax, params, fb)
+        PGX_CHECK_ARG(fb || params, "pgx_comb: params required for a scalar feedback");
+        if (in_lds) {
+            if (fb) PGX_RING(true, true);
+            else PGX_RING(true, false);
+        } else {
+            if (fb) PGX_RING(false, true);
+            else PGX_RING(false, false);
+        }
+#undef PGX_RING
+        PGX_LAUNCH_CHECK("k_comb_ring");
+        return PGX_OK;
+    }
+    // ---- scalar frequency: polyphase chains
+    PGX_CHECK_ARG(params && delay_min >= 1 && delay_max >= delay_min && delay_max < ring_rows,
+                  "pgx_comb: bad delay range");
+    const PolyPlan worst = poly_plan(n, delay_min);               // most segments
+    int64_t lanes = 0;                                            // the widest voice
+    {
+        const PolyPlan a = poly_plan(n, delay_min), b = poly_plan(n, delay_max);
+        const int64_t la = (int64_t)a.nseg * delay_min, lb = (int64_t)b.nseg * delay_max;
+        // nseg * D is not monotonic in D; bound it: nseg * D <= n / steps + D
+        lanes = (la > lb ? la : lb);
+        const int64_t bound = n / kPolySegSteps + 2 * (int64_t)delay_max;
+        if (delay_min != delay_max) lanes = bound;
+        lanes *= channels;
+    }
+    const int64_t ws_stride = poly_ws_doubles(n, channels, delay_max);
+    const bool segmented = worst.nseg > 1 || poly_plan(n, delay_max).nseg > 1;
+    PGX_CHECK_ARG(!segmented || workspace != nullptr, "pgx_comb: workspace required for segmented renders");
+    const dim3 grid((unsigned)pgx::ceil_div(lanes, 256), (unsigned)batch);
+    if (segmented) {
+        if (fb)
+            hipLaunchKernelGGL((k_comb_poly<COMB_REDUCE, true>), grid, dim3(256), 0, pgx::stream(), out, out_stride, in,
+                               in_stride, n, channels, params, fb, ring, ring_rows, total_frames, parity,
+                               (double *)workspace, ws_stride);
+        else
+            hipLaunchKernelGGL((k_comb_poly<COMB_REDUCE, false>), grid, dim3(256), 0, pgx::stream(), out, out_stride,
+                               in, in_stride, n, channels, params, fb, ring, ring_rows, total_frames, parity,
+                               (double *)workspace, ws_stride);
+        PGX_LAUNCH_CHECK("k_comb_poly<reduce>");
+    }
+    if (fb)
+        hipLaunchKernelGGL((k_comb_poly<COMB_APPLY, true>), grid, dim3(256), 0, pgx::stream(), out, out_stride, in,
+                           in_stride, n, channels, params, fb, ring, ring_rows, total_frames, parity,
+                           (double *)workspace, ws_stride);
+    else
+        hipLaunchKernelGGL((k_comb_poly<COMB_APPLY, false>), grid, dim3(256), 0, pgx::stream(), out, out_stride, in,
+                           in_stride, n, channels, params, fb, ring, ring_rows, total_frames, parity,
+                           (double *)workspace, ws_stride);
+    PGX_LAUNCH_CHECK("k_comb_poly<apply>");
+    return PGX_OK;
+}
+
+}  // extern "C"

@@ -655,11 +655,21 @@ __device__ __forceinline__ V2 mv_add_fma(const M2 &p, const V2 &v, const V2 &q) 
               __builtin_fma(p.c, v.x, __builtin_fma(p.d, v.y, q.y))};
 }
 
-template <bool MONO, bool STAGED>
+// SINE: the input is a pure SinePE (sine_pe.py:159-175) generated in registers instead of read from HBM: the chain
+// BiquadPE(SinePE) then moves 4 B per frame (its output) in one launch.  A thread's first frame is evaluated exactly
+// as k_sine evaluates it (phase0 + w * (n / sr), pgx_sincos_bounded); its other 15 frames turn that (sin, cos) pair
+// by the fixed angle w / sr (two multiplies and two fused multiply-adds per frame, error ~1e-16 per step).  The
+// reference's own phase carries ~ulp(phase) of rounding noise per sample; the rotated samples sit inside it.
+struct SbSine {
+    double w, amp, phase0, sr, inv_sr, cos_d, sin_d;
+    int64_t start;
+};
+
+template <bool MONO, bool STAGED, bool SINE = false>
 __global__ void __launch_bounds__(kSbBlock, MONO ? 4 : 2)
 k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__restrict__ in, int64_t in_stride,
                  int64_t n, int channels_arg, const double *__restrict__ coef, const double *__restrict__ tables,
-                 double *state, int seg, int head, int tail, int warm, int groups) {
+                 double *state, int seg, int head, int tail, int warm, int groups, SbSine sine = SbSine{}) {
     __shared__ SbShared sh;
     __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? kSbWaves * kStageWords : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -678,7 +688,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
     float *wlds = stage_lds + (STAGED ? wave * kStageWords : 0);
     // STAGED (mono only): a wave whose 1024 frames are all inside the block and 16-byte aligned moves them
     // with coalesced accesses; any other wave takes the per-lane path.  `xn_staged` says which layout xn has.
-    const bool io_aligned = STAGED && aligned16(ib) && aligned16(ob);
+    const bool io_aligned = STAGED && (SINE || aligned16(ib)) && aligned16(ob);
     bool xn_staged = false;
     const int64_t halves = (n + kSbHalf - 1) / kSbHalf;
     int64_t tail_start = halves - tail;
@@ -695,6 +705,20 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
     auto request = [&](int64_t hh) {
         const int64_t w0 = hh * kSbHalf + (int64_t)(tid - lane) * kBqT;      // first frame of this wave
         const int64_t f0 = w0 + lane * kBqT;
+        if (SINE) {
+            xn_staged = false;
+            const double t = pgx::pgx_div_by((double)(sine.start + f0), sine.sr, sine.inv_sr);
+            double sn, cs;
+            pgx::pgx_sincos_bounded(sine.phase0 + sine.w * t, sn, cs);
+#pragma unroll
+            for (int j = 0; j < kBqT; ++j) {
+                xn[j] = (float)(sine.amp * sn);
+                const double s2 = __builtin_fma(cs, sine.sin_d, sn * sine.cos_d);
+                cs = __builtin_fma(-sn, sine.sin_d, cs * sine.cos_d);
+                sn = s2;
+            }
+            return;
+        }
         xn_staged = io_aligned && w0 + 64 * kBqT <= emit_to;
         if (xn_staged) {
             stage_fetch(ib + w0, lane, xn);
@@ -705,7 +729,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             for (int j = 0; j < kBqT; ++j) xn[j] = 0.0f;
         }
     };
-    if (hb < he) request(h);
+    if (!SINE && hb < he) request(h);
 
     const double b0 = coef[inst * 5 + 0], b1 = coef[inst * 5 + 1], b2 = coef[inst * 5 + 2];
     const double a1 = coef[inst * 5 + 3], a2 = coef[inst * 5 + 4];
@@ -729,7 +753,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             if (hb >= he) break;
             h = hb - warm;
             emit_to = n;
-            request(h);
+            if (!SINE) request(h);
         }
         if (hb >= he) continue;
         V2 carry{0.0, 0.0};
@@ -740,10 +764,16 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
         for (; h < he; h += 2) {
             const int64_t f0 = h * kSbHalf + (int64_t)tid * kBqT;
             float xf[kBqT];
+            if (SINE) {
+                request(h);                                    // generated, not fetched: nothing to have in flight
 #pragma unroll
-            for (int j = 0; j < kBqT; ++j) xf[j] = xn[j];
-            if (STAGED && xn_staged) stage_to_chunks(wlds, lane, xf);
-            if (h + 2 < he) request(h + 2);                    // next tile's frames, in flight during this one
+                for (int j = 0; j < kBqT; ++j) xf[j] = xn[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kBqT; ++j) xf[j] = xn[j];
+                if (STAGED && xn_staged) stage_to_chunks(wlds, lane, xf);
+                if (h + 2 < he) request(h + 2);                // next tile's frames, in flight during this one
+            }
             // zero-state response of the 16-frame chunk
             V2 e{0.0, 0.0};
             const double na1 = -a1, na2 = -a2;
@@ -2834,6 +2864,38 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
                            p.seg_tiles, p.nseg);
         PGX_LAUNCH_CHECK("k_biquad_const");
     }
+    return PGX_OK;
+}
+
+int pgx_biquad_sine_supported(int64_t n, int64_t settle_frames) {
+    return (n > 0 && biquad_settled_plan(1, n, 1, settle_frames, true).ok) ? 1 : 0;
+}
+
+int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, double w, double amp, double phase0,
+                    const double *coef, const double *tables, int64_t settle_frames, double *state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && coef && tables && state && sample_rate > 0, "pgx_biquad_sine: bad argument");
+    const BqSettledPlan sp = biquad_settled_plan(1, n, 1, settle_frames, true);
+    PGX_CHECK_ARG(sp.ok, "pgx_biquad_sine: block too short for the single-launch plan (pgx_biquad_sine_supported)");
+    // the largest phase of the render has to stay in the bounded sine's range
+    const double far = fabs(phase0) + fabs(w) * ((double)(llabs(start) + n) / sample_rate);
+    PGX_CHECK_ARG(far < pgx::kSinFastRange, "pgx_biquad_sine: phase beyond the fast sine range");
+    SbSine sine;
+    sine.w = w;
+    sine.amp = amp;
+    sine.phase0 = phase0;
+    sine.sr = sample_rate;
+    sine.inv_sr = 1.0 / sample_rate;
+    const long double d = (long double)w / (long double)sample_rate;
+    sine.cos_d = (double)cosl(d);
+    sine.sin_d = (double)sinl(d);
+    sine.start = start;
+    const dim3 grid(sp.groups == 1 ? 1 : (sp.groups + 7) / 8 * 8, 1);
+    hipLaunchKernelGGL((k_biquad_settled<true, true, true>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
+                       (int64_t)0, (const float *)nullptr, (int64_t)0, n, 1, coef, tables, state, sp.seg, sp.head,
+                       sp.tail, sp.warm, sp.groups, sine);
+    PGX_LAUNCH_CHECK("k_biquad_settled<sine>");
     return PGX_OK;
 }
 

@@ -461,113 +461,6 @@ k_ladder_finish(float *out, int64_t out_stride, const float *in, int64_t in_stri
     }
 }
 
-// ================================================================================================
-// CombPE (comb_pe.py:26-113).
-// Kernel 1 (one lane): the control recurrence -- smoothed frequency -> integer delay, clamped
-// feedback -- is inherently sequential and must be exact because it produces INDICES.
-// Kernel 2 (one workgroup per channel): y[n] = x[n] + fb[n]*ring[n - D[n]]; samples whose delay
-// reaches before the current chunk start are independent, so chunks of up to 256 such samples are
-// processed in parallel (reads, barrier, writes, barrier).
-// ================================================================================================
-__global__ void __launch_bounds__(256)
-k_comb_control(int64_t n, double sr, double freq_scalar, double fb_scalar, const float *freq, const float *fb,
-               double min_frequency, double smooth_alpha, int64_t buffer_len, double max_feedback,
-               double *state, int32_t *delay, double *fbv) {
-    // feedback clamp: parallel
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        double f = fb ? (double)fb[i] : fb_scalar;
-        if (!isfinite(f)) f = 0.0;
-        if (f > max_feedback) f = max_feedback;
-        if (f < -max_feedback) f = -max_feedback;
-        fbv[i] = f;
-    }
-    __shared__ long long s_fill_from;
-    __shared__ int s_fill_val;
-    if (threadIdx.x == 0) {
-        double smoothed = state[1];
-        long long fill_from = n;
-        int fill_val = 1;
-        const bool constant = (freq == nullptr);
-        const double raw_c = freq_scalar < min_frequency ? min_frequency : freq_scalar;
-        for (int64_t i = 0; i < n; ++i) {
-            double raw = raw_c;
-            if (!constant) {
-                raw = (double)freq[i];
-                if (raw < min_frequency) raw = min_frequency;
-            }
-            const double prev = smoothed;
-            if (smoothed < 0.0) smoothed = raw;
-            else smoothed += (raw - smoothed) * smooth_alpha;
-            double f = smoothed < 1.0 ? 1.0 : smoothed;
-            int64_t d = (int64_t)rint(sr / f);
-            if (d < 1) d = 1;
-            if (d >= buffer_len) d = buffer_len - 1;
-            delay[i] = (int32_t)d;
-            // constant frequency: once the one-pole no longer moves, every later sample repeats
-            // this delay exactly -- hand the rest to the parallel fill below.
-            if (constant && smoothed == prev) {
-                fill_from = i + 1;
-                fill_val = (int)d;
-                break;
-            }
-        }
-        state[1] = smoothed;
-        // advance write_pos here (kernel 2 derives its start position from the new value)
-        int64_t wp = (int64_t)state[0];
-        wp = (wp + n) % buffer_len;
-        state[0] = (double)wp;
-        s_fill_from = fill_from;
-        s_fill_val = fill_val;
-    }
-    __syncthreads();
-    for (int64_t i = s_fill_from + threadIdx.x; i < n; i += blockDim.x) delay[i] = s_fill_val;
-}
-
-__global__ void __launch_bounds__(256)
-k_comb_apply(float *out, const float *in, int64_t n, int channels, double *ring, int64_t buffer_len,
-             const double *state, const int32_t *delay, const double *fbv) {
-    __shared__ int s_first_bad[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.x;
-    const int64_t wp_new = (int64_t)state[0];
-    int64_t wp = ((wp_new - n) % buffer_len + buffer_len) % buffer_len;   // write position at block start
-    int64_t pos = 0;
-    while (pos < n) {
-        // chunk length S: first j with pos+j >= n or delay[pos+j] <= j
-        const int64_t i = pos + tid;
-        int32_t d = 0;
-        bool ok = false;
-        if (i < n) {
-            d = delay[i];
-            ok = d > tid;
-        }
-        unsigned long long bad = __ballot(!ok);
-        int fb_lane = bad ? (__ffsll((long long)bad) - 1) : 64;
-        if (lane == 0) s_first_bad[wave] = fb_lane;
-        __syncthreads();
-        int S = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            int v = s_first_bad[w];
-            if (S == w * 64) S += v;          // extend only while all previous waves were fully ok
-        }
-        // S >= 1 always (delay >= 1 > 0 for tid 0 when pos < n)
-        double y = 0.0;
-        if (tid < S) {
-            int64_t rp = (wp + tid - d) % buffer_len;
-            if (rp < 0) rp += buffer_len;
-            const double delayed = ring[rp * channels + ch];
-            y = (double)in[i * channels + ch] + fbv[i] * delayed;
-            out[i * channels + ch] = (float)y;
-        }
-        __syncthreads();
-        if (tid < S) ring[((wp + tid) % buffer_len) * channels + ch] = y;
-        __syncthreads();
-        wp = (wp + S) % buffer_len;
-        pos += S;
-    }
-}
-
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -658,26 +551,6 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
                        channels, sample_rate, params, freq, resonance, drive, state, settle_frames, p.seg_len,
                        p.nseg, (const double *)warm, (const double *)ends, fallbacks);
     PGX_LAUNCH_CHECK("k_ladder_finish");
-    return PGX_OK;
-}
-
-int pgx_comb(float *out, const float *in, int64_t n, int channels, double sample_rate, double freq_scalar,
-             double fb_scalar, const float *freq, const float *fb, double min_frequency,
-             int64_t smoothing_samples, double *ring, int64_t buffer_len, double *state, int32_t *delay_scratch,
-             double *fb_scratch) {
-    PGX_REQUIRE_INIT();
-    if (n <= 0) return PGX_OK;
-    PGX_CHECK_ARG(out && in && ring && state && delay_scratch && fb_scratch, "pgx_comb: null pointer");
-    PGX_CHECK_ARG(channels >= 1 && buffer_len >= 2 && smoothing_samples >= 1 && sample_rate > 0,
-                  "pgx_comb: bad argument");
-    hipLaunchKernelGGL(k_comb_control, dim3(1), dim3(256), 0, pgx::stream(), n, sample_rate, freq_scalar,
-                       fb_scalar, freq, fb, min_frequency, 1.0 / (double)smoothing_samples, buffer_len, 0.995,
-                       state, delay_scratch, fb_scratch);
-    PGX_LAUNCH_CHECK("k_comb_control");
-    hipLaunchKernelGGL(k_comb_apply, dim3(channels), dim3(256), 0, pgx::stream(), out, in, n, channels, ring,
-                       buffer_len, (const double *)state, (const int32_t *)delay_scratch,
-                       (const double *)fb_scratch);
-    PGX_LAUNCH_CHECK("k_comb_apply");
     return PGX_OK;
 }
 

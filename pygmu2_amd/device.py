@@ -82,6 +82,8 @@ _SIGNATURES = [
     ("pgx_biquad_table_doubles", _Z, []),
     ("pgx_biquad_tables", _I, [_P, _P, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _L, _P, _P]),
+    ("pgx_biquad_sine_supported", _I, [_L, _L]),
+    ("pgx_biquad_sine", _I, [_P, _L, _L, _D, _D, _D, _D, _P, _P, _L, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P, _P]),
     ("pgx_scan2_workspace_bytes", _Z, [_L, _I]),
     ("pgx_convolve_fft_size", _L, [_L]),
@@ -113,7 +115,8 @@ _SIGNATURES = [
     ("pgx_supersaw_bank", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P]),
     ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P, _L, _L, _P]),
     ("pgx_ladder_workspace_bytes", _Z, [_I, _L, _I, _L]),
-    ("pgx_comb", _I, [_P, _P, _L, _I, _D, _D, _D, _P, _P, _D, _L, _P, _L, _P, _P, _P]),
+    ("pgx_comb", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _I, _I, _P, _P, _D, _L, _P, _L, _L, _I, _P, _P]),
+    ("pgx_comb_workspace_bytes", _Z, [_I, _L, _I, _I, _I]),
     ("pgx_periodic_gate", _I, [_P, _L, _I, _L, _L, _P]),
     ("pgx_periodic_trigger", _I, [_P, _L, _L, _L, _L, _F]),
     ("pgx_adsr_workspace_bytes", _Z, [_I, _L]),
@@ -147,6 +150,7 @@ DYNAMICS_PARAMS = np.dtype([("mode", "<i4"), ("soft", "<i4"), ("stereo_link", "<
 BLITSAW_PARAMS = np.dtype([("freq", "<f8"), ("amp", "<f8"), ("leak", "<f8"), ("m", "<f8")])
 LADDER_PARAMS = np.dtype([("freq", "<f8"), ("resonance", "<f8"), ("drive", "<f8"),
                           ("passband_gain", "<f8"), ("oversample", "<i4"), ("mode", "<i4")])
+COMB_PARAMS = np.dtype([("feedback", "<f8"), ("delay", "<i4"), ("buffer_len", "<i4")])
 TRANSFORM_OP = np.dtype([("code", "<i4"), ("pad", "<i4"), ("p0", "<f8"), ("p1", "<f8")])
 GATE_PARAMS = np.dtype([("dt", "<f8"), ("phase", "<f8"), ("duty", "<f8")])
 ADSR_PARAMS = np.dtype([("attack_dvdt", "<f8"), ("decay_dvdt", "<f8"), ("release_dvdt", "<f8"),

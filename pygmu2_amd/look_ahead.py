@@ -35,7 +35,8 @@ from . import read_ahead as _read_ahead
 
 SMALL_BLOCK = 1 << 20       # pulls up to this many frames are served from a look-ahead window
 FIRST_WINDOW_BLOCKS = 8     # the first window of a stream; every further one is WINDOW_GROWTH times longer, up to
-WINDOW_GROWTH = 8
+WINDOW_GROWTH = 2           # (8, 16, 32, 64: a stream that stops after k blocks has rendered < 2k + 8; with x8 a
+                            # 20-block stream rendered 8 + 33 blocks)
 AHEAD_BLOCKS = 64           # ... at most this many blocks per window ...
 AHEAD_FRAMES = 1 << 25      # ... and about this many frames (1 M-frame pulls: 32 blocks per window, 128 MB per
                             # channel of every PE in it: C2 3.8 us per step at 2^24, 3.5 at 2^25, 3.3 at 2^26)
@@ -161,13 +162,17 @@ class _Window:
 def render(pe, start: int, duration: int):
     """Serve (start, duration) from the PE's window, or open one when the pull continues the previous
     one.  None: the request takes the normal path (any window has been settled by then)."""
-    if not _ENABLED or _busy():
+    if _busy():
         return None
     d = pe.__dict__
     owner = d.get("_la_owner")
     if owner is not None:                             # pulled directly while inside somebody's window
         settle(owner)
     win = d.get("_la_win")
+    if not _ENABLED:                                  # switched off mid-stream: open windows are settled, none opened
+        if win is not None:
+            settle(pe)
+        return None
     if win is not None:
         if start == win.served and start + duration <= win.end and (not win.block or duration == win.block):
             win.served = start + duration
@@ -195,16 +200,25 @@ def render(pe, start: int, duration: int):
     block = duration if d.get("_la_sensitive") else 0
     _tls.busy = True
     _tls.period = block
+    # slow start: a stream that stops after a few blocks has not paid for 64; one that keeps going doubles its
+    # window with every refill (8, 16, 32, 64 blocks)
+    grow = d.get("_la_grow", FIRST_WINDOW_BLOCKS)
+    blocks = max(2, min(grow, AHEAD_BLOCKS, AHEAD_FRAMES // duration))
     try:
-        # slow start: a stream that stops after a few blocks has not paid for 64; one that keeps going reaches
-        # the full window with its second refill (8, then 64 blocks)
-        grow = d.get("_la_grow", FIRST_WINDOW_BLOCKS)
-        d["_la_grow"] = grow * WINDOW_GROWTH
-        blocks = max(2, min(grow, AHEAD_BLOCKS, AHEAD_FRAMES // duration))
         big = pe._render(start, duration * blocks)
+    except Exception:                                 # noqa: BLE001
+        # a render `blocks` times longer can fail where the block itself would not (HBM for the intermediates,
+        # a kernel's size limit): every state goes back to the snapshot, this PE stops opening windows and the
+        # request takes the block-by-block path -- the caller sees what it would have seen without look-ahead
+        _tls.busy = False
+        _tls.period = 0
+        restore_snapshot(snap)
+        d["_la_ok"] = False
+        return None
     finally:
         _tls.busy = False
         _tls.period = 0
+    d["_la_grow"] = grow * WINDOW_GROWTH
     if not big.on_device:                             # host-side graph: nothing to gain, nothing was assumed
         restore_snapshot(snap)
         _tls.busy = True

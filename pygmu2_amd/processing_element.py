@@ -93,6 +93,8 @@ class ProcessingElement(ABC):
             ch = self.channel_count()
             return Snippet.from_zeros(start, 0, int(ch) if ch is not None else 1)
         if diag and timing_enabled():
+            if "_la_win" in self.__dict__ or "_la_owner" in self.__dict__:
+                _look_ahead.before_direct_access(self)   # timing turned on mid-stream: an open window is settled first
             t0 = time.perf_counter_ns()
             out = self._render(start, duration)
             record_timing(self, time.perf_counter_ns() - t0)

@@ -12,7 +12,7 @@ The batched kernels are the very same kernels the single PEs use (batch = 1 ther
 bank produces the same samples as rendering the voices one by one.
 
 Supported nodes: SinePE (scalar), BlitSawPE (scalar), SuperSawPE (scalar), BiquadPE
-(constant coefficients), LadderPE (scalar controls), GainPE (constant or PE gain),
+(constant coefficients), LadderPE (scalar controls), CombPE (scalar controls), GainPE (constant or PE gain),
 AdsrGatedPE, PeriodicGate.  Anything else -> `try_build_bank` returns None and MixPE
 falls back to per-input rendering.
 """
@@ -26,6 +26,7 @@ from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, ptr
 from .adsr_pe import AdsrGatedPE
 from .biquad_pe import BiquadPE, rbj_coefficients, settle_frames
 from .blit_saw_pe import BlitSawPE
+from .comb_pe import CombPE
 from .extent import Extent
 from .gain_pe import GainPE
 from .ladder_pe import LadderPE
@@ -338,6 +339,49 @@ class _LadderNode(_Node):
         return out
 
 
+class _CombNode(_Node):
+    """Bank of CombPEs with scalar frequency and feedback: every voice's D * C polyphase chains in one launch
+    (two when the block is long enough to be cut into time segments), per-voice delay / feedback / ring."""
+
+    def __init__(self, pes, children):
+        super().__init__(pes, children)
+        rec = np.concatenate([pe._param_record() for pe in pes])
+        self.params = _dev.upload_structs(rec)
+        self.d_min, self.d_max = int(rec["delay"].min()), int(rec["delay"].max())
+        self.rows = int(rec["buffer_len"].max())
+        self.ring = None
+        self.ws = None
+        self.total = 0
+        self.parity = 0
+
+    def reset(self):
+        super().reset()
+        # CombPE has no _reset_state hook (comb_pe.py): only start / stop clear the ring -- VoiceBank.reset is
+        # called from those
+        self.ring = None
+
+    def channels(self):
+        return self.children["source"].channels()
+
+    def render(self, start, n):
+        L = lib()
+        x = self.children["source"].render(start, n)
+        ch = x.shape[2]
+        if self.ring is None:
+            self.ring = DeviceBuffer((self.k, 2, self.rows, ch), np.float64, zero=True)
+            self.total, self.parity = 0, 0
+        need = L.pgx_comb_workspace_bytes(self.k, n, ch, self.d_max, 0)
+        if need and (self.ws is None or self.ws.nbytes < need):
+            self.ws = DeviceBuffer((need,), np.uint8)
+        out = DeviceBuffer((self.k, n, ch), np.float32)
+        check(L.pgx_comb(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr, self.d_min,
+                         self.d_max, None, None, 1.0, 1, self.ring.ptr, self.rows, self.total, self.parity, None,
+                         ptr(self.ws) if need else None), "pgx_comb")
+        self.total += n
+        self.parity ^= 1
+        return out
+
+
 class _GateNode(_Node):
     def __init__(self, pes):
         super().__init__(pes, {})
@@ -455,6 +499,11 @@ def _signature(pe):
             return None
         sub = _signature(pe._source)
         return None if sub is None else ("ladder", sub)
+    if isinstance(pe, CombPE):
+        if pe._freq_is_pe or pe._fb_is_pe:
+            return None
+        sub = _signature(pe._source)
+        return None if sub is None else ("comb", sub)
     if isinstance(pe, PeriodicGate):
         return ("gate",) if pe.is_pure() else None        # PE-driven gates carry a phase: not batched
     if isinstance(pe, AdsrGatedPE):
@@ -490,6 +539,8 @@ def _build(pes):
         return _BiquadNode(pes, {"source": _build([p._source for p in pes])})
     if isinstance(pe, LadderPE):
         return _LadderNode(pes, {"source": _build([p._source for p in pes])})
+    if isinstance(pe, CombPE):
+        return _CombNode(pes, {"source": _build([p._source for p in pes])})
     if isinstance(pe, PeriodicGate):
         return _GateNode(pes)
     if isinstance(pe, AdsrGatedPE):

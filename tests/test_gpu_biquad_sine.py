@@ -1,0 +1,88 @@
+"""
+GPU: BiquadPE(SinePE) as ONE launch (pgx_biquad_sine: the sine is generated in registers inside the settled filter
+kernel, csrc/pgx_scan.hip k_biquad_settled<.., SINE>) against the two-PE path and against the oracle
+(np.sin + scipy.signal.lfilter, biquad_pe.py:383-404 over sine_pe.py:159-175).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(pg, freq=440.0, amp=1.0, phase=0.0, cutoff=1000.0, q=0.707, mode="lowpass"):
+    return pg.BiquadPE(pg.SinePE(frequency=freq, amplitude=amp, phase=phase), frequency=cutoff, q=q,
+                       mode=pg.BiquadMode(mode))
+
+
+def _render(fuse, blocks, sr=44100, **kw):
+    import pygmu2_amd as pg
+    from pygmu2_amd import biquad_pe, look_ahead
+    pg.set_sample_rate(sr)
+    keep = biquad_pe.FUSE_SINE_SOURCE
+    biquad_pe.FUSE_SINE_SOURCE = fuse
+    look_ahead.set_enabled(False)
+    try:
+        pe = _chain(pg, **kw)
+        r = pg.NullRenderer(sample_rate=sr)
+        r.set_source(pe)
+        r.start()
+        outs = [pe.render(s, n).data.copy() for s, n in blocks]
+        r.stop()
+        return outs
+    finally:
+        biquad_pe.FUSE_SINE_SOURCE = keep
+        look_ahead.set_enabled(True)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(freq=3000.3, amp=0.3, phase=1.1, cutoff=2500.0, q=2.0, mode="bandpass"),
+                                dict(freq=5500.0, cutoff=3000.0, mode="highpass"),
+                                dict(freq=700.0, cutoff=1000.0, q=1.0, mode="peaking")])
+def test_fused_chain_equals_the_two_launch_chain(kw):
+    blocks = [(0, 1_000_000), (1_000_000, 300_001), (1_300_001, 50_000), (10 ** 9, 2_000_000)]
+    fused, plain = _render(True, blocks, **kw), _render(False, blocks, **kw)
+    for a, b in zip(fused, plain):
+        peak = float(np.max(np.abs(b)))
+        err = float(np.max(np.abs(a.astype(np.float64) - b)))
+        assert err <= 2e-7 * peak, (err, peak)
+
+
+def test_fused_chain_against_the_oracle():
+    from oracle import pe_oracle as O
+    n = 1_000_000
+    got = _render(True, [(0, n), (n, n)])
+    st = O.biquad_state(1)
+    for k in range(2):
+        want = O.biquad_const(st, O.sine_pure(k * n, n, 440.0, sr=44100), 1000.0, 0.707, "lowpass", 0.0, 44100)
+        peak = float(np.max(np.abs(want)))
+        assert float(np.max(np.abs(got[k].astype(np.float64) - want))) <= 1e-6 * peak
+
+
+def test_filters_that_pass_rounding_noise_rather_than_the_tone_keep_two_launches():
+    """A high-pass three octaves above the tone answers mostly to the float32 rounding of its input: there the
+    sine has to be the separate SinePE's float32 samples, and the chain is the two-launch chain bit for bit."""
+    import pygmu2_amd as pg
+    kw = dict(freq=55.0, cutoff=8000.0, mode="highpass")
+    pg.set_sample_rate(44100)
+    assert _chain(pg, **kw)._render_sine_source(0, 1_000_000) is None
+    blocks = [(0, 1_000_000), (10 ** 9, 1_000_000)]
+    for a, b in zip(_render(True, blocks, **kw), _render(False, blocks, **kw)):
+        assert np.array_equal(a, b)
+
+
+def test_fused_path_is_taken_and_declined():
+    import pygmu2_amd as pg
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+    pg.set_sample_rate(44100)
+    pe = _chain(pg)
+    assert pe._render_sine_source(0, 1_000_000) is not None
+    assert pe._render_sine_source(0, 1024) is not None                  # a short block: one workgroup, carried state
+    slow = pg.BiquadPE(pg.SinePE(frequency=440.0), frequency=20.0, q=10.0)   # forgets too slowly: the exact pair
+    assert slow._render_sine_source(0, 1_000_000) is None
+    assert pe._render_sine_source(10 ** 13, 1_000_000) is None          # phase beyond the bounded sine's range
+    stereo = pg.BiquadPE(pg.SinePE(frequency=440.0, channels=2), frequency=1000.0, q=0.707)
+    assert stereo._render_sine_source(0, 1_000_000) is None
+    fm = pg.BiquadPE(pg.SinePE(frequency=pg.SinePE(frequency=2.0, amplitude=100.0)), frequency=1000.0, q=0.707)
+    assert fm._render_sine_source(0, 1_000_000) is None
+    assert lib.pgx_biquad_sine_supported(1_000_000, 1024) == 1 and lib.pgx_biquad_sine_supported(1_000_000, 0) == 0

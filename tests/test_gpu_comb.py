@@ -1,0 +1,166 @@
+"""
+GPU: CombPE (csrc/pgx_comb.hip) against the oracle's restatement of _comb_process_numba (comb_pe.py:26-113).
+
+* scalar frequency, one time segment (<= 1024 steps per residue chain): the reference's loop operation for operation
+  -> BIT-EXACT, whatever the block partition (the double-buffered ring carries the state);
+* scalar frequency, long renders (concurrent time segments, carries through a float64 affine fold): <= 1e-7 of peak,
+  and the ring left behind continues a stream exactly like the single-segment path does;
+* frequency from a PE (time-parallel one-pole -> integer delays, ring in LDS; ring in HBM for a very low
+  min_frequency): delays are integers, so the output is BIT-EXACT unless sr / f sits within ~1e-11 of a rounding
+  tie;
+* a bank of combs under a MixPE == the voices rendered one by one.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(spec, sr, blocks):
+    import pygmu2_amd as pg
+    import spec_build
+    pg.set_sample_rate(sr)
+    pe = spec_build.build(spec)
+    r = pg.NullRenderer(sample_rate=sr)
+    r.set_source(pe)
+    r.start()
+    outs = [pe.render(s, n).data.copy() for s, n in blocks]
+    r.stop()
+    return outs
+
+
+def _oracle(spec, sr, blocks):
+    from oracle import graph_eval
+    g = graph_eval.Node(spec, sr)
+    return [g.render(s, n) for s, n in blocks]
+
+
+def _contig(sizes, start=0):
+    out, pos = [], start
+    for n in sizes:
+        out.append((pos, n))
+        pos += n
+    return out
+
+
+def _S():
+    from oracle.golden_cases import S
+    return S
+
+
+NOISE = {"rng": 7, "n": 400_000, "ch": 2, "scale": 0.3}
+NOISE1 = {"rng": 8, "n": 400_000, "ch": 1, "scale": 0.3}
+
+
+@pytest.mark.parametrize("freq,fb,sr", [(440.0, 0.7, 44100), (30000.0, 0.99, 48000), (25.0, -0.9, 48000),
+                                        (97.3, 0.5, 44100), (20.0, 0.995, 48000)])
+def test_scalar_frequency_is_the_reference_loop(freq, fb, sr):
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE), frequency=freq, feedback=fb)
+    blocks = _contig([512, 17, 23, 4096, 1, 3000, 41, 20_000])
+    got, want = _hip(spec, sr, blocks), _oracle(spec, sr, blocks)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), (i, int(np.sum(g != w)), float(np.max(np.abs(g.astype(np.float64) - w))))
+
+
+def test_scalar_frequency_feedback_stream():
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE1), frequency=330.0,
+             feedback=S("SinePE", frequency=1.3, amplitude=1.4))          # clamps at +-0.995 on the way
+    blocks = _contig([3000, 19, 6000])
+    got, want = _hip(spec, 48000, blocks), _oracle(spec, 48000, blocks)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("freq,ch", [(440.0, 1), (220.0, 2), (12000.0, 2), (30.0, 1)])
+def test_long_render_runs_in_time_segments(freq, ch):
+    """400 000 frames in one call: 4 000 steps per chain at 440 Hz -> segmented.  Then a short block: the ring the
+    segmented render left continues the stream."""
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE if ch == 2 else NOISE1), frequency=freq, feedback=0.9)
+    blocks = _contig([300_000, 5000, 90_000])
+    got, want = _hip(spec, 44100, blocks), _oracle(spec, 44100, blocks)
+    for g, w in zip(got, want):
+        peak = float(np.max(np.abs(w)))
+        err = float(np.max(np.abs(g.astype(np.float64) - w)))
+        assert err <= 1e-7 * peak, (err, peak)
+        assert np.mean(g != w) < 1e-3
+
+
+def test_long_render_with_feedback_stream():
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE1), frequency=1000.0,
+             feedback=S("SinePE", frequency=0.7, amplitude=0.9))
+    blocks = _contig([350_000, 2000])
+    got, want = _hip(spec, 48000, blocks), _oracle(spec, 48000, blocks)
+    for g, w in zip(got, want):
+        peak = float(np.max(np.abs(w)))
+        assert float(np.max(np.abs(g.astype(np.float64) - w))) <= 1e-7 * peak
+
+
+def _sweep(lo, hi, hz):
+    S = _S()
+    return S("MixPE", inputs=[S("ConstantPE", value=0.5 * (lo + hi)), S("SinePE", frequency=hz, amplitude=0.5 * (hi - lo))])
+
+
+@pytest.mark.parametrize("min_f,smooth", [(20.0, 2400), (30.0, 200), (2.0, 50), (20.0, 1)])
+def test_frequency_stream_delays_are_exact(min_f, smooth):
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE), frequency=_sweep(60.0, 900.0, 2.5), feedback=0.8,
+             min_frequency=min_f, smoothing_samples=smooth)
+    blocks = _contig([5000, 17, 44_100, 3, 9000])
+    got, want = _hip(spec, 48000, blocks), _oracle(spec, 48000, blocks)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), (i, int(np.sum(g != w)))
+
+
+def test_frequency_and_feedback_streams_below_min_frequency():
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE1), frequency=_sweep(-50.0, 400.0, 3.0),     # clamps at min_f
+             feedback=S("SinePE", frequency=0.9, amplitude=1.2), min_frequency=25.0, smoothing_samples=480)
+    blocks = _contig([20_000, 20_000])
+    got, want = _hip(spec, 44100, blocks), _oracle(spec, 44100, blocks)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_bank_of_combs_matches_voices_one_by_one():
+    import pygmu2_amd as pg
+    from pygmu2_amd import voice_bank
+    pg.set_sample_rate(48000)
+
+    def voices():
+        return [pg.CombPE(pg.BlitSawPE(frequency=55.0 * 2 ** (i / 7.0)), frequency=40.0 * 2 ** (i / 5.0),
+                          feedback=0.3 + 0.02 * i) for i in range(24)]
+
+    def run(banked):
+        keep = voice_bank.MIN_VOICES
+        voice_bank.MIN_VOICES = 4 if banked else 10 ** 9
+        try:
+            mix = pg.MixPE(*voices())
+            r = pg.NullRenderer(sample_rate=48000)
+            r.set_source(mix)
+            r.start()
+            assert bool(mix._voice_bank()) == banked
+            outs = [mix.render(s, n).data.copy() for s, n in _contig([4800, 100_000, 777])]
+            r.stop()
+            return outs
+        finally:
+            voice_bank.MIN_VOICES = keep
+
+    for a, b in zip(run(True), run(False)):
+        assert np.array_equal(a, b)
+
+
+def test_look_ahead_window_of_a_comb_stream():
+    """44 100-frame blocks through look-ahead windows (a window is one long, time-segmented render) against the
+    oracle rendering block by block."""
+    S = _S()
+    spec = S("CombPE", source=S("SinePE", frequency=330.0), frequency=440.0, feedback=0.7)
+    blocks = _contig([44_100] * 12)
+    got, want = _hip(spec, 44100, blocks), _oracle(spec, 44100, blocks)
+    for g, w in zip(got, want):
+        peak = float(np.max(np.abs(w)))
+        assert float(np.max(np.abs(g.astype(np.float64) - w))) <= 1e-6 * peak

@@ -127,11 +127,13 @@ def test_streams_really_come_from_windows_and_states_roll_back():
     win = flt.__dict__.get("_la_win")
     assert win is not None and win.first == 1024 and win.end == 1024 + look_ahead.FIRST_WINDOW_BLOCKS * 1024
     assert win.served == 5 * 1024
-    for i in range(5, 30):                                    # slow start: the next window is 64 blocks long
+    for i in range(5, 30):                                    # slow start: every refill is WINDOW_GROWTH times longer
         flt.render(i * 1024, 1024)
     win = flt.__dict__.get("_la_win")
-    first = 1 + look_ahead.FIRST_WINDOW_BLOCKS
-    assert win.first == first * 1024 and win.end == (first + 64) * 1024 and win.served == 30 * 1024
+    first, length = 1, look_ahead.FIRST_WINDOW_BLOCKS
+    while first + length <= 29:                               # the window that holds block 29
+        first, length = first + length, min(length * look_ahead.WINDOW_GROWTH, look_ahead.AHEAD_BLOCKS)
+    assert win.first == first * 1024 and win.end == (first + length) * 1024 and win.served == 30 * 1024
     ahead_state = flt._state.to_host().copy()             # the state at the end of the window
     look_ahead.settle(flt)
     assert "_la_win" not in flt.__dict__
