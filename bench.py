@@ -61,12 +61,21 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="primary workload only")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch glue only (CPU host): ranks rendezvous and report, nothing is rendered")
+    ap.add_argument("--allow-no-rccl", action="store_true",
+                    help="N > 1 ranks without an RCCL communicator: go on with store barriers (n_ranks_seen = 0, "
+                         "collective = 'store', sharded mixes reported as unavailable) instead of failing")
     return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------- launching N ranks
+SPAWN_DEADLINE = float(os.environ.get("PGX_BENCH_DEADLINE", "1500"))     # seconds for the whole N-rank run
+
+
 def spawn_ranks(n: int) -> int:
-    """Parent of a `--gpus N` run: N child ranks of this same command line; relay rank 0's stdout."""
+    """Parent of a `--gpus N` run: N child ranks of this same command line; relay rank 0's stdout.  The whole run
+    has a deadline: a rank stuck in a collective or at the store takes its siblings down with it instead of
+    hanging the parent."""
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -74,28 +83,51 @@ def spawn_ranks(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGX_BENCH_SPAWNED="1")
+        # This pool's host driver shares device memory between processes through dmabuf only: with the legacy IPC
+        # mode RCCL's peer-to-peer setup fails in hipIpcGetMemHandle ("invalid argument").  The driver's launcher
+        # exports the same setting; a value the caller chose is kept.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
     out0 = procs[0].stdout
-    failed = 0
-    try:
+
+    def relay():
         for line in iter(out0.readline, b""):            # rank 0's JSON line (and nothing else) goes to stdout
             text = line.decode("utf-8", "replace")
             dest = sys.stdout if text.lstrip().startswith("{") else sys.stderr     # (a library's banner: stderr)
             dest.write(text)
             dest.flush()
-        deadline = time.time() + 600
-        for p in procs:
-            try:
-                rc = p.wait(timeout=max(1.0, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                rc = -9
-            failed = failed or rc
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    deadline = time.time() + SPAWN_DEADLINE
+    failed = 0
+    try:
+        pending = list(procs)
+        while pending and time.time() < deadline:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is not None:
+                    pending.remove(p)
+                    failed = failed or rc
+            if failed:
+                break                                     # one rank failed: the others cannot finish a collective
+            time.sleep(0.02)
+        if pending:
+            if not failed:
+                print(f"[bench] {len(pending)} of {n} ranks still running after {SPAWN_DEADLINE:.0f} s: killed",
+                      file=sys.stderr, flush=True)
+            failed = failed or 1
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        reader.join(timeout=5)
     return 1 if failed else 0
 
 
@@ -107,7 +139,8 @@ class Dist:
     """World / rank from the launcher's environment.  world > 1: the c10d store the launcher provides
     carries the communicator id (and, in a dry run, the whole report); RCCL carries everything else."""
 
-    def __init__(self, dry_run=False):
+    def __init__(self, dry_run=False, allow_no_rccl=False):
+        self.allow_no_rccl = allow_no_rccl
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -159,16 +192,33 @@ class Dist:
             os.dup2(saved, 1)
             os.close(saved)
         ok = "seen" in outcome and outcome["seen"] == self.world
+        timed_out = not ok and "error" not in outcome and t.is_alive()
         if not ok and "error" not in outcome:
             outcome["error"] = "timed out" if t.is_alive() else f"saw {outcome.get('seen')} of {self.world} ranks"
         all_ok = self._store_sum("rccl_ok", 1 if ok else 0) == self.world
         if all_ok:
-            return outcome["seen"]
+            return outcome["seen"]                    # the all-reduce of ones on the communicator, nothing else
         self.collective = "store"
         self.collective_error = outcome.get("error", "a peer could not build the communicator")
+        any_timeout = self._store_sum("rccl_timeout", 1 if timed_out else 0) > 0
+        if any_timeout or not self.allow_no_rccl:
+            # no communicator, no multi-GPU measurement: every rank leaves with an error (a timed-out bootstrap also
+            # leaves a thread inside ncclCommInitRank that could still publish a communicator later: never go on)
+            print(f"[bench] rank {self.rank}: RCCL communicator unavailable ({self.collective_error}); "
+                  f"--gpus {self.world} needs it (pass --allow-no-rccl to measure replicas over store barriers)",
+                  file=sys.stderr, flush=True)
+            if self.rank == 0:
+                print(json.dumps({"metric": "Msamples/s rendered (benchmark_pes.py metric: output frames / wall second)",
+                                  "value": None, "unit": "Msamples/s", "n_gpus": self.world, "n_ranks_seen": 0,
+                                  "collective": None,
+                                  "error": f"no RCCL communicator: {self.collective_error}"}), flush=True)
+            self._leave_store()
+            sys.stdout.flush()
+            os._exit(3)
         print(f"[bench] rank {self.rank}: RCCL communicator unavailable ({self.collective_error}); "
-              f"barriers go through the store", file=sys.stderr, flush=True)
-        return int(self._store_sum("ranks_seen", 1))
+              f"--allow-no-rccl: barriers go through the store, n_ranks_seen = 0", file=sys.stderr, flush=True)
+        self.ranks_present = int(self._store_sum("ranks_present", 1))
+        return 0                                      # RCCL saw nobody
 
     def _store_sum(self, key, value):
         self.store.add(key, int(value))
@@ -205,6 +255,15 @@ class Dist:
         from pygmu2_amd import comm
         return comm.reduce_scalar(value, "max")
 
+    def _leave_store(self):
+        # rank 0 may be hosting the store (bench.py's own spawner): it leaves last
+        if self.rank != 0:
+            self.store.add("pgx_done", 1)
+            return
+        t0 = time.time()
+        while int(self.store.add("pgx_done", 0)) < self.world - 1 and time.time() - t0 < 60:
+            time.sleep(0.005)
+
     def shutdown(self):
         if not self.enabled:
             return
@@ -213,13 +272,7 @@ class Dist:
             self.barrier()
             if self.collective == "rccl":
                 comm.destroy()
-        # rank 0 may be hosting the store (bench.py's own spawner): it leaves last
-        if self.rank != 0:
-            self.store.add("pgx_done", 1)
-            return
-        t0 = time.time()
-        while int(self.store.add("pgx_done", 0)) < self.world - 1 and time.time() - t0 < 60:
-            time.sleep(0.005)
+        self._leave_store()
 
 
 class _Solo:
@@ -380,6 +433,39 @@ def sine_kernel_roofline(pg, frames, launches, start):
             "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 6),
             "note": "float64-issue bound, not HBM: ~30 float64-class instructions per sample "
                     f"({frames / (ms * 1e-3) / 1e9:.0f} Gsamples/s); listed because it is the other half of a C2 window"}
+
+
+def biquad_sine_roofline(pg, frames, launches, start):
+    """The C2 chain as the timed steps launch it: pgx_biquad_sine (the sine generated inside the settled filter
+    kernel), one launch per look-ahead window.  Algorithmic bytes: SURVEY 8d "C2 = 4 B/frame fused with its SinePE"
+    (the float32 output; nothing is read)."""
+    from pygmu2_amd import device
+    from pygmu2_amd.biquad_pe import rbj_coefficients, settle_frames
+    lib = device.ensure_init()
+    pg.set_sample_rate(44100)
+    out = device.DeviceBuffer((frames, 1), np.float32)
+    c = rbj_coefficients(pg.BiquadMode.LOWPASS, 1000.0, 0.707, 0.0, 44100.0)
+    coef = device.DeviceBuffer.from_host(np.asarray(c, dtype=np.float64))
+    settle = settle_frames(c[3], c[4])
+    state = device.DeviceBuffer((1, 2), np.float64, zero=True)
+    tables = device.DeviceBuffer((lib.pgx_biquad_table_doubles(),), np.float64)
+    device.check(lib.pgx_biquad_tables(tables.ptr, coef.ptr, 1))
+    w = 2.0 * np.pi * 440.0
+
+    def launch():
+        device.check(lib.pgx_biquad_sine(out.ptr, start, frames, 44100.0, w, 1.0, 0.0, coef.ptr, tables.ptr, settle,
+                                         state.ptr))
+
+    ms = event_avg_ms(launch, launches)
+    algo_bytes = 4.0 * frames
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("pgx_biquad_sine", frames),
+            "kernel": f"k_biquad_settled<mono, staged, sine> (pgx_biquad_sine, settle_frames={settle})",
+            "frames_per_launch": frames, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms, 6),
+            "gsamples_per_s": round(frames / (ms * 1e-3) / 1e9, 1),
+            "note": "one launch per window, 4 B/frame written, nothing read: bound by float64 issue (sine rotation + "
+                    "two filter passes + scan, ~25 float64 operations per frame), not by HBM"}
 
 
 def biquad_kernel_roofline(pg, frames, launches, settled=True):
@@ -677,6 +763,8 @@ def mix_entry(pg, dist, config, steps, warmup, with_cpu):
            "ms_per_block": round(dt / steps * 1e3, 4), "scaling": "strong", "workload": name,
            "steps": steps, "warmup": warmup, "n_ranks": dist.world if dist.enabled else 1,
            "voices_on_this_rank": info["owned"],
+           "render_ms": info.get("render_ms"), "render_ms_max_over_ranks": info.get("render_ms_max"),
+           "allreduce_wait_ms": info.get("allreduce_wait_ms"),
            "oscillator_msamples_s": round(per_voice * voices * frames * steps / dt / 1e6, 1),
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                         "achieved": round(4.0 * frames * steps / dt / 1e9, 4),
@@ -765,6 +853,53 @@ def suite_rows(pg, with_cpu):
                         "1 thread", "rows": rows}
 
 
+def north_star_pe_rows(pg, with_cpu):
+    """The north_star PEs the reference's own suite has no config for -- CombPE, LadderPE, AdsrGatedPE -- under that
+    suite's protocol (44 100-frame renders, 5 + 50), each with the CPU figure of the same graph (oracle:
+    oracle/seq_kernels.c, gcc -O2, 1 thread -- the stand-in for the reference's numba kernels), plus a 512-chain
+    CombPE bank under a MixPE (48 000-frame blocks)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_suite as B
+    import comb_probe as CP
+    from oracle.golden_cases import S
+    sine = lambda f=440.0, a=1.0, ch=1: S("SinePE", frequency=f, amplitude=a, channels=ch)
+    configs = list(CP.CONFIGS) + [
+        ("LadderPE (lp24, 1200 Hz, res 0.3, oversample 2)",
+         S("LadderPE", source=S("BlitSawPE", frequency=110.0), frequency=1200.0, resonance=0.3, mode="lp24",
+           drive=1.0, oversample=2)),
+        ("LadderPE (modulated cutoff)",
+         S("LadderPE", source=S("BlitSawPE", frequency=110.0), frequency=S("MixPE", inputs=[
+             S("ConstantPE", value=1200.0), sine(0.5, 600.0)]), resonance=0.3, mode="lp24", drive=1.0, oversample=2)),
+        ("AdsrGatedPE (PeriodicGate 2 Hz)",
+         S("AdsrGatedPE", gate=S("PeriodicGate", frequency=2.0, duty_cycle=0.5), attack_time=0.01, decay_time=0.1,
+           sustain_level=0.7, release_time=0.2)),
+        ("AdsrGatedPE (PeriodicGate 7 Hz)",
+         S("AdsrGatedPE", gate=S("PeriodicGate", frequency=7.0, duty_cycle=0.5), attack_time=0.01, decay_time=0.1,
+           sustain_level=0.7, release_time=0.2)),
+    ]
+    rows = {}
+    for name, spec in configs:
+        rates = B.device_rates(spec)
+        row = {k: round(v, 1) for k, v in rates.items()}
+        if with_cpu:
+            row["cpu"] = round(B.cpu_rate(spec, budget_s=1.0), 2)
+            row["pipelined_over_cpu"] = round(rates["pipelined"] / row["cpu"], 1)
+            row["sync_over_cpu"] = round(rates["sync"] / row["cpu"], 1)
+        rows[name] = row
+    dt = CP.bank_rate()
+    bank = {"ms_per_block": round(dt * 1e3, 4), "value": round(48000 / dt / 1e6, 3), "unit": "Msamples/s",
+            "chain_msamples_s": round(512 * 48000 / dt / 1e6, 1),
+            "workload": "512 x CombPE(BlitSawPE(f_i), 55*2^(i/96) Hz, fb 0.7) -> MixPE, 48 kHz, 48 000-frame blocks"}
+    if with_cpu:
+        cpu = CP.bank_cpu()
+        bank["cpu_ms_per_block"] = round(cpu * 1e3, 2)
+        bank["over_cpu"] = round(cpu / dt, 1)
+    return {"protocol": "benchmark_pes.py:149-196 (44 100-frame renders, 5 warm-up + 50 timed), Msamples/s; "
+                        "cpu = oracle (seq_kernels.c -O2 for the comb / ladder / ADSR loops), 1 thread",
+            "rows": rows, "comb_bank_512": bank}
+
+
 # ----------------------------------------------------------------------------- dry run (launch glue on CPU)
 def dry_run(args, dist):
     import pygmu2_amd as pg
@@ -792,7 +927,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))          # before anything touches the GPU
-    dist = Dist(dry_run=args.dry_run)
+    dist = Dist(dry_run=args.dry_run, allow_no_rccl=args.allow_no_rccl)
     if args.dry_run:
         dry_run(args, dist)
         return
@@ -856,13 +991,15 @@ def main():
 
     if dist.enabled:
         result["collective"] = dist.collective
+        if dist.collective != "rccl":
+            result["n_ranks_present"] = getattr(dist, "ranks_present", 0)      # counted through the store, not by RCCL
     if not sharded and not args.no_extras and dist.enabled and dist.collective != "rccl":
         note = {"error": f"no RCCL communicator ({dist.collective_error}): the sharded mixes were not run"}
         result["voice_mix"], result["supersaw_mix"] = dict(note), dict(note)
     elif not sharded and not args.no_extras:
         # collectives: every rank takes part.  The sharded mixes ride along in the default line.
-        result["voice_mix"] = mix_entry(pg, dist, "c5", 10, 2, with_cpu and dist.rank == 0)
-        result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 6, 2, with_cpu and dist.rank == 0)
+        result["voice_mix"] = mix_entry(pg, dist, "c5", 50, 5, with_cpu and dist.rank == 0)
+        result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 50, 5, with_cpu and dist.rank == 0)
         result["voice_mix"].pop("_dt"), result["supersaw_mix"].pop("_dt")
 
     if dist.rank == 0 and not args.no_extras and not sharded:
@@ -871,12 +1008,16 @@ def main():
         # the filter kernel as the C2 steps launch it: look-ahead renders `ahead` 1 M-frame steps per launch
         from pygmu2_amd import look_ahead
         ahead = max(2, min(look_ahead.AHEAD_BLOCKS, look_ahead.AHEAD_FRAMES // 1_000_000)) if look_ahead.enabled() else 1
-        # (steady state: a stream's first windows are 4 and 16 steps long)
-        result["roofline"] = biquad_kernel_roofline(pg, 1_000_000 * ahead, 100)
+        # (steady state: a stream's windows are 8, 16, 32, then `ahead` steps long)
+        far = (args.warmup + 1000) * 1_000_000
+        result["roofline"] = biquad_sine_roofline(pg, 1_000_000 * ahead, 100, far)
         result["roofline"]["steps_per_launch"] = ahead
-        result["roofline_sine"] = sine_kernel_roofline(pg, 1_000_000 * ahead, 50, (args.warmup + 1000) * 1_000_000)
-        result["roofline_one_step"] = biquad_kernel_roofline(pg, 1_000_000, 200)
-        result["roofline_scaled"] = biquad_kernel_roofline(pg, 1 << 26, 10)
+        result["roofline_one_step"] = biquad_sine_roofline(pg, 1_000_000, 200, far)
+        result["roofline_scaled"] = biquad_sine_roofline(pg, 1 << 26, 10, far)
+        # the two kernels of the same chain when it is not fused (stereo, PE-driven sine, filters that reject the
+        # tone): the filter alone is the HBM-streaming kernel, 8 B/frame
+        result["roofline_filter_alone"] = biquad_kernel_roofline(pg, 1_000_000 * ahead, 50)
+        result["roofline_sine_alone"] = sine_kernel_roofline(pg, 1_000_000 * ahead, 30, far)
         cases = {}
         if args.workload == "c2" and n_gpus == 1:
             result["value_with_d2h"] = bench_c2_with_d2h(pg, 40, 5)
@@ -902,6 +1043,7 @@ def main():
             cases["c4_supersaw_ladder_mix_64"].pop("_dt")
             cases["autowah_biquad_1024_blocks"] = {"value": autowah_case(pg, "biquad"), "unit": "Msamples/s"}
             cases["autowah_svf_1024_blocks"] = {"value": autowah_case(pg, "svf"), "unit": "Msamples/s"}
+            result["north_star_pes"] = north_star_pe_rows(pg, with_cpu)
             result["suite"] = suite_rows(pg, with_cpu)
         if with_cpu:
             result["cpu_baseline"] = cpu_c2(1_000_000)
@@ -923,6 +1065,46 @@ def main():
                         cases[k]["cpu_oracle_msamples_s"] = c3cpu
         if cases:
             result["cases"] = cases
+        # the driver's record keeps `config`, `roofline` and `cpu_baseline` whole and only the tail of the rest:
+        # the numbers a reader looks for first are repeated here, compactly (Msamples/s unless said otherwise)
+        hl = {}
+        try:
+            if "value_with_d2h" in result:
+                hl["c2_with_d2h_pipelined"] = result["value_with_d2h"]["pipelined"]["value"]
+                hl["c2_with_d2h_sync"] = result["value_with_d2h"]["sync"]["value"]
+            for key, short in (("c1_sine_gain_1024_blocks", "c1"), ("c3_convolve_64k_taps", "c3_96000"),
+                               ("c3_convolve_64k_taps_1440000_whole", "c3_1440000"),
+                               ("c4_supersaw_ladder_mix_64", "c4")):
+                if key in cases:
+                    hl[short] = cases[key]["value"]
+                    if "cpu_oracle_msamples_s" in cases[key]:
+                        hl[short + "_cpu"] = cases[key]["cpu_oracle_msamples_s"]
+                    elif "cpu_baseline" in cases[key]:
+                        hl[short + "_cpu"] = cases[key]["cpu_baseline"]["value"]
+            if "c3_convolve_64k_taps" in cases:
+                hl["c3_call_us"] = round(cases["c3_convolve_64k_taps"]["roofline"]["avg_launch_ms"] * 1e3, 2)
+            for key, short in (("voice_mix", "c5"), ("supersaw_mix", "supersaw_mix")):
+                if key in result and "value" in result[key]:
+                    hl[short] = result[key]["value"]
+                    hl[short + "_ms_per_block"] = result[key]["ms_per_block"]
+                    if "cpu_baseline" in result[key]:
+                        hl[short + "_cpu"] = result[key]["cpu_baseline"]["value"]
+            if "north_star_pes" in result:
+                for name, row in result["north_star_pes"]["rows"].items():
+                    tag = name.split(" (")[0].lower() + "_" + name.split("(")[1].rstrip(")").replace(" ", "_").replace(",", "")
+                    hl[tag] = [row.get("sync"), row.get("pipelined"), row.get("cpu")]
+                hl["comb_bank_512_ms_per_block"] = result["north_star_pes"]["comb_bank_512"]["ms_per_block"]
+                hl["_pe_rows"] = "[sync, pipelined, cpu]"
+            if "suite" in result:
+                for name in ("BiquadPE (lowpass, fixed)", "SinePE (440 Hz)", "BlitSawPE (440 Hz, auto M)",
+                             "SuperSawPE (7 voices)"):
+                    row = result["suite"]["rows"].get(name)
+                    if row:
+                        hl["suite " + name] = [row.get("sync"), row.get("pipelined"), row.get("cpu")]
+        except (KeyError, TypeError, IndexError):
+            pass
+        if hl:
+            result["config"]["highlights"] = hl
 
     if dist.rank == 0:
         print(json.dumps(result), flush=True)

@@ -376,6 +376,24 @@ int pgx_blitsaw_biquad_bank(float *out, int64_t out_stride, int batch, int64_t n
 int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
                       double sample_rate, const pgx_blitsaw_params *params, double *state /* [batch*nvoices][2] */,
                       const double *amp_scalar /* [batch] */);
+/* The same bank when a few instances have to fill the chip (a rank's share of a sharded mix): every instance is cut
+ * into pgx_supersaw_bank_segments(batch, n) time segments rendered by concurrent workgroups of one launch.  A later
+ * segment takes its oscillators' phase sums by replaying the per-tile additions and their integrator levels from
+ * the closed form of the leaky integrator's response to the BLIT's harmonics (blit_saw_pe.py:196-235:
+ * y = yss(phase) + leak^frames * (y0 - yss(phase0))); needs scalar frequencies, the automatic (odd) M and
+ * leak < 1.  Agreement with the sequential recurrence ~1e-14 (float64), i.e. the same float32 samples up to a
+ * rounding flip in ~1e-7 of them.  state_in is read, state_out (another buffer) receives the new states. */
+int pgx_supersaw_bank_segments(int batch, int64_t n);
+int pgx_supersaw_bank_seg(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                          double sample_rate, const pgx_blitsaw_params *params,
+                          const double *state_in, double *state_out, const double *amp_scalar /* [batch] */,
+                          const double *tables /* pgx_supersaw_bank_tables, or NULL: made by every workgroup */);
+/* What the bank's workgroups need per voice and what depends on the parameters only (Dirichlet constants, rotation
+ * sines, powers of the leak, per-thread prefix offsets, per-lane scan powers): made once per bank, loaded by every
+ * later launch.  The same operations as the in-kernel preparation, hence the same samples. */
+size_t pgx_supersaw_bank_table_bytes(int batch, int nvoices);
+int pgx_supersaw_bank_tables(double *tables, int batch, int nvoices, double sample_rate,
+                             const pgx_blitsaw_params *params);
 
 /* ------------------------------------------------------------------ LadderPE
  * _ladder_process_numba (ladder_pe.py:31-203), the reference's float64 operation order.

@@ -104,16 +104,51 @@ int pgx_comm_init(int rank, int world, const void *id_host, size_t len) {
     PGX_HIP(hipSetDevice(pgx::device_index()));
     ncclUniqueId id;
     memcpy(&id, id_host, sizeof(id));
-    PGX_NCCL(c.api.CommInitRank(&c.comm, world, id, rank));
+    // Everything is built into locals and published only when every step succeeded: a failure half-way leaves the
+    // singleton exactly as it was (no communicator, a retry is welcome) and frees what had been made.
+    ncclComm_t comm = nullptr;
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_in = nullptr;
+    hipEvent_t done[kRing] = {};
+    double *scratch = nullptr;
+    std::string why;
+    auto step = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        why = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    };
+    bool ok = true;
+    {
+        const ncclResult_t r = c.api.CommInitRank(&comm, world, id, rank);
+        if (r != ncclSuccess) {
+            why = std::string("c.api.CommInitRank(&c.comm, world, id, rank): ") + c.api.GetErrorString(r);
+            comm = nullptr;
+            ok = false;
+        }
+    }
     int least = 0, greatest = 0;
-    PGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    PGX_HIP(hipStreamCreateWithPriority(&c.cstream, hipStreamNonBlocking, greatest));
-    PGX_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
-    for (auto &e : c.done) PGX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    PGX_HIP(hipMalloc(&c.scratch, sizeof(double)));
+    ok = ok && step(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    ok = ok && step(hipStreamCreateWithPriority(&cstream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    ok = ok && step(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming), "hipEventCreateWithFlags");
+    for (int i = 0; ok && i < kRing; ++i) ok = step(hipEventCreateWithFlags(&done[i], hipEventDisableTiming), "hipEventCreateWithFlags");
+    ok = ok && step(hipMalloc(&scratch, sizeof(double)), "hipMalloc");
+    if (!ok) {
+        if (scratch) (void)hipFree(scratch);
+        for (auto &e : done)
+            if (e) (void)hipEventDestroy(e);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (cstream) (void)hipStreamDestroy(cstream);
+        if (comm) (void)c.api.CommDestroy(comm);
+        return pgx::fail(PGX_ERR_RUNTIME, "pgx_comm_init: " + why);
+    }
+    c.cstream = cstream;
+    c.ev_in = ev_in;
+    for (int i = 0; i < kRing; ++i) c.done[i] = done[i];
+    c.scratch = scratch;
     c.rank = rank;
     c.world = world;
     c.issued = 0;
+    c.comm = comm;                                    // last: its presence is what "initialised" means
     return PGX_OK;
 }
 

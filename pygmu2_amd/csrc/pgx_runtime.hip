@@ -268,6 +268,25 @@ int pgx_malloc(void **dptr, size_t bytes) {
         r.live[p] = cls;
     }
     *dptr = p;
+    // The first large block of a process announces a streaming caller (a look-ahead window: 32 MB for 8 blocks of
+    // 1 M frames): its next windows are 2, 4, 8 times longer, and a hipMalloc of that size in the middle of a stream
+    // costs more than rendering the window.  Put one block of each of the next classes aside now (480 MB of 288 GB).
+    static const bool reserve = !(getenv("PGX_POOL_RESERVE") && atoi(getenv("PGX_POOL_RESERVE")) == 0);
+    static bool reserved = false;
+    if (reserve && !reserved && cls >= ((size_t)16 << 20)) {
+        reserved = true;
+        for (size_t c = (size_t)32 << 20; c <= ((size_t)256 << 20); c <<= 1) {
+            if (c == cls) continue;
+            void *q = nullptr;
+            if (hipMalloc(&q, c) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            std::lock_guard<std::mutex> lock(r.mu);
+            r.free_lists[c].push_back(q);                // a cached block like any other (pgx_pool_trim frees it)
+            r.bytes_cached += c;
+        }
+    }
     return PGX_OK;
 }
 

@@ -1510,21 +1510,17 @@ struct SsShared {
 };
 // NW = 4: 2048-frame tiles, two workgroups per CU (512 instances fill the chip in one round and one workgroup's
 // barrier waits overlap the other's arithmetic); NW = 8: 4096-frame tiles for fewer instances.  Same bits.
+// What a workgroup needs per voice before its first tile and what depends on the parameters only: the Dirichlet
+// constants, the rotation sines, the powers of the leak, and per thread / lane the prefix offsets and scan powers.
+// ss_make_tables computes them (as every launch did); k_supersaw_tables leaves them in HBM once per bank so that
+// the workgroups of later launches -- four per instance in the time-segmented form -- only load them (26 KB, L2).
+// Per voice: rot[4], rot_ok, kc[0..4], lam[8], run8, tot, offset[256], lane_pw[64][3].
+constexpr int kSsTabDoubles = 4 + 1 + 5 + 8 + 2 + 256 + 192;
+
 template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels, double sr,
-                const pgx_blitsaw_params *params, double *state, const double *amp_scalar) {
-    constexpr int kTile = NW * 64 * kSawT;
-    __shared__ SsShared<NW> sh;
+__device__ __forceinline__ void ss_make_tables(SsShared<NW> &sh, const pgx_blitsaw_params *pv, int nv, double sr) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int inst = blockIdx.x;
-    const pgx_blitsaw_params *pv = params + (int64_t)inst * nv;
-    double *sv = state + (int64_t)inst * nv * 2;
-    float *ob = out + (int64_t)inst * out_stride;
-    const double g = amp_scalar[inst];
     if (tid < nv) {
-        sh.carry_sum[tid] = 0.0;
-        sh.carry_y[tid] = sv[tid * 2 + 1];
         const pgx_blitsaw_params pt = pv[tid];
         const SawConst kt = saw_const(pt.freq, sr, pt.m, false, 0.0);
         const SawRot r = saw_rot(kt);
@@ -1532,7 +1528,6 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         sh.rot_ok[tid] = r.usable ? 1 : 0;
         sh.kc[tid][0] = kt.inc; sh.kc[tid][1] = kt.m; sh.kc[tid][2] = kt.P; sh.kc[tid][3] = kt.invP;
         sh.kc[tid][4] = kt.m / kt.P;
-        sh.kc[tid][5] = sv[tid * 2 + 0];                    // (the state is rewritten only after the last tile)
         double l = pt.leak;
 #pragma unroll
         for (int t = 1; t < kSawT; t <<= 1) l = l * l;      // leak^T
@@ -1561,9 +1556,167 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             sh.lane_pw[v][lane][0] = lp.lane; sh.lane_pw[v][lane][1] = lp.p16; sh.lane_pw[v][lane][2] = lp.p32;
         }
     }
+}
+
+template <int NW>
+__device__ __forceinline__ void ss_load_tables(SsShared<NW> &sh, const double *tab, int nv) {
+    // all of a batch's loads first (unconditional, clamped index), then the stores: a load inside the branchy store
+    // loop is waited for right behind its issue, one memory latency per entry (seven in a row: ~10 us)
+    constexpr int U = 8;
+    const int total = nv * kSsTabDoubles;
+    for (int base = 0; base < total; base += U * NW * 64) {
+        double val[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * NW * 64 + (int)threadIdx.x;
+            val[u] = tab[idx < total ? idx : total - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * NW * 64 + (int)threadIdx.x;
+            if (idx >= total) continue;
+            const int v = idx / kSsTabDoubles, o = idx - v * kSsTabDoubles;
+            const double x = val[u];
+            if (o < 4) sh.rot[v][o] = x;
+            else if (o < 5) sh.rot_ok[v] = x != 0.0 ? 1 : 0;
+            else if (o < 10) sh.kc[v][o - 5] = x;
+            else if (o < 18) sh.lam[v][o - 10] = x;
+            else if (o < 19) sh.run8[v] = x;
+            else if (o < 20) sh.tot[v] = x;
+            else if (o < 276) {
+#pragma unroll
+                for (int rep = 0; rep < NW / kWaves; ++rep) sh.offset[v][(o - 20) + rep * 256] = x;   // periodic in the wave group
+            } else {
+                const int q = o - 276;
+                sh.lane_pw[v][q / 3][q % 3] = x;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_supersaw_tables(double *tables, int nv, double sr, const pgx_blitsaw_params *params) {
+    __shared__ SsShared<4> sh;
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    ss_make_tables<4>(sh, params + (int64_t)inst * nv, nv, sr);
     __syncthreads();
+    double *tab = tables + (int64_t)inst * nv * kSsTabDoubles;
+    for (int idx = tid; idx < nv * kSsTabDoubles; idx += 256) {
+        const int v = idx / kSsTabDoubles, o = idx - v * kSsTabDoubles;
+        double x;
+        if (o < 4) x = sh.rot[v][o];
+        else if (o < 5) x = (double)sh.rot_ok[v];
+        else if (o < 10) x = sh.kc[v][o - 5];
+        else if (o < 18) x = o - 10 < 7 ? sh.lam[v][o - 10] : 0.0;
+        else if (o < 19) x = sh.run8[v];
+        else if (o < 20) x = sh.tot[v];
+        else if (o < 276) x = sh.offset[v][o - 20];
+        else {
+            const int q = o - 276;
+            x = sh.lane_pw[v][q / 3][q % 3];
+        }
+        tab[idx] = x;
+    }
+}
+
+// Time segments (gridDim.y > 1: a few instances have to fill the chip -- a rank's share of a sharded mix): workgroup
+// (instance, s) renders the tiles [s * seg_tiles, (s + 1) * seg_tiles).  What it needs on entering its first tile is,
+// per voice, the running phase sum (the same additions the lone workgroup makes tile after tile: replayed, a few
+// scalar adds) and the integrator level.  The latter has a closed form for a scalar-frequency oscillator with odd M:
+// the DC-free BLIT is (2/P) * sum_{k=1..(M-1)/2} cos(2 pi k phase) (Dirichlet kernel), each harmonic passes the
+// leaky integrator 1 / (1 - leak z^-1) with a known complex gain, so the steady-state level at a frame with phase ph is
+//     yss(ph) = (2/P) * sum_k Re[ e^(j 2 pi k ph) / (1 - leak e^(-j 2 pi k inc)) ]
+// and y - yss decays exactly like leak^frames: y[s0 - 1] = yss(ph[s0 - 1]) + leak^s0 * (y[b - 1] - yss(ph[b - 1]))
+// from the carried state at the block start b.  (M - 1)/2 <= a few hundred terms, spread over the workgroup: ~1 % of
+// a segment's work; agreement with the recurrence ~1e-14, far below the float32 rounding of the output.
+__device__ __forceinline__ void saw_steady_terms(double ph_a, double ph_b, double inc, double leak, int K, int first,
+                                                 int stride, double &sum_a, double &sum_b) {
+    // lane terms k = first, first + stride, ...: the three unit vectors e^(j 2 pi k x) are evaluated once and then
+    // turned by e^(j 2 pi stride x) (a handful of steps: ~1e-16 each) instead of three sincos per term
+    double a = 0.0, b = 0.0;
+    if (first > K) {
+        sum_a = sum_b = 0.0;
+        return;
+    }
+    const double kk = (double)first, st = (double)stride;
+    double s0, c0, s1, c1, s2, c2, rs0, rc0, rs1, rc1, rs2, rc2;
+    pgx::pgx_sincos_bounded((2.0 * kPi) * (kk * inc), s0, c0);
+    pgx::pgx_sincos_bounded((2.0 * kPi) * (kk * ph_a), s1, c1);
+    pgx::pgx_sincos_bounded((2.0 * kPi) * (kk * ph_b), s2, c2);
+    pgx::pgx_sincos_bounded((2.0 * kPi) * (st * inc), rs0, rc0);
+    pgx::pgx_sincos_bounded((2.0 * kPi) * (st * ph_a), rs1, rc1);
+    pgx::pgx_sincos_bounded((2.0 * kPi) * (st * ph_b), rs2, rc2);
+    for (int k = first; k <= K; k += stride) {
+        const double dr = 1.0 - leak * c0, di = leak * s0;      // 1 - leak e^(-ja) = dr + j di
+        const double inv = 1.0 / (dr * dr + di * di);
+        a += (c1 * dr + s1 * di) * inv;
+        b += (c2 * dr + s2 * di) * inv;
+        double t;
+        t = __builtin_fma(s0, rc0, c0 * rs0); c0 = __builtin_fma(c0, rc0, -(s0 * rs0)); s0 = t;
+        t = __builtin_fma(s1, rc1, c1 * rs1); c1 = __builtin_fma(c1, rc1, -(s1 * rs1)); s1 = t;
+        t = __builtin_fma(s2, rc2, c2 * rs2); c2 = __builtin_fma(c2, rc2, -(s2 * rs2)); s2 = t;
+    }
+    sum_a = a;
+    sum_b = b;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels, double sr,
+                const pgx_blitsaw_params *params, const double *state, double *state_out, const double *amp_scalar,
+                int seg_tiles, const double *tables) {
+    constexpr int kTile = NW * 64 * kSawT;
+    __shared__ SsShared<NW> sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int inst = blockIdx.x;
+    const pgx_blitsaw_params *pv = params + (int64_t)inst * nv;
+    const double *sv = state + (int64_t)inst * nv * 2;
+    double *sv_out = state_out + (int64_t)inst * nv * 2;
+    const int64_t tile_first = (int64_t)blockIdx.y * seg_tiles;
+    const int64_t frame_first = tile_first * kTile;
+    int64_t frame_end = frame_first + (int64_t)seg_tiles * kTile;
+    if (frame_end > n) frame_end = n;
+    if (frame_first >= n) return;
+    float *ob = out + (int64_t)inst * out_stride;
+    const double g = amp_scalar[inst];
+    if (tables) ss_load_tables<NW>(sh, tables + (int64_t)inst * nv * kSsTabDoubles, nv);
+    else ss_make_tables<NW>(sh, pv, nv, sr);
+    if (tid < nv) {
+        sh.carry_sum[tid] = 0.0;
+        sh.carry_y[tid] = sv[tid * 2 + 1];
+        sh.kc[tid][5] = sv[tid * 2 + 0];                    // (the state is rewritten only after the last tile)
+    }
+    __syncthreads();
+    if (tile_first > 0) {
+        // entering a later segment: phase sums by replaying the lone workgroup's per-tile additions, integrator
+        // levels from the closed form (comment above the kernel).  One wave per voice, the harmonics over its lanes:
+        // the voices' sums run side by side and meet no barrier.
+        const int wave = tid >> 6;
+        for (int v = wave; v < nv; v += NW) {
+            double cs = 0.0;
+            for (int64_t t = 0; t < tile_first * (NW / kWaves); ++t) cs = cs + sh.tot[v];
+            const double ph_b = sh.kc[v][5];
+            const double ph_a = pgx::pgx_mod1(ph_b + cs);
+            const int K = ((int)sh.kc[v][1] - 1) / 2;
+            const double leak = pv[v].leak;
+            double pa, pb;
+            saw_steady_terms(ph_a, ph_b, sh.kc[v][0], leak, K, lane + 1, 64, pa, pb);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                pa += __shfl_xor(pa, o);
+                pb += __shfl_xor(pb, o);
+            }
+            if (lane == 0) {
+                const double scale = 2.0 * sh.kc[v][3];                       // 2 / P
+                const double decay = pow(leak, (double)frame_first);
+                sh.carry_sum[v] = cs;
+                sh.carry_y[v] = __builtin_fma(decay, sv[v * 2 + 1] - scale * pb, scale * pa);
+            }
+        }
+        __syncthreads();
+    }
     int parity = 0;
-    for (int64_t base = 0; base < n; base += kTile) {
+    for (int64_t base = frame_first; base < frame_end; base += kTile) {
         const int64_t f0 = base + (int64_t)tid * kSawT;
         const bool full = base + kTile <= n;                // uniform: every frame of the tile is live
         double acc[kSawT];
@@ -1648,8 +1801,8 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 if (!INNER && f0 + j == n - 1) final_y = y;
             }
             if (!INNER && f0 <= n - 1 && n - 1 < f0 + kSawT) {   // the thread that renders the last frame
-                sv[v * 2 + 0] = final_phase;
-                sv[v * 2 + 1] = final_y;
+                sv_out[v * 2 + 0] = final_phase;
+                sv_out[v * 2 + 1] = final_y;
             }
             if (tid == 0) {                                 // every thread holds the same carries
                 sh.carry_sum[v] = carry_sum;
@@ -3000,13 +3153,74 @@ int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, in
     PGX_CHECK_ARG(nvoices >= 1 && nvoices <= 16, "pgx_supersaw_bank: 1..16 voices per instance");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_bank: out_stride too small");
     // (a third wave per SIMD, forced with a 168-VGPR cap, spills and is slower: 0.88 against 0.78 ms per block)
+    const int whole = 1 << 30;             // one segment: the whole block
     if (batch > 256)                       // two 4-wave workgroups per CU; up to 256 instances: one 8-wave each
         hipLaunchKernelGGL(k_supersaw_bank<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
-                           nvoices, n, channels, sample_rate, params, state, amp_scalar);
+                           nvoices, n, channels, sample_rate, params, (const double *)state, state, amp_scalar, whole,
+                           (const double *)nullptr);
     else
         hipLaunchKernelGGL(k_supersaw_bank<8>, dim3(batch), dim3(8 * 64), 0, pgx::stream(), out, out_stride,
-                           nvoices, n, channels, sample_rate, params, state, amp_scalar);
+                           nvoices, n, channels, sample_rate, params, (const double *)state, state, amp_scalar, whole,
+                           (const double *)nullptr);
     PGX_LAUNCH_CHECK("k_supersaw_bank");
+    return PGX_OK;
+}
+
+// The segmented bank runs 8-wave workgroups on 4096-frame tiles, one per CU (two waves on every SIMD): what a
+// workgroup prepares before its first tile -- per-voice constants, per-thread prefix tables, the carries -- is
+// spread over twice the threads and amortised over twice the frames of the 4-wave form.
+constexpr int kSsSegNW = 8;
+
+int pgx_supersaw_bank_segments(int batch, int64_t n) {
+    if (batch <= 0 || n <= 0 || batch > 256) return 1;
+    const int64_t tiles = pgx::ceil_div(n, kSsSegNW * 64 * kSawT);
+    int64_t want = pgx::ceil_div(pgx::kNumCU, batch);
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    const int64_t seg_tiles = pgx::ceil_div(tiles, want);
+    return (int)pgx::ceil_div(tiles, seg_tiles);
+}
+
+size_t pgx_supersaw_bank_table_bytes(int batch, int nvoices) {
+    if (batch <= 0 || nvoices <= 0) return 0;
+    return (size_t)batch * nvoices * kSsTabDoubles * sizeof(double);
+}
+
+int pgx_supersaw_bank_tables(double *tables, int batch, int nvoices, double sample_rate,
+                             const pgx_blitsaw_params *params) {
+    PGX_REQUIRE_INIT();
+    if (batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(tables && params && nvoices >= 1 && nvoices <= 16 && sample_rate > 0,
+                  "pgx_supersaw_bank_tables: bad argument");
+    hipLaunchKernelGGL(k_supersaw_tables, dim3(batch), dim3(256), 0, pgx::stream(), tables, nvoices, sample_rate,
+                       params);
+    PGX_LAUNCH_CHECK("k_supersaw_tables");
+    return PGX_OK;
+}
+
+int pgx_supersaw_bank_seg(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                          double sample_rate, const pgx_blitsaw_params *params, const double *state_in,
+                          double *state_out, const double *amp_scalar, const double *tables) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && params && state_in && state_out && state_in != state_out && amp_scalar && channels >= 1 &&
+                      sample_rate > 0,
+                  "pgx_supersaw_bank_seg: bad argument (state_in and state_out must be two buffers)");
+    PGX_CHECK_ARG(nvoices >= 1 && nvoices <= 16, "pgx_supersaw_bank_seg: 1..16 voices per instance");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_bank_seg: out_stride too small");
+    if (batch > 256) {                     // enough instances for two 4-wave workgroups per CU: one segment each
+        hipLaunchKernelGGL(k_supersaw_bank<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride, nvoices,
+                           n, channels, sample_rate, params, state_in, state_out, amp_scalar, 1 << 30, tables);
+        PGX_LAUNCH_CHECK("k_supersaw_bank");
+        return PGX_OK;
+    }
+    const int64_t tiles = pgx::ceil_div(n, kSsSegNW * 64 * kSawT);
+    const int nseg = pgx_supersaw_bank_segments(batch, n);
+    const int seg_tiles = (int)pgx::ceil_div(tiles, nseg);
+    hipLaunchKernelGGL(k_supersaw_bank<kSsSegNW>, dim3(batch, nseg), dim3(kSsSegNW * 64), 0, pgx::stream(), out,
+                       out_stride, nvoices, n, channels, sample_rate, params, state_in, state_out, amp_scalar,
+                       seg_tiles, tables);
+    PGX_LAUNCH_CHECK("k_supersaw_bank<segments>");
     return PGX_OK;
 }
 

@@ -8,6 +8,7 @@ be initialised, every call that needs the device raises RuntimeError.
 
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import threading
@@ -113,6 +114,10 @@ _SIGNATURES = [
     ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
     ("pgx_blitsaw_biquad_bank", _I, [_P, _L, _I, _L, _D, _P, _P, _P, _P]),
     ("pgx_supersaw_bank", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P]),
+    ("pgx_supersaw_bank_segments", _I, [_I, _L]),
+    ("pgx_supersaw_bank_seg", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P, _P, _P]),
+    ("pgx_supersaw_bank_table_bytes", _Z, [_I, _I]),
+    ("pgx_supersaw_bank_tables", _I, [_P, _I, _I, _D, _P]),
     ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P, _L, _L, _P]),
     ("pgx_ladder_workspace_bytes", _Z, [_I, _L, _I, _L]),
     ("pgx_comb", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _I, _I, _P, _P, _D, _L, _P, _L, _L, _I, _P, _P]),
@@ -214,7 +219,32 @@ def ensure_init(device: int | None = None):
                 "There is no CPU fallback for the render path.")
         check(lib.pgx_init(dev % n.value if device is None else dev), "pgx_init")
         _initialised = True
+        global _exit_hook
+        if not _exit_hook:
+            atexit.register(shutdown)
+            _exit_hook = True
     return lib
+
+
+_exit_hook = False
+
+
+def shutdown() -> None:
+    """Orderly end of the library: wait for the streams, then pgx_shutdown() -- communicator, streams, events and
+    every pooled device / pinned block are released while the HIP runtime (and a profiler's tool library riding on
+    it) is still fully alive.  Registered with atexit by the first ensure_init(): without it the process reached
+    C++ static teardown with three streams, 64+ events and the pools still open, and under rocprofv3 that ended in
+    a SIGSEGV inside __cxa_finalize after the results were written (gpurun_out/r2o_ss.log, round 2).  Buffers that
+    Python still holds are harmless afterwards: pgx_free / pgx_host_free return quietly once the library is down.
+    Safe to call twice; ensure_init() brings the library up again."""
+    global _initialised
+    if not _initialised or _lib is None:
+        return
+    _initialised = False
+    try:
+        _lib.pgx_stream_sync()
+    finally:
+        _lib.pgx_shutdown()
 
 
 def device_available() -> bool:

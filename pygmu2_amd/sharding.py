@@ -260,6 +260,22 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     device.synchronize()               # ... and wait for it: every block is rendered AND reduced
     dist.barrier()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
+    # what a block costs this rank before the exchange: the same stream continued on the rank-local mix alone (no
+    # collective), and with it what the blocks above spent waiting for the slowest rank and the links
+    info = {"owned": len(root.owned)}
+    probe = max(3, min(20, steps))
+    pos = (warmup + steps) * block
+    root.local.render(pos, block)
+    device.synchronize()
+    t1 = time.perf_counter()
+    for i in range(probe):
+        keep["s"] = root.local.render(pos + (1 + i) * block, block)
+    keep["s"].dev
+    device.synchronize()
+    render = (time.perf_counter() - t1) / probe
+    info["render_ms"] = round(render * 1e3, 4)
+    info["render_ms_max"] = round(dist.max_over_ranks(render) * 1e3, 4)
+    info["allreduce_wait_ms"] = round(max(0.0, dt / steps - dist.max_over_ranks(render)) * 1e3, 4) if world > 1 else 0.0
     r.stop()
     if config == "c5":
         name = (f"C5: {voices}-voice polyphonic graph (BlitSawPE->BiquadPE->xAdsrGatedPE per voice)->MixPE, "
@@ -270,4 +286,4 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     else:
         name = (f"C4: {voices} x LadderPE(SuperSawPE 7 voices)->MixPE, 48 kHz mono, {block}-frame blocks, "
                 f"instances sharded i mod {world}")
-    return dt, block, name, {"owned": len(root.owned)}
+    return dt, block, name, info

@@ -40,6 +40,7 @@ MIN_VOICES = 4
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
+SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
 FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
 
@@ -137,9 +138,20 @@ class _SuperSawNode(_Node):
         self.ch = pes[0]._channels
         self.last_end = None
         self.ahead = None            # (start, n, voices buffer, (state copy, last_end))
+        rec = np.concatenate([pe._voice_param_records() for pe in pes])
+        self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
+                                   and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
+        self.state_alt = None        # the segmented bank reads one state buffer and writes the other
+        self.tables = None           # ... and loads what depends on the parameters only (pgx_supersaw_bank_tables)
 
     def fused(self) -> bool:
         return self.k >= FUSED_SUPERSAW_MIN and self.nv <= 16
+
+    def segmented(self, n: int) -> bool:
+        """Fewer instances than fill the chip (a rank's share of a sharded mix): the fused bank in concurrent time
+        segments (pgx_supersaw_bank_seg), carries from the integrator's closed form -- automatic (odd) M, leak < 1."""
+        return (SEGMENTED_SUPERSAW and not self.fused() and self.nv <= 16 and self.closed_form_ok
+                and lib().pgx_supersaw_bank_segments(self.k, n) > 1)
 
     def _forget_ahead(self, restore: bool) -> None:
         ahead, self.ahead = self.ahead, None
@@ -190,6 +202,26 @@ class _SuperSawNode(_Node):
 
     def render(self, start, n):
         L = lib()
+        if self.segmented(n) or (self.fused() and self.closed_form_ok):
+            # (the one-segment bank of >= FUSED_SUPERSAW_MIN instances takes the same entry: per-voice tables loaded
+            # instead of made by every workgroup of every launch)
+            if self.ahead is not None:
+                self._forget_ahead(restore=True)
+            if self.last_end is None or start != self.last_end:
+                self.state.upload(self.init_state)
+            if self.state_alt is None:
+                self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
+                self.tables = DeviceBuffer((L.pgx_supersaw_bank_table_bytes(self.k, self.nv),), np.uint8)
+                check(L.pgx_supersaw_bank_tables(self.tables.ptr, self.k, self.nv, self.sr, self.params.ptr),
+                      "pgx_supersaw_bank_tables")
+            out = DeviceBuffer((self.k, n, self.ch), np.float32)
+            check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
+                                          self.params.ptr, self.state.ptr, self.state_alt.ptr, self.amp.ptr,
+                                          self.tables.ptr),
+                  "pgx_supersaw_bank_seg")
+            self.state, self.state_alt = self.state_alt, self.state
+            self.last_end = start + n
+            return out
         if self.fused():
             # enough instances to fill the chip with one wave per oscillator: voices summed on chip
             if self.last_end is None or start != self.last_end:
@@ -586,8 +618,8 @@ class VoiceBank:
 
     def render_mix(self, start: int, duration: int) -> Snippet:
         root = self.root
-        if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and not root.fused() and duration >= 4096
-                and not lib().pgx_stream_is_forked()):
+        if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and not root.fused()
+                and not root.segmented(duration) and duration >= 4096 and not lib().pgx_stream_is_forked()):
             return self._supersaw_pipelined(start, duration)
         if isinstance(root, _GainNode) and root.gains is None:
             # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix.  The gain

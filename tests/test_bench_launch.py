@@ -50,20 +50,31 @@ def test_parent_reports_a_failed_rank():
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_the_device_print_one_line_with_or_without_the_communicator():
-    """Two real ranks.  On a box with one GPU both land on device 0 and RCCL refuses the communicator: the ranks
-    must agree to carry on with store barriers, measure the replica workload and say that the sharded mixes were
-    not run; on a box with two GPUs the communicator exists.  Either way stdout is exactly one JSON line (RCCL's
-    greeting banner goes to stderr)."""
-    p = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu"], env={"PGX_BENCH_RCCL_TIMEOUT": "60"},
-             timeout=400)
+def test_two_ranks_without_a_communicator_fail_unless_told_otherwise():
+    """Two real ranks.  On a box with one GPU both land on device 0 and RCCL refuses the communicator: the run must
+    FAIL (rank 0's line says n_ranks_seen 0 and why) -- a multi-GPU number without RCCL is not a measurement.  With
+    --allow-no-rccl the ranks agree to carry on with store barriers, measure the replica workload, report
+    n_ranks_seen = 0 / collective "store" and say that the sharded mixes were not run.  On a box with two GPUs the
+    communicator exists and both runs are ordinary.  Either way stdout is exactly one JSON line (RCCL's greeting
+    banner goes to stderr)."""
+    args = ["--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu"]
+    p = _run(args, env={"PGX_BENCH_RCCL_TIMEOUT": "60"}, timeout=400)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    if p.returncode != 0:
+        assert d["n_ranks_seen"] == 0 and d["value"] is None and "RCCL" in d["error"]
+    else:
+        assert d["collective"] == "rccl" and d["n_ranks_seen"] == 2
+        assert d["voice_mix"]["n_ranks"] == 2 and d["voice_mix"]["value"] > 0
+    p = _run(args + ["--allow-no-rccl"], env={"PGX_BENCH_RCCL_TIMEOUT": "60"}, timeout=400)
     assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["value"] > 0
-    assert d["collective"] in ("rccl", "store")
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["collective"] in ("rccl", "store")
     if d["collective"] == "store":
+        assert d["n_ranks_seen"] == 0 and d["n_ranks_present"] == 2
         assert "error" in d["voice_mix"] and "error" in d["supersaw_mix"]
     else:
-        assert d["voice_mix"]["n_ranks"] == 2 and d["voice_mix"]["value"] > 0
+        assert d["n_ranks_seen"] == 2 and d["voice_mix"]["n_ranks"] == 2 and d["voice_mix"]["value"] > 0

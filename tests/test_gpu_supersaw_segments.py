@@ -1,0 +1,69 @@
+"""
+GPU: a small bank of SuperSawPEs under a MixPE (a rank's share of the sharded 512-voice SuperSaw mix) rendered by the
+fused bank kernel in concurrent TIME SEGMENTS (pgx_supersaw_bank_seg: phase sums replayed, integrator levels from
+the closed form of the leaky integrator's response to the BLIT harmonics, blit_saw_pe.py:196-235) against the same
+bank rendered oscillator by oscillator (pgx_blitsaw + pgx_supersaw_sum, whose samples are the single PE's).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mix(pg, count, voices=7, base=55.0, channels=1):
+    return pg.MixPE(*[pg.SuperSawPE(frequency=base * 2 ** (i / 12.0), voices=voices, detune_cents=20.0, seed=i,
+                                    channels=channels) for i in range(count)])
+
+
+def _run(segmented, count, blocks, **kw):
+    import pygmu2_amd as pg
+    from pygmu2_amd import voice_bank
+    pg.set_sample_rate(48000)
+    keep = voice_bank.SEGMENTED_SUPERSAW, voice_bank.PREFETCH_SUPERSAW_VOICES
+    voice_bank.SEGMENTED_SUPERSAW = segmented
+    voice_bank.PREFETCH_SUPERSAW_VOICES = False        # (the pipelined path keeps its states one block ahead)
+    try:
+        mix = _mix(pg, count, **kw)
+        r = pg.NullRenderer(sample_rate=48000)
+        r.set_source(mix)
+        r.start()
+        bank = mix._voice_bank()
+        assert bank and bank.root.segmented(blocks[0][1]) == segmented
+        outs = [mix.render(s, n).data.copy() for s, n in blocks]
+        state = bank.root.state.to_host().copy()
+        r.stop()
+        return outs, state
+    finally:
+        voice_bank.SEGMENTED_SUPERSAW, voice_bank.PREFETCH_SUPERSAW_VOICES = keep
+
+
+@pytest.mark.parametrize("count,kw", [(64, {}), (16, dict(voices=3)), (100, dict(voices=5, base=110.0, channels=2))])
+def test_time_segments_render_the_sequential_bank(count, kw):
+    blocks = [(0, 48_000), (48_000, 48_000), (96_000, 30_001), (500_000, 48_000)]       # a stream, then a seek (reset)
+    got, st_got = _run(True, count, blocks, **kw)
+    want, st_want = _run(False, count, blocks, **kw)
+    for g, w in zip(got, want):
+        peak = float(np.max(np.abs(w)))
+        err = float(np.max(np.abs(g.astype(np.float64) - w)))
+        assert err <= 1e-6 * peak, (err, peak)
+        assert np.mean(g != w) < 2e-3
+    # phases are the same additions; integrator levels agree to the closed form's ~1e-14
+    assert np.allclose(st_got, st_want, rtol=0, atol=1e-11)
+
+
+def test_segment_plan_and_fallbacks():
+    import pygmu2_amd as pg
+    from pygmu2_amd import device
+    lib = device.ensure_init()
+    assert lib.pgx_supersaw_bank_segments(64, 48_000) == 4          # 12 tiles of 4096 frames, 3 per segment
+    assert lib.pgx_supersaw_bank_segments(512, 48_000) == 1
+    assert lib.pgx_supersaw_bank_segments(64, 4096) == 1
+    pg.set_sample_rate(48000)
+    # an explicit leak of 1.0 has no steady state: the bank keeps the oscillator-by-oscillator path
+    mix = pg.MixPE(*[pg.SuperSawPE(frequency=110.0 + i, voices=3, seed=i) for i in range(8)])
+    for pe in mix._inputs:
+        for osc in pe._oscillators:
+            osc._leak = 1.0
+    bank = mix._voice_bank()
+    assert bank and not bank.root.segmented(48_000)

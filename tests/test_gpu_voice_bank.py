@@ -68,7 +68,8 @@ def test_c4_bank_supersaw_ladder():
     plain._bank = False
     got_plain = _render_blocks(plain, 48000, blocks)
     for a, b in zip(got_bank, got_plain):
-        assert np.array_equal(a, b)
+        # the bank's oscillators run in concurrent time segments (closed-form integrator carries, ~1e-14 in float64)
+        assert float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * float(np.max(np.abs(b)))
     spec = S("MixPE", inputs=[
         S("LadderPE", source=S("SuperSawPE", frequency=55.0 * 2 ** (i / 12.0), voices=7, detune_cents=20.0, seed=i),
           frequency=1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2) for i in range(6)])
@@ -203,6 +204,7 @@ def test_supersaw_bank_summed_on_chip_is_the_two_launch_path_bit_for_bit(voices,
     got_fused = _render_blocks(fused, 48000, blocks)
     assert fused._bank and fused._bank.root.k == n_inst
     monkeypatch.setattr(voice_bank, "FUSED_SUPERSAW_MIN", 10 ** 9)
+    monkeypatch.setattr(voice_bank, "SEGMENTED_SUPERSAW", False)      # (tests/test_gpu_supersaw_segments.py)
     two = make()
     got_two = _render_blocks(two, 48000, blocks)
     for a, b in zip(got_fused, got_two):
