@@ -1535,6 +1535,7 @@ __device__ __forceinline__ void ss_make_tables(SsShared<NW> &sh, const pgx_blits
             sh.lam[tid][k] = l;
             l = l * l;
         }
+        sh.lam[tid][7] = pt.leak;
     }
     __syncthreads();
     for (int v = 0; v < nv; ++v) {                          // the per-thread tables (all threads, every voice)
@@ -1607,7 +1608,7 @@ k_supersaw_tables(double *tables, int nv, double sr, const pgx_blitsaw_params *p
         if (o < 4) x = sh.rot[v][o];
         else if (o < 5) x = (double)sh.rot_ok[v];
         else if (o < 10) x = sh.kc[v][o - 5];
-        else if (o < 18) x = o - 10 < 7 ? sh.lam[v][o - 10] : 0.0;
+        else if (o < 18) x = sh.lam[v][o - 10];
         else if (o < 19) x = sh.run8[v];
         else if (o < 20) x = sh.tot[v];
         else if (o < 276) x = sh.offset[v][o - 20];
@@ -1639,13 +1640,13 @@ __device__ __forceinline__ void saw_steady_terms(double ph_a, double ph_b, doubl
         return;
     }
     const double kk = (double)first, st = (double)stride;
-    double s0, c0, s1, c1, s2, c2, rs0, rc0, rs1, rc1, rs2, rc2;
-    pgx::pgx_sincos_bounded((2.0 * kPi) * (kk * inc), s0, c0);
-    pgx::pgx_sincos_bounded((2.0 * kPi) * (kk * ph_a), s1, c1);
-    pgx::pgx_sincos_bounded((2.0 * kPi) * (kk * ph_b), s2, c2);
-    pgx::pgx_sincos_bounded((2.0 * kPi) * (st * inc), rs0, rc0);
-    pgx::pgx_sincos_bounded((2.0 * kPi) * (st * ph_a), rs1, rc1);
-    pgx::pgx_sincos_bounded((2.0 * kPi) * (st * ph_b), rs2, rc2);
+    // six evaluations through one copy of the routine (a loop the compiler must not unroll): this code runs once per
+    // workgroup, straight from a cold instruction cache -- its size, not its arithmetic, is what it costs
+    double arg[6] = {kk * inc, kk * ph_a, kk * ph_b, st * inc, st * ph_a, st * ph_b}, sn[6], cs[6];
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) pgx::pgx_sincos_bounded((2.0 * kPi) * arg[i], sn[i], cs[i]);
+    double s0 = sn[0], c0 = cs[0], s1 = sn[1], c1 = cs[1], s2 = sn[2], c2 = cs[2];
+    const double rs0 = sn[3], rc0 = cs[3], rs1 = sn[4], rc1 = cs[4], rs2 = sn[5], rc2 = cs[5];
     for (int k = first; k <= K; k += stride) {
         const double dr = 1.0 - leak * c0, di = leak * s0;      // 1 - leak e^(-ja) = dr + j di
         const double inv = 1.0 / (dr * dr + di * di);
@@ -1660,6 +1661,9 @@ __device__ __forceinline__ void saw_steady_terms(double ph_a, double ph_b, doubl
     sum_b = b;
 }
 
+#ifndef PGX_SS_STAMP
+#define PGX_SS_STAMP(i)            /* tools/microbench/ss_phases.hip defines it to record wall_clock64() */
+#endif
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
 k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels, double sr,
@@ -1679,14 +1683,18 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
     if (frame_first >= n) return;
     float *ob = out + (int64_t)inst * out_stride;
     const double g = amp_scalar[inst];
+    PGX_SS_STAMP(0);
+    // the carried state is requested before the tables so that the two memory round trips overlap
+    const double st_phase = sv[(tid < nv ? tid : 0) * 2 + 0], st_level = sv[(tid < nv ? tid : 0) * 2 + 1];
     if (tables) ss_load_tables<NW>(sh, tables + (int64_t)inst * nv * kSsTabDoubles, nv);
     else ss_make_tables<NW>(sh, pv, nv, sr);
     if (tid < nv) {
         sh.carry_sum[tid] = 0.0;
-        sh.carry_y[tid] = sv[tid * 2 + 1];
-        sh.kc[tid][5] = sv[tid * 2 + 0];                    // (the state is rewritten only after the last tile)
+        sh.carry_y[tid] = st_level;
+        sh.kc[tid][5] = st_phase;                           // (the state is rewritten only after the last tile)
     }
     __syncthreads();
+    PGX_SS_STAMP(1);
     if (tile_first > 0) {
         // entering a later segment: phase sums by replaying the lone workgroup's per-tile additions, integrator
         // levels from the closed form (comment above the kernel).  One wave per voice, the harmonics over its lanes:
@@ -1698,7 +1706,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             const double ph_b = sh.kc[v][5];
             const double ph_a = pgx::pgx_mod1(ph_b + cs);
             const int K = ((int)sh.kc[v][1] - 1) / 2;
-            const double leak = pv[v].leak;
+            const double leak = sh.lam[v][7];
             double pa, pb;
             saw_steady_terms(ph_a, ph_b, sh.kc[v][0], leak, K, lane + 1, 64, pa, pb);
 #pragma unroll
@@ -1708,24 +1716,38 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             }
             if (lane == 0) {
                 const double scale = 2.0 * sh.kc[v][3];                       // 2 / P
-                const double decay = pow(leak, (double)frame_first);
+                // leak^frame_first, frame_first = tile_first tiles of NW * 512 frames: from leak^512 by squarings
+                double per_tile = sh.lam[v][6];
+#pragma unroll
+                for (int t = 1; t < NW; t <<= 1) per_tile = per_tile * per_tile;
+                double decay = 1.0;
+                for (int64_t e = tile_first; e > 0; e >>= 1) {
+                    if (e & 1) decay = decay * per_tile;
+                    per_tile = per_tile * per_tile;
+                }
                 sh.carry_sum[v] = cs;
-                sh.carry_y[v] = __builtin_fma(decay, sv[v * 2 + 1] - scale * pb, scale * pa);
+                sh.carry_y[v] = __builtin_fma(decay, sh.carry_y[v] - scale * pb, scale * pa);
             }
         }
         __syncthreads();
     }
+    PGX_SS_STAMP(2);
     int parity = 0;
     for (int64_t base = frame_first; base < frame_end; base += kTile) {
+        PGX_SS_STAMP(3 + (int)((base - frame_first) / kTile));
         const int64_t f0 = base + (int64_t)tid * kSawT;
-        const bool full = base + kTile <= n;                // uniform: every frame of the tile is live
         double acc[kSawT];
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) acc[j] = 0.0;
-        // A tile strictly inside the block (every frame live, the block's last frame elsewhere) drops the per-sample
-        // bounds selects and the carried-state captures: ~10 of the ~75 instructions per sample.  Same arithmetic.
-        auto voices = [&](auto inner_tag) {
-        constexpr bool INNER = decltype(inner_tag)::value;
+        // Every tile runs the body without per-sample bounds tests: frames past the end of the block are rendered like
+        // the others (their phases and levels only reach lanes that hold no live frame, and the stores are bounded),
+        // so what the live frames get is the same arithmetic as ever.  LAST = the tile that holds the block's last
+        // frame: the thread that renders it also captures the carried state.  (A separate bounds-testing body for that
+        // tile cost 5 us more than a plain one -- its code was cold in the instruction cache -- and in the
+        // time-segmented form the workgroups that own it are the critical path.)
+        auto voices = [&](auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool INNER = true;
 #pragma unroll 1
         for (int v = 0; v < nv; ++v, ++parity) {
             const pgx_blitsaw_params p = pv[v];
@@ -1743,29 +1765,18 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             double carry_sum = sh.carry_sum[v], carry_y = sh.carry_y[v];
             double loc[kSawT];
             double chunk_base;
-            if (INNER) {
-                // every frame live: the thread's increments, their scan and the folds are this voice's table entries
-                if (!sh.rot_ok[v]) {                           // (only the per-sample Dirichlet forms read loc[1..])
-                    double run = 0.0;
-#pragma unroll
-                    for (int j = 0; j < kSawT; ++j) {
-                        run = run + k0.inc;
-                        loc[j] = run;
-                    }
-                } else {
-                    loc[0] = 0.0 + k0.inc;
-                }
-                chunk_base = block_excl_sum_wide_uniform<NW>(UniformPrefix{sh.offset[v][tid], sh.tot[v]}, carry_sum);
-            } else {
+            // the thread's increments, their scan and the folds are this voice's table entries
+            if (!sh.rot_ok[v]) {                               // (only the per-sample Dirichlet forms read loc[1..])
                 double run = 0.0;
 #pragma unroll
                 for (int j = 0; j < kSawT; ++j) {
-                    run = run + ((f0 + j < n) ? k0.inc : 0.0);
+                    run = run + k0.inc;
                     loc[j] = run;
                 }
-                chunk_base = full ? block_excl_sum_wide_uniform<NW>(run, carry_sum)
-                                  : block_excl_sum_wide<NW>(run, sh.sum, carry_sum);
+            } else {
+                loc[0] = 0.0 + k0.inc;
             }
+            chunk_base = block_excl_sum_wide_uniform<NW>(UniformPrefix{sh.offset[v][tid], sh.tot[v]}, carry_sum);
             double xb[kSawT];
             double final_phase = 0.0, final_y = 0.0;
             const double m_over_p = sh.kc[v][4];
@@ -1779,14 +1790,14 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                     const double sin_den = pgx::pgx_sin_bounded(theta);
                     double blit = pgx::pgx_div_fast(sin_num, k0.P * sin_den);   // a select, not a branch (k_blitsaw)
                     if (fabs(sin_den) < 1e-9) blit = m_over_p;
-                    xb[j] = (INNER || f0 + j < n) ? (blit - k0.invP) : 0.0;
-                    if (!INNER && f0 + j == n - 1) final_phase = ph;
+                    xb[j] = blit - k0.invP;
+                    if (LAST && f0 + j == n - 1) final_phase = ph;
                 }
             };
             if (sh.rot_ok[v]) {
                 const SawRot rot{sh.rot[v][0], sh.rot[v][1], sh.rot[v][2], sh.rot[v][3], true};
                 saw_dirichlet_rot<INNER>(pgx::pgx_mod1(phase0 + (chunk_base + loc[0])), k0, rot, m_over_p, f0, n, xb);
-                if (!INNER && f0 <= n - 1 && n - 1 < f0 + kSawT) final_phase = saw_phase_at(phase0, chunk_base, k0.inc, (int)(n - 1 - f0));
+                if (LAST && f0 <= n - 1 && n - 1 < f0 + kSawT) final_phase = saw_phase_at(phase0, chunk_base, k0.inc, (int)(n - 1 - f0));
             } else if (k0.m < kSawBoundedM) dirichlet(std::true_type{});
             else dirichlet(std::false_type{});
             double e = 0.0;
@@ -1798,9 +1809,9 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 double z = leak * y;
                 y = z + xb[j];
                 acc[j] += (double)(float)(y * amp2);           // (y * 2) * amp: doubling is exact, so 2 * amp first
-                if (!INNER && f0 + j == n - 1) final_y = y;
+                if (LAST && f0 + j == n - 1) final_y = y;
             }
-            if (!INNER && f0 <= n - 1 && n - 1 < f0 + kSawT) {   // the thread that renders the last frame
+            if (LAST && f0 <= n - 1 && n - 1 < f0 + kSawT) {     // the thread that renders the last frame
                 sv_out[v * 2 + 0] = final_phase;
                 sv_out[v * 2 + 1] = final_y;
             }
@@ -1810,8 +1821,8 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             }
         }
         };
-        if (base + kTile < n) voices(std::true_type{});
-        else voices(std::false_type{});
+        if (base + kTile < n) voices(std::false_type{});
+        else voices(std::true_type{});
         float yf[kSawT];
 #pragma unroll
         for (int j = 0; j < kSawT; ++j) yf[j] = (float)(acc[j] * g);
@@ -1819,6 +1830,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         if (nv == 1) __syncthreads();                       // with more voices the carries written above are
                                                             // read again only after the other voices' barriers
     }
+    PGX_SS_STAMP(15);
 }
 
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
@@ -3166,15 +3178,20 @@ int pgx_supersaw_bank(float *out, int64_t out_stride, int batch, int nvoices, in
     return PGX_OK;
 }
 
-// The segmented bank runs 8-wave workgroups on 4096-frame tiles, one per CU (two waves on every SIMD): what a
-// workgroup prepares before its first tile -- per-voice constants, per-thread prefix tables, the carries -- is
-// spread over twice the threads and amortised over twice the frames of the 4-wave form.
-constexpr int kSsSegNW = 8;
+// The segmented bank: 8-wave workgroups on 4096-frame tiles, one per CU, or 4-wave workgroups on 2048-frame tiles,
+// two per CU (one's memory latencies and barrier waits overlap the other's arithmetic).  PGX_SS_SEG_NW picks (experiments).
+static int ss_seg_nw() {
+    static const int nw = getenv("PGX_SS_SEG_NW") ? atoi(getenv("PGX_SS_SEG_NW")) : 8;
+    return nw == 4 ? 4 : 8;
+}
 
 int pgx_supersaw_bank_segments(int batch, int64_t n) {
     if (batch <= 0 || n <= 0 || batch > 256) return 1;
-    const int64_t tiles = pgx::ceil_div(n, kSsSegNW * 64 * kSawT);
-    int64_t want = pgx::ceil_div(pgx::kNumCU, batch);
+    const int nw = ss_seg_nw();
+    const int64_t tiles = pgx::ceil_div(n, nw * 64 * kSawT);
+    int64_t want = pgx::ceil_div((nw == 4 ? 2 : 1) * pgx::kNumCU, batch);
+    static const int forced = getenv("PGX_SS_SEGS") ? atoi(getenv("PGX_SS_SEGS")) : 0;      // experiments
+    if (forced > 0) want = forced;
     if (want > tiles) want = tiles;
     if (want < 1) want = 1;
     const int64_t seg_tiles = pgx::ceil_div(tiles, want);
@@ -3214,12 +3231,16 @@ int pgx_supersaw_bank_seg(float *out, int64_t out_stride, int batch, int nvoices
         PGX_LAUNCH_CHECK("k_supersaw_bank");
         return PGX_OK;
     }
-    const int64_t tiles = pgx::ceil_div(n, kSsSegNW * 64 * kSawT);
+    const int nw = ss_seg_nw();
+    const int64_t tiles = pgx::ceil_div(n, nw * 64 * kSawT);
     const int nseg = pgx_supersaw_bank_segments(batch, n);
     const int seg_tiles = (int)pgx::ceil_div(tiles, nseg);
-    hipLaunchKernelGGL(k_supersaw_bank<kSsSegNW>, dim3(batch, nseg), dim3(kSsSegNW * 64), 0, pgx::stream(), out,
-                       out_stride, nvoices, n, channels, sample_rate, params, state_in, state_out, amp_scalar,
-                       seg_tiles, tables);
+    if (nw == 4)
+        hipLaunchKernelGGL(k_supersaw_bank<4>, dim3(batch, nseg), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
+                           nvoices, n, channels, sample_rate, params, state_in, state_out, amp_scalar, seg_tiles, tables);
+    else
+        hipLaunchKernelGGL(k_supersaw_bank<8>, dim3(batch, nseg), dim3(8 * 64), 0, pgx::stream(), out, out_stride,
+                           nvoices, n, channels, sample_rate, params, state_in, state_out, amp_scalar, seg_tiles, tables);
     PGX_LAUNCH_CHECK("k_supersaw_bank<segments>");
     return PGX_OK;
 }

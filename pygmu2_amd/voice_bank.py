@@ -40,6 +40,7 @@ MIN_VOICES = 4
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
+PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
 FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
@@ -142,6 +143,7 @@ class _SuperSawNode(_Node):
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
         self.state_alt = None        # the segmented bank reads one state buffer and writes the other
+        self.ahead_bank = None       # (start, n, bank output, last_end before): VoiceBank._supersaw_pipelined
         self.tables = None           # ... and loads what depends on the parameters only (pgx_supersaw_bank_tables)
 
     def fused(self) -> bool:
@@ -162,6 +164,7 @@ class _SuperSawNode(_Node):
 
     def reset(self):
         self._forget_ahead(restore=False)
+        self.ahead_bank = None
         self.last_end = None
 
     def channels(self):
@@ -170,6 +173,8 @@ class _SuperSawNode(_Node):
     def _voices(self, start, n, backup=None):
         """[instances * voices][n] float32 oscillator samples, on the current stream.  backup: a buffer that
         receives the states on entry (written by the oscillator kernel itself: no extra launch)."""
+        if self.ahead_bank is not None:
+            self._forget_bank_ahead(restore=True)
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
         voices = DeviceBuffer((self.k * self.nv, n), np.float32)
@@ -200,28 +205,59 @@ class _SuperSawNode(_Node):
                                      self.amp.ptr, None, 0), "pgx_supersaw_sum")
         return out
 
+    def banked(self, n: int) -> bool:
+        """The voices-summed-on-chip kernel with per-voice tables and double-buffered states (pgx_supersaw_bank_seg):
+        in time segments for a few instances, one segment each from FUSED_SUPERSAW_MIN instances on."""
+        return self.segmented(n) or (self.fused() and self.closed_form_ok)
+
+    def _bank(self, start, n):
+        """[instances][n][channels] on the current stream; the states move from `state` to `state_alt` and swap."""
+        L = lib()
+        if self.ahead is not None:
+            self._forget_ahead(restore=True)
+        if self.last_end is None or start != self.last_end:
+            self.state.upload(self.init_state)
+        if self.state_alt is None:
+            self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
+            self.tables = DeviceBuffer((L.pgx_supersaw_bank_table_bytes(self.k, self.nv),), np.uint8)
+            check(L.pgx_supersaw_bank_tables(self.tables.ptr, self.k, self.nv, self.sr, self.params.ptr),
+                  "pgx_supersaw_bank_tables")
+        out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
+                                      self.params.ptr, self.state.ptr, self.state_alt.ptr, self.amp.ptr,
+                                      self.tables.ptr),
+              "pgx_supersaw_bank_seg")
+        self.state, self.state_alt = self.state_alt, self.state
+        self.last_end = start + n
+        return out
+
+    def _forget_bank_ahead(self, restore: bool) -> None:
+        ahead, self.ahead_bank = self.ahead_bank, None
+        if ahead is not None and restore:
+            # one render happened since: the states it started from are the other buffer
+            self.state, self.state_alt = self.state_alt, self.state
+            self.last_end = ahead[3]
+
+    def take_bank(self, start, n):
+        """The bank's output for (start, n): the block rendered ahead if it is this one, else rendered now (after the
+        states went back to where the caller's last block left them)."""
+        if self.ahead_bank is not None:
+            if self.ahead_bank[0] == start and self.ahead_bank[1] == n:
+                out, self.ahead_bank = self.ahead_bank[2], None
+                return out
+            self._forget_bank_ahead(restore=True)
+        return self._bank(start, n)
+
+    def render_bank_ahead(self, start, n) -> None:
+        last_end = self.last_end
+        self.ahead_bank = (start, n, self._bank(start, n), last_end)
+
     def render(self, start, n):
         L = lib()
-        if self.segmented(n) or (self.fused() and self.closed_form_ok):
-            # (the one-segment bank of >= FUSED_SUPERSAW_MIN instances takes the same entry: per-voice tables loaded
-            # instead of made by every workgroup of every launch)
-            if self.ahead is not None:
-                self._forget_ahead(restore=True)
-            if self.last_end is None or start != self.last_end:
-                self.state.upload(self.init_state)
-            if self.state_alt is None:
-                self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
-                self.tables = DeviceBuffer((L.pgx_supersaw_bank_table_bytes(self.k, self.nv),), np.uint8)
-                check(L.pgx_supersaw_bank_tables(self.tables.ptr, self.k, self.nv, self.sr, self.params.ptr),
-                      "pgx_supersaw_bank_tables")
-            out = DeviceBuffer((self.k, n, self.ch), np.float32)
-            check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
-                                          self.params.ptr, self.state.ptr, self.state_alt.ptr, self.amp.ptr,
-                                          self.tables.ptr),
-                  "pgx_supersaw_bank_seg")
-            self.state, self.state_alt = self.state_alt, self.state
-            self.last_end = start + n
-            return out
+        if self.banked(n):
+            return self.take_bank(start, n)
+        if self.ahead_bank is not None:
+            self._forget_bank_ahead(restore=True)
         if self.fused():
             # enough instances to fill the chip with one wave per oscillator: voices summed on chip
             if self.last_end is None or start != self.last_end:
@@ -594,32 +630,40 @@ class VoiceBank:
         self.root.reset()
 
     def _supersaw_pipelined(self, start: int, n: int) -> Snippet:
-        """A small bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8).  The
-        oscillators are the long pole (69 of 94 us) and depend on nothing but time and two carried numbers each, so they
-        own the main stream, one block ahead: block k's voice sum and mix run on the side stream beside block k+1's
-        oscillators.  Nothing on the main stream ever waits for the side stream to catch up (the join at the end is
+        """A bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8 -- or all 512).
+        The oscillators are the long pole and depend on nothing but time and two carried numbers each, so they
+        own the main stream, one block ahead: block k's mix (and, on the oscillator-by-oscillator path, its voice
+        sum) runs on the side stream beside block k+1's oscillators.  Nothing on the main stream ever waits for the side stream to catch up (the join at the end is
         enqueued behind the oscillators, which outlast sum + mix): a cross-stream wait that has to wake a stalled
         queue costs ~16 us on this part, a whole launch.  A pull that is not the next block copies the oscillator
         states back (take_voices).  What follows on the library stream -- the all-reduce of this block, a read-back --
         runs behind the next block's oscillators: one block of latency, no throughput."""
         root, L = self.root, lib()
-        voices = root.take_voices(start, n)
+        banked = root.banked(n)
+        # main stream: this block's oscillators (already there when the previous call rendered them ahead)
+        first = root.take_bank(start, n) if banked else root.take_voices(start, n)
         check(L.pgx_stream_fork(), "pgx_stream_fork")                  # side stream: behind this block's oscillators
         try:
-            stacked = root.sum_voices(voices, n)
+            stacked = first if banked else root.sum_voices(first, n)
             ch = stacked.shape[2]
             out = DeviceBuffer((n, ch), np.float32)
             check(L.pgx_mix_batch(out.ptr, stacked.ptr, n * ch, self.k, n * ch), "pgx_mix_batch")
             check(L.pgx_stream_select(0), "pgx_stream_select")
-            root.render_ahead(start + n, n)                            # main stream
+            if banked:
+                root.render_bank_ahead(start + n, n)                   # main stream
+            else:
+                root.render_ahead(start + n, n)
         finally:
             check(L.pgx_stream_join(), "pgx_stream_join")
         return Snippet(start, out)
 
     def render_mix(self, start: int, duration: int) -> Snippet:
         root = self.root
+        # (the voices-summed-on-chip bank + mix stay on one stream: with the bank one block ahead and the mix on the
+        # side stream a rank's share went from 60.5 to 64.3 us -- the fork / join packets cost more than the 5 us mix)
         if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and not root.fused()
-                and not root.segmented(duration) and duration >= 4096 and not lib().pgx_stream_is_forked()):
+                and (PIPELINE_SUPERSAW_BANK or not root.banked(duration)) and duration >= 4096
+                and not lib().pgx_stream_is_forked()):
             return self._supersaw_pipelined(start, duration)
         if isinstance(root, _GainNode) and root.gains is None:
             # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix.  The gain
