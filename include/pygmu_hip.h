@@ -269,6 +269,10 @@ int pgx_interp_lookup(float *out, const float *window, int64_t window_start, int
 /* result_dev[0..1] = min, max of float64(start + i) - delay[i]  (np.min / np.max of the indices,
  * interpolated_lookup.py:111-112): the host sizes the source window from them. */
 int pgx_index_range(double *result_dev, const float *delay, int64_t start, int64_t n);
+/* partials_dev[2 p + {0, 1}] = (min, max) of workgroup p's share of the mono stream x[0..n), p < parts <= 1024
+ * (NaN if it met one): the host folds the pairs.  LadderPE with a PE-driven cutoff / resonance sizes the warm-up
+ * of its time segments from the block's lowest cutoff and highest resonance (ladder_pe.py:84-113 clamps). */
+int pgx_stream_range(double *partials_dev, int parts, const float *x, int64_t n);
 /* PiecewisePE._render (piecewise_pe.py:164-229); times sorted int64, values float64 (device).
  * transition: 0 step, 1 linear, 2 exponential, 3 sigmoid, 4 constant_power. */
 int pgx_piecewise(float *out, int64_t start, int64_t n, int channels, const int64_t *times,

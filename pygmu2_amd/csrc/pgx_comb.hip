@@ -28,7 +28,8 @@ namespace {
 constexpr double kMaxFeedback = 0.995;                  // comb_pe.py:32 (max_feedback passed by _render)
 constexpr int kPolySingleSteps = 1024;                  // up to this many steps per lane: one segment (exact)
 constexpr int kPolySegSteps = 64;                       // steps per lane and segment when segmented
-constexpr int kPolyMaxSeg = 512;                        // the apply pass folds up to this many (P, Z) pairs per lane
+constexpr int kPolyMaxSeg = 512;
+constexpr int kPolyBatch = 32;                          // loads in flight per lane (and as many being consumed)                        // the apply pass folds up to this many (P, Z) pairs per lane
 
 __device__ __forceinline__ double comb_fb(double f) {   // comb_pe.py:87-95
     f = isfinite(f) ? f : 0.0;
@@ -83,15 +84,24 @@ k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, 
         const int64_t e0 = seg * seg_frames * channels + chain;   // first element of the lane
         const int64_t f0 = seg * seg_frames + r;
         double z = 0.0, p = 1.0;
-        constexpr int U = 8;
-        for (int64_t k0 = 0; k0 < plan.steps; k0 += U) {
-            float xv[U], fv[U];
+        // A lane's frames are D frames apart: every step is its own memory transaction, and the chain itself is two
+        // dependent operations per step.  U loads are kept in flight while the U before them are consumed (a batch
+        // fetched, waited for and consumed in turn cost one memory latency per 8 steps: 61 us for a 44 100-frame block).
+        constexpr int U = kPolyBatch;
+        float xa[U], fa[U];
+        // (uniform base pointer + 32-bit lane offset: see APPLY)
+        const unsigned xo = (unsigned)e0, fo = (unsigned)f0;
+        const unsigned sx = (unsigned)DC, sf = (unsigned)D, last = (unsigned)(plan.steps - 1);
+        auto fetch = [&](int64_t k0, float (&xv)[U], float (&fv)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t k = (k0 + u < plan.steps) ? k0 + u : plan.steps - 1;
-                xv[u] = x[e0 + k * DC];
-                fv[u] = FBS ? fbs[f0 + k * D] : 0.f;
+                unsigned k = (unsigned)k0 + u;
+                k = k < last ? k : last;
+                xv[u] = x[xo + k * sx];
+                fv[u] = FBS ? fbs[fo + k * sf] : 0.f;
             }
+        };
+        auto consume = [&](int64_t k0, const float (&xv)[U], const float (&fv)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (k0 + u < plan.steps) {
@@ -100,6 +110,14 @@ k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, 
                     p *= f;
                 }
             }
+        };
+        float xb[U], fb2[U];
+        fetch(0, xa, fa);
+        for (int64_t k0 = 0; k0 < plan.steps; k0 += 2 * U) {      // two register images used in turn (see APPLY)
+            fetch(k0 + U, xb, fb2);
+            consume(k0, xa, fa);
+            fetch(k0 + 2 * U, xa, fa);
+            consume(k0 + U, xb, fb2);
         }
         P[L] = p;
         Z[L] = z;
@@ -123,7 +141,22 @@ k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, 
     int64_t row = (wp0 + r - D) % len;
     if (row < 0) row += len;
     double c = ring_old[row * channels + ch];
-    for (int64_t t = 0; t < seg; ++t) c = __builtin_fma(P[t * DC + chain], c, Z[t * DC + chain]);
+    {
+        // the earlier segments' (P, Z) pairs, a batch of loads at a time
+        constexpr int U = 16;
+        for (int64_t t0 = 0; t0 < seg; t0 += U) {
+            double pv[U], zv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t t = (t0 + u < seg) ? t0 + u : seg - 1;
+                pv[u] = P[t * DC + chain];
+                zv[u] = Z[t * DC + chain];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u < seg) c = __builtin_fma(pv[u], c, zv[u]);
+        }
+    }
 
     float *y = out + (int64_t)voice * out_stride;
     const int64_t f0 = seg * seg_frames + r;                      // first frame of the lane
@@ -131,24 +164,70 @@ k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, 
     if (f0 >= n) steps = 0;
     else if (f0 + (steps - 1) * D >= n) steps = (n - 1 - f0) / D + 1;
     const int64_t keep_from = n - len;                            // frames from here on stay in the ring
-    int64_t slot = (wp0 + f0) % len;                              // ring row of the lane's current frame
-    constexpr int U = 8;
-    for (int64_t k0 = 0; k0 < steps; k0 += U) {
-        float xv[U], fv[U];
+    if (steps <= 0) return;
+    constexpr int U = kPolyBatch;
+    // Element offsets inside a voice's block fit 32 bits (the entry point checks n * channels < 2^30): every access is
+    // "uniform base pointer + 32-bit lane offset", one address register per access instead of two -- with 2 x 32
+    // loads in flight that is the difference between one and two or three waves per SIMD.
+    const unsigned xo = (unsigned)(f0 * channels + ch), fo = (unsigned)f0;
+    const unsigned sx = (unsigned)DC, sf = (unsigned)D, last = (unsigned)(steps - 1);
+    // the lane's first step whose frame stays in the ring (keep_from <= f0 + k * D)
+    int64_t keep_k = keep_from <= f0 ? 0 : (keep_from - f0 + D - 1) / D;
+    if (keep_k > steps) keep_k = steps;
+    auto fetch = [&](unsigned k0, float (&xv)[U], float (&fv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k = (k0 + u < steps) ? k0 + u : steps - 1;
-            xv[u] = x[(f0 + k * D) * channels + ch];
-            fv[u] = FBS ? fbs[f0 + k * D] : 0.f;
+            unsigned k = k0 + u;
+            k = k < last ? k : last;
+            xv[u] = x[xo + k * sx];
+            fv[u] = FBS ? fbs[fo + k * sf] : 0.f;
         }
+    };
+    // U whole steps that neither end the lane's run nor reach the ring: nothing but the recurrence and its store
+    auto plain = [&](unsigned k0, const float (&xv)[U], const float (&fv)[U]) {
+        unsigned off = xo + k0 * sx;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (k0 + u < steps) {
-                const int64_t i = f0 + (k0 + u) * D;
+            const double f = FBS ? comb_fb((double)fv[u]) : fbc;
+            const double v = (double)xv[u] + f * c;               // comb_pe.py:97 (multiply, then add)
+            y[off] = (float)v;
+            off += sx;
+            c = v;
+        }
+    };
+    // Phase 1: whole batches before the ring part, two register images used in turn -- the loads of one are in flight
+    // while the other is consumed, and nothing waits for them at the end of an iteration (copying one image onto the
+    // other did: the wait for the next batch sat behind every batch's arithmetic instead of under it).
+    const unsigned whole = (unsigned)(keep_k / U) * U;
+    unsigned k = 0;
+    if (whole) {
+        float xa[U], fa[U], xb[U], fb2[U];
+        fetch(0, xa, fa);
+        while (k + 2 * U <= whole) {
+            fetch(k + U, xb, fb2);
+            plain(k, xa, fa);
+            fetch(k + 2 * U, xa, fa);                             // (clamped: the last one may fetch past `whole`)
+            plain(k + U, xb, fb2);
+            k += 2 * U;
+        }
+        if (k + U <= whole) {
+            plain(k, xa, fa);
+            k += U;
+        }
+    }
+    // Phase 2: the steps that are left -- the ring part (the last buffer_len frames) and the ragged end
+    int64_t slot = (wp0 + f0 + (int64_t)k * D) % len;             // ring row of the lane's current frame
+    for (unsigned k0 = k; k0 <= last; k0 += U) {
+        float xv[U], fv[U];
+        fetch(k0, xv, fv);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned kk = k0 + u;
+            if (kk <= last) {
                 const double f = FBS ? comb_fb((double)fv[u]) : fbc;
-                const double v = (double)xv[u] + f * c;           // comb_pe.py:97 (multiply, then add)
-                y[i * channels + ch] = (float)v;
-                if (i >= keep_from) ring_new[slot * channels + ch] = v;
+                const double v = (double)xv[u] + f * c;
+                y[xo + kk * sx] = (float)v;
+                if ((int64_t)kk >= keep_k) ring_new[slot * channels + ch] = v;
                 slot += D;
                 slot = slot >= len ? slot - len : slot;
                 c = v;
@@ -368,6 +447,7 @@ int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride,
     PGX_CHECK_ARG(batch == 1 || (out_stride >= n * channels && in_stride >= n * channels),
                   "pgx_comb: voice stride too small");
     PGX_CHECK_ARG(batch == 1 || (!freq && !fb), "pgx_comb: per-sample control streams require batch == 1");
+    PGX_CHECK_ARG(n * channels < ((int64_t)1 << 30), "pgx_comb: block too long (n * channels must stay below 2^30)");
     if (freq) {
         // ---- delays from the control stream, then the ring in LDS
         PGX_CHECK_ARG(state && workspace && smoothing_samples >= 1 && min_frequency >= 1.0,

@@ -84,6 +84,37 @@ k_index_range(double *result, const float *delay, int64_t start, int64_t n) {
     }
 }
 
+// min / max of a control stream, one (min, max) pair per workgroup (the host folds the few pairs): LadderPE sizes
+// the warm-up of its time segments from the lowest cutoff and the highest resonance of the block.  NaN propagates.
+__global__ void __launch_bounds__(kBlock)
+k_stream_range(double *partials, const float *x, int64_t n) {
+    __shared__ double smin[kBlock], smax[kBlock];
+    double lo = INFINITY, hi = -INFINITY;
+    bool nan = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double v = (double)x[i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+        nan = nan || v != v;
+    }
+    if (nan) lo = hi = NAN;
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double a = smin[threadIdx.x + s], b = smax[threadIdx.x + s];
+            if (a != a || a < smin[threadIdx.x]) smin[threadIdx.x] = a;
+            if (b != b || b > smax[threadIdx.x]) smax[threadIdx.x] = b;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = smin[0];
+        partials[blockIdx.x * 2 + 1] = smax[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PiecewisePE (piecewise_pe.py:44-75, 164-229).  transition: 0 step, 1 linear, 2 exponential,
 // 3 sigmoid, 4 constant_power.
@@ -283,6 +314,14 @@ int pgx_index_range(double *result_dev, const float *delay, int64_t start, int64
     PGX_CHECK_ARG(result_dev && delay && n >= 1, "pgx_index_range: bad argument");
     hipLaunchKernelGGL(k_index_range, dim3(1), dim3(kBlock), 0, pgx::stream(), result_dev, delay, start, n);
     PGX_LAUNCH_CHECK("k_index_range");
+    return PGX_OK;
+}
+
+int pgx_stream_range(double *partials_dev, int parts, const float *x, int64_t n) {
+    PGX_REQUIRE_INIT();
+    PGX_CHECK_ARG(partials_dev && x && n >= 1 && parts >= 1 && parts <= 1024, "pgx_stream_range: bad argument");
+    hipLaunchKernelGGL(k_stream_range, dim3(parts), dim3(kBlock), 0, pgx::stream(), partials_dev, x, n);
+    PGX_LAUNCH_CHECK("k_stream_range");
     return PGX_OK;
 }
 

@@ -102,6 +102,7 @@ _SIGNATURES = [
     ("pgx_gate_stateful", _I, [_P, _L, _D, _D, _D, _D, _P, _P, _P, _P]),
     ("pgx_interp_lookup", _I, [_P, _P, _L, _L, _I, _L, _L, _D, _P, _I, _I, _D, _D]),
     ("pgx_index_range", _I, [_P, _P, _L, _L]),
+    ("pgx_stream_range", _I, [_P, _I, _P, _L]),
     ("pgx_piecewise", _I, [_P, _L, _L, _I, _P, _P, _I, _I, _I, _I]),
     ("pgx_f32_to_pcm16", _I, [_P, _P, _L]),
     ("pgx_pcm16_to_f32", _I, [_P, _P, _L]),

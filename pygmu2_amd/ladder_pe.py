@@ -22,6 +22,8 @@ from .snippet import Snippet
 
 
 ACCURATE_TAIL_FACTOR = 4e-4
+SEGMENT_STREAM_LADDER = True          # PE-driven cutoff / resonance: time segments too (warm-up from the block's range)
+STREAM_SEGMENT_MIN_FRAMES = 8192      # shorter blocks stay on the sequential kernel (the range costs a read-back)
 
 
 class LadderMode(Enum):
@@ -111,6 +113,8 @@ class LadderPE(ProcessingElement):
         self._state: DeviceBuffer | None = None      # [C][9]: z0[4], z1[4], old_input
         self._state_channels = 0
         self._workspace: DeviceBuffer | None = None
+        self._range_dev: DeviceBuffer | None = None          # (256, 2) float64: min / max pairs of a control stream
+        self._stream_settle_cache: dict = {}
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -171,6 +175,8 @@ class LadderPE(ProcessingElement):
         _, d_buf = self._control_stream(self._drive, start, duration)
         out = new_output(duration, ch)
         settle = self._settle_frames()
+        if (self._freq_is_pe or self._res_is_pe) and SEGMENT_STREAM_LADDER:
+            settle = self._settle_frames_for_streams(f_buf, r_buf, duration)
         L = lib()
         need = L.pgx_ladder_workspace_bytes(1, duration, ch, settle)
         if need and (self._workspace is None or self._workspace.nbytes < need):
@@ -184,6 +190,40 @@ class LadderPE(ProcessingElement):
         if self._freq_is_pe or self._res_is_pe:
             return 0
         return ladder_settle_frames(self._frequency, self._resonance, self.sample_rate, self._oversample)
+
+    def _stream_range(self, buf: DeviceBuffer, duration: int):
+        """(min, max) of a control stream of this block: one small launch and a read-back of a few pairs."""
+        parts = int(min(256, max(1, duration // 4096)))
+        if self._range_dev is None or self._range_dev.shape[0] < parts:
+            self._range_dev = DeviceBuffer((256, 2), np.float64)
+        check(lib().pgx_stream_range(self._range_dev.ptr, parts, buf.ptr, duration), "pgx_stream_range")
+        pairs = self._range_dev.to_host()[:parts]
+        return float(np.min(pairs[:, 0])), float(np.max(pairs[:, 1]))
+
+    def _settle_frames_for_streams(self, f_buf, r_buf, duration: int) -> int:
+        """Warm-up length of the time segments when cutoff and / or resonance are PEs: the ladder forgets slowest at
+        the lowest cutoff and the highest resonance it sees, so the estimate of ladder_settle_frames is taken there
+        (block minimum / maximum from the device, quantised so that a sweep does not recompute it every block, and
+        half as much again for the coefficients moving under the warm-up).  Only an estimate is needed: the device
+        verifies every segment against its neighbour and re-renders the chain sequentially if one disagrees."""
+        if duration < STREAM_SEGMENT_MIN_FRAMES:
+            return 0
+        lo_f = hi_r = None
+        if f_buf is not None:
+            lo_f, _ = self._stream_range(f_buf, duration)
+        if r_buf is not None:
+            _, hi_r = self._stream_range(r_buf, duration)
+        cutoff = float(self._frequency) if lo_f is None else lo_f
+        res = float(self._resonance) if hi_r is None else hi_r
+        if not (np.isfinite(cutoff) and np.isfinite(res)):
+            return 0
+        cutoff = max(cutoff, 5.0)
+        key = (int(np.floor(np.log2(cutoff) * 8.0)), int(np.ceil(min(max(res, 0.0), 1.0) * 50.0)))
+        hit = self._stream_settle_cache.get(key)
+        if hit is None:
+            est = ladder_settle_frames(2.0 ** (key[0] / 8.0), key[1] / 50.0, self.sample_rate, self._oversample)
+            hit = self._stream_settle_cache[key] = int(est * 1.5) if est else 0
+        return hit
 
     def _accurate_frames(self) -> int:
         """Tail of a segment's warm-up that needs the float64 tanh: long enough to contract the ~1e-7 the
