@@ -239,14 +239,27 @@ k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, 
 // ------------------------------------------------------------------------------------------------ PE-driven frequency
 constexpr int kCtlThreads = 1024, kCtlT = 4, kCtlTile = kCtlThreads * kCtlT;
 
-// One workgroup.  delay[i] = clip(rint(sr / max(sm_i, 1)), 1, len - 1) with sm the one-pole of comb_pe.py:61-68;
+constexpr int kCtlSegTiles = 16;                              // a workgroup's share of a long block: 65 536 samples
+
+// delay[i] = clip(rint(sr / max(sm_i, 1)), 1, len - 1) with sm the one-pole of comb_pe.py:61-68;
 // gmin / gmax[g] = min / max of the delays of samples [64 g, 64 g + 64).  state[0] = smoothed frequency (-1: unset).
+// One workgroup per segment of kCtlSegTiles tiles.  A block of more than one segment (a look-ahead window) takes two
+// launches: PASS 0 runs every segment's one-pole and keeps only where it ends -- segment 0 from the carried level, the
+// others from zero (the one-pole is affine in its level: sm_end = F sm_start + Z with one F for all whole segments) --
+// and PASS 1 folds those ends onto the carried level to enter its own segment, then produces the delays.  (One
+// workgroup walking a 2.8 M-sample window tile by tile took 1.1 ms.)  ends[s] for s < nseg - 1.
+template <int PASS>
 __global__ void __launch_bounds__(kCtlThreads)
 k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, double alpha, int64_t len, double *state,
-              int32_t *delay, int32_t *gmin, int32_t *gmax) {
+              int32_t *delay, int32_t *gmin, int32_t *gmax, double *ends, int nseg) {
     __shared__ double s_wave[kCtlThreads / 64];
     __shared__ double s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = blockIdx.x;
+    const int64_t seg_begin = (int64_t)seg * kCtlSegTiles * kCtlTile;
+    int64_t seg_end = seg_begin + (int64_t)kCtlSegTiles * kCtlTile;
+    if (seg_end > n) seg_end = n;
+    if (PASS == 0 && seg == nseg - 1) return;                     // nobody enters after the last segment
     // the homogeneous factor of kCtlT literal steps, its powers along a wave, and the factor of a whole wave
     double at = 1.0;
 #pragma unroll
@@ -266,10 +279,28 @@ k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, dou
             c = (double)freq[0];
             c = c < min_frequency ? min_frequency : c;
         }
+        // (the last segment of PASS 1 rewrites state[0] when it ends: with several segments the level on entering the
+        // block travels through the spare slot ends[nseg - 1], written by PASS 0, not through state[0])
+        if (nseg > 1 && seg == 0) {
+            if (PASS == 0) ends[nseg - 1] = c;
+            else c = ends[nseg - 1];
+        }
+        if (seg > 0) {
+            if (PASS == 0) {
+                c = 0.0;                                          // zero-state response of the segment
+            } else {
+                // F = (factor of one thread's samples)^(threads x tiles): squarings from at^64
+                double F = aw;
+#pragma unroll
+                for (int t = 64; t < kCtlThreads * kCtlSegTiles; t <<= 1) F = F * F;
+                c = ends[0];
+                for (int t = 1; t < seg; ++t) c = __builtin_fma(F, c, ends[t]);
+            }
+        }
         s_carry = c;
     }
     __syncthreads();
-    for (int64_t base = 0; base < n; base += kCtlTile) {
+    for (int64_t base = seg_begin; base < seg_end; base += kCtlTile) {
         const int64_t i0 = base + (int64_t)tid * kCtlT;
         double raw[kCtlT];
 #pragma unroll
@@ -298,33 +329,40 @@ k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, dou
 #pragma unroll
         for (int j = 0; j < kCtlT; ++j) {
             sm = sm + (raw[j] - sm) * alpha;                      // comb_pe.py:68
-            const double f = sm < 1.0 ? 1.0 : sm;
-            int64_t d = (int64_t)rint(sr / f);                    // np.round: half to even
-            d = d < 1 ? 1 : d;
-            d = d >= len ? len - 1 : d;
-            if (i0 + j < n) {
-                delay[i0 + j] = (int32_t)d;
-                dmin = min(dmin, (int)d);
-                dmax = max(dmax, (int)d);
-                if (i0 + j == n - 1) state[0] = sm;
+            if (PASS == 1) {
+                const double f = sm < 1.0 ? 1.0 : sm;
+                int64_t d = (int64_t)rint(sr / f);                // np.round: half to even
+                d = d < 1 ? 1 : d;
+                d = d >= len ? len - 1 : d;
+                if (i0 + j < n) {
+                    delay[i0 + j] = (int32_t)d;
+                    dmin = min(dmin, (int)d);
+                    dmax = max(dmax, (int)d);
+                    if (i0 + j == n - 1) state[0] = sm;
+                }
             }
         }
+        if (PASS == 1) {
 #pragma unroll
-        for (int s = 1; s < 64 / kCtlT; s <<= 1) {
-            dmin = min(dmin, __shfl_xor(dmin, s));
-            dmax = max(dmax, __shfl_xor(dmax, s));
-        }
-        if ((tid & (64 / kCtlT - 1)) == 0 && i0 < n) {
-            gmin[i0 >> 6] = dmin;
-            gmax[i0 >> 6] = dmax;
+            for (int s = 1; s < 64 / kCtlT; s <<= 1) {
+                dmin = min(dmin, __shfl_xor(dmin, s));
+                dmax = max(dmax, __shfl_xor(dmax, s));
+            }
+            if ((tid & (64 / kCtlT - 1)) == 0 && i0 < n) {
+                gmin[i0 >> 6] = dmin;
+                gmax[i0 >> 6] = dmax;
+            }
         }
         __syncthreads();                                          // s_wave / s_carry read by everyone
-        if (tid == kCtlThreads - 1) s_carry = sm;
+        if (tid == kCtlThreads - 1) {
+            s_carry = sm;
+            if (PASS == 0 && base + kCtlTile >= seg_end) ends[seg] = sm;      // a whole segment: its last thread's level
+        }
         __syncthreads();
     }
 }
 
-constexpr int kRingThreads = 512, kRingTile = 2048, kRingGroups = kRingTile / 64, kRingPer = kRingTile / kRingThreads;
+constexpr int kRingThreads = 256, kRingTile = 2048, kRingGroups = kRingTile / 64, kRingPer = kRingTile / kRingThreads;
 
 // One workgroup per channel.  RING_LDS: the ring lives in LDS (dynamic shared memory, `len` doubles); otherwise in the
 // new half of the global ring (min_frequency so low that it does not fit).
@@ -396,26 +434,46 @@ k_comb_ring(float *out, const float *in, int64_t n, int channels, const double *
             s_chunk[tid] = min(max(s, 1), kRingThreads);
         }
         __syncthreads();
+        // The chunk loop is one dependent chain per chunk (ring read -> multiply-add -> ring write -> barrier); all
+        // that does not depend on the ring is taken off it: every wave keeps the tile's chunk lengths in one register
+        // (lane g = group g: a v_readlane with a scalar index instead of an LDS round trip per chunk), and a chunk's
+        // delays / samples / feedback are read from LDS while the chunk before it is still in flight.
+        const int my_chunk = s_chunk[(tid & 63) < kRingGroups ? (tid & 63) : 0];
+        const int len32 = (int)len;
+        int wp32 = (int)wp;
         int p = 0;
+        int S = min(__builtin_amdgcn_readlane(my_chunk, 0), tl);
+        int ic = tid < tl ? tid : tl - 1;
+        int d_cur = s_d[ic];
+        float x_cur = s_x[ic], f_cur = FBS ? s_f[ic] : 0.f;
         while (p < tl) {
-            int S = s_chunk[p >> 6];
-            S = min(S, tl - p);
+            const int pn = p + S;
+            int Sn = 0;
+            if (pn < tl) Sn = min(__builtin_amdgcn_readlane(my_chunk, pn >> 6), tl - pn);
+            int in = pn + tid;
+            in = in < tl ? in : tl - 1;
+            const int d_nxt = s_d[in];
+            const float x_nxt = s_x[in], f_nxt = FBS ? s_f[in] : 0.f;
             if (tid < S) {
-                const int i = p + tid;
-                int64_t rp = wp + tid - s_d[i];
-                rp = rp < 0 ? rp + len : rp;
-                const double f = FBS ? comb_fb((double)s_f[i]) : fbc;
-                const double v = (double)s_x[i] + f * ring[rp * rs + ro];     // comb_pe.py:97
-                out[(tb + i) * channels + ch] = (float)v;
-                int64_t w = wp + tid;
-                w = w >= len ? w - len : w;
-                ring[w * rs + ro] = v;
+                int rp = wp32 + tid - d_cur;
+                rp = rp < 0 ? rp + len32 : rp;
+                const double f = FBS ? comb_fb((double)f_cur) : fbc;
+                const double v = (double)x_cur + f * ring[(int64_t)rp * rs + ro];     // comb_pe.py:97
+                out[(tb + p + tid) * channels + ch] = (float)v;
+                int w = wp32 + tid;
+                w = w >= len32 ? w - len32 : w;
+                ring[(int64_t)w * rs + ro] = v;
             }
             __syncthreads();
-            wp += S;
-            wp = wp >= len ? wp - len : wp;
-            p += S;
+            wp32 += S;
+            wp32 = wp32 >= len32 ? wp32 - len32 : wp32;
+            p = pn;
+            S = Sn;
+            d_cur = d_nxt;
+            x_cur = x_nxt;
+            f_cur = f_nxt;
         }
+        wp = wp32;
     }
     if (RING_LDS) {
         __syncthreads();
@@ -430,7 +488,9 @@ extern "C" {
 
 size_t pgx_comb_workspace_bytes(int batch, int64_t n, int channels, int delay_max, int freq_stream) {
     if (batch <= 0 || n <= 0 || channels <= 0) return 0;
-    if (freq_stream) return (size_t)(n + 2 * ((n + 63) / 64) + 64) * sizeof(int32_t);
+    if (freq_stream)       // delays, group minima / maxima, segment ends of the control one-pole
+        return (size_t)(n + 2 * ((n + 63) / 64) + 64) * sizeof(int32_t) +
+               (size_t)(pgx::ceil_div(n, (int64_t)kCtlSegTiles * kCtlTile) + 2) * sizeof(double);
     if (delay_max < 1) return 0;
     return (size_t)batch * (size_t)poly_ws_doubles(n, channels, delay_max) * sizeof(double);
 }
@@ -455,8 +515,18 @@ int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride,
         const int64_t len = ring_rows;
         int32_t *delay = (int32_t *)workspace;
         int32_t *gmin = delay + n, *gmax = gmin + (n + 63) / 64;
-        hipLaunchKernelGGL(k_comb_delays, dim3(1), dim3(kCtlThreads), 0, pgx::stream(), n, sample_rate, freq,
-                           min_frequency, 1.0 / (double)smoothing_samples, len, state, delay, gmin, gmax);
+        double *ends = (double *)(gmax + (n + 63) / 64 + 2);       // (8-byte aligned: see pgx_comb_workspace_bytes)
+        ends = (double *)(((uintptr_t)ends + 7) & ~(uintptr_t)7);
+        const int ctl_segs = (int)pgx::ceil_div(n, (int64_t)kCtlSegTiles * kCtlTile);
+        if (ctl_segs > 1) {
+            hipLaunchKernelGGL(k_comb_delays<0>, dim3(ctl_segs), dim3(kCtlThreads), 0, pgx::stream(), n, sample_rate,
+                               freq, min_frequency, 1.0 / (double)smoothing_samples, len, state, delay, gmin, gmax,
+                               ends, ctl_segs);
+            PGX_LAUNCH_CHECK("k_comb_delays<ends>");
+        }
+        hipLaunchKernelGGL(k_comb_delays<1>, dim3(ctl_segs), dim3(kCtlThreads), 0, pgx::stream(), n, sample_rate, freq,
+                           min_frequency, 1.0 / (double)smoothing_samples, len, state, delay, gmin, gmax, ends,
+                           ctl_segs);
         PGX_LAUNCH_CHECK("k_comb_delays");
         const double *ring_old = ring + (int64_t)parity * ring_rows * channels;
         double *ring_new = ring + (int64_t)(parity ^ 1) * ring_rows * channels;

@@ -665,8 +665,11 @@ struct SbSine {
     int64_t start;
 };
 
+#ifndef PGX_SB_SINE_WAVES
+#define PGX_SB_SINE_WAVES 3        // waves per SIMD the sine-source variant is compiled for: 166 VGPRs, no spill (4: 128 + 28 B of scratch per lane, 6 MB of extra HBM traffic per 33 M frames and 5 % slower)
+#endif
 template <bool MONO, bool STAGED, bool SINE = false>
-__global__ void __launch_bounds__(kSbBlock, MONO ? 4 : 2)
+__global__ void __launch_bounds__(kSbBlock, MONO ? (SINE ? PGX_SB_SINE_WAVES : 4) : 2)
 k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__restrict__ in, int64_t in_stride,
                  int64_t n, int channels_arg, const double *__restrict__ coef, const double *__restrict__ tables,
                  double *state, int seg, int head, int tail, int warm, int groups, SbSine sine = SbSine{}) {

@@ -28,31 +28,40 @@ class TransitionType(Enum):
 _TRANSITION_INDEX = {t: i for i, t in enumerate(TransitionType)}
 
 
+def _as_transition(kind) -> TransitionType:
+    """A TransitionType, or its name in any case; an unknown name means LINEAR (piecewise_pe.py:124-130)."""
+    if isinstance(kind, TransitionType):
+        return kind
+    by_name = {t.value: t for t in TransitionType}
+    return by_name.get(str(kind).lower(), TransitionType.LINEAR)
+
+
+def _break_points(points):
+    """Break points as two device-ready columns ordered by time: int64 sample indices (fractions truncate, as a
+    float64 -> int64 cast does) and float64 values.  Points that share a time keep the order numpy's default argsort
+    gives them -- the order the reference's curve sees (piecewise_pe.py:31-43)."""
+    table = np.asarray(list(points), dtype=np.float64).reshape(-1, 2)
+    when = table[:, 0].astype(np.int64)
+    rank = np.argsort(when)
+    return np.ascontiguousarray(when[rank]), np.ascontiguousarray(table[rank, 1])
+
+
 class PiecewisePE(SourcePE):
     _READ_AHEAD_SAFE = True
 
     def __init__(self, points: Sequence[Tuple[int, float]],
                  transition_type: TransitionType | str = TransitionType.LINEAR,
                  extend_mode: ExtendMode = ExtendMode.ZERO, channels: int = 1):
-        if not points:
+        if len(points) == 0:
             raise ValueError("PiecewisePE requires at least one point")
-        arr = np.array(points, dtype=np.float64)
-        times = arr[:, 0].astype(np.int64)
-        values = arr[:, 1].astype(np.float64)
-        order = np.argsort(times)                 # same (default) sort as the reference, piecewise_pe.py:38
-        self._times, self._values = times[order], values[order]
-        self._n = len(self._times)
-        if isinstance(transition_type, str):
-            try:
-                transition_type = TransitionType(transition_type.lower())
-            except ValueError:
-                transition_type = TransitionType.LINEAR
-        self._transition_type = transition_type
+        if int(channels) < 1:
+            raise ValueError(f"channels must be >= 1, got {int(channels)}")
+        self._times, self._values = _break_points(points)
+        self._n = int(self._times.shape[0])
+        self._transition_type = _as_transition(transition_type)
         self._extend_mode = extend_mode
         self._channels = int(channels)
-        if self._channels < 1:
-            raise ValueError(f"channels must be >= 1, got {self._channels}")
-        self._times_dev: DeviceBuffer | None = None
+        self._times_dev: DeviceBuffer | None = None      # uploaded on the first render
         self._values_dev: DeviceBuffer | None = None
 
     @property

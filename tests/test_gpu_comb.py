@@ -164,3 +164,15 @@ def test_look_ahead_window_of_a_comb_stream():
     for g, w in zip(got, want):
         peak = float(np.max(np.abs(w)))
         assert float(np.max(np.abs(g.astype(np.float64) - w))) <= 1e-6 * peak
+
+
+def test_frequency_stream_over_a_long_window():
+    """300 000 frames in one call with a PE frequency: the control one-pole runs in several 65 536-sample segments
+    (two launches), the ring walks the whole block.  Delays are integers: bit-exact against the oracle."""
+    S = _S()
+    spec = S("CombPE", source=S("ArrayPE", data=NOISE1), frequency=_sweep(80.0, 700.0, 1.7), feedback=0.6,
+             smoothing_samples=960)
+    blocks = _contig([300_000, 4000, 70_000])
+    got, want = _hip(spec, 48000, blocks), _oracle(spec, 48000, blocks)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), (i, int(np.sum(g != w)))
