@@ -454,7 +454,7 @@ def biquad_sine_roofline(pg, frames, launches, start):
 
     def launch():
         device.check(lib.pgx_biquad_sine(out.ptr, start, frames, 44100.0, w, 1.0, 0.0, coef.ptr, tables.ptr, settle,
-                                         state.ptr))
+                                         state.ptr, None))
 
     ms = event_avg_ms(launch, launches)
     algo_bytes = 4.0 * frames

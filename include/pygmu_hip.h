@@ -196,7 +196,8 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
 int pgx_biquad_sine_supported(int64_t n, int64_t settle_frames);
 int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, double w, double amp, double phase0,
                     const double *coef /* [5] */, const double *tables, int64_t settle_frames,
-                    double *state /* [2] */);
+                    double *state /* [2] */,
+                    double *state_backup /* [2] or NULL: receives the state on entry (a window's snapshot) */);
 
 /* Time-varying coefficients: _compute_coefficients per sample (biquad_pe.py:217-335) +
  * the direct-form-I recurrence of _biquad_varying_numba (biquad_pe.py:35-62).

@@ -155,7 +155,9 @@ class BiquadPE(ProcessingElement):
         self._q_is_pe = isinstance(q, ProcessingElement)
         self._coef: DeviceBuffer | None = None        # [5] float64 (constant path)
         self._coef_host = None
-        self._sine_fuse_ok = None                     # _passes_more_signal_than_rounding, evaluated once
+        self._sine_chain_memo = None                  # _sine_chain(), evaluated once
+        self._sine_supported: dict = {}               # duration -> pgx_biquad_sine_supported
+        self._backup_target = None                    # a snapshot buffer the next fused render has to fill
         self._settle = 0                              # settle_frames of the constant section
         self._tables: DeviceBuffer | None = None      # its power tables (single-launch path)
         self._params: DeviceBuffer | None = None      # pgx_biquad_var_params (varying path)
@@ -216,35 +218,65 @@ class BiquadPE(ProcessingElement):
                 self._tables = DeviceBuffer((L.pgx_biquad_table_doubles(),), np.float64)
                 check(L.pgx_biquad_tables(self._tables.ptr, self._coef.ptr, 1), "pgx_biquad_tables")
 
+    def _sine_chain(self):
+        """(w, amplitude, phase) of the source when this is BiquadPE(SinePE) with scalar parameters, mono, and the
+        filter passes more signal than rounding noise -- evaluated once; None otherwise."""
+        if self._sine_chain_memo is None:
+            src, chain = self._source, False
+            if (not self._freq_is_pe and not self._q_is_pe and type(src) is SinePE and not src._has_pe_inputs()
+                    and src._channels == 1):
+                L = lib()
+                sr = float(self.sample_rate)
+                self._prepare_constant(L, sr)
+                w = 2.0 * np.pi * float(src._frequency)              # sine_pe.py: (2 pi) f, left to right
+                if self._settle and _passes_more_signal_than_rounding(self._coef_host, w / sr, self._settle):
+                    chain = (w, float(src._amplitude), float(src._phase))
+            self._sine_chain_memo = chain
+        return self._sine_chain_memo or None
+
     def _render_sine_source(self, start: int, duration: int):
         """BiquadPE(SinePE) with scalar parameters, mono, long block: the sine is generated inside the filter kernel
         (pgx_biquad_sine): one launch, 4 B per frame.  None when the chain does not qualify."""
-        src = self._source
-        if (not FUSE_SINE_SOURCE or self._freq_is_pe or self._q_is_pe or type(src) is not SinePE
-                or src._has_pe_inputs() or src._channels != 1 or _diag.is_enabled()):
+        if not FUSE_SINE_SOURCE or _diag.is_enabled():
             return None
+        chain = self._sine_chain()
+        if chain is None:
+            return None
+        w, amp, phase = chain
         L = lib()
         sr = float(self.sample_rate)
-        self._prepare_constant(L, sr)
-        if not self._settle or not L.pgx_biquad_sine_supported(duration, self._settle):
-            return None
-        w = 2.0 * np.pi * float(src._frequency)                      # sine_pe.py: (2 pi) f, left to right
-        if self._sine_fuse_ok is None:
-            self._sine_fuse_ok = _passes_more_signal_than_rounding(self._coef_host, w / sr, self._settle)
-        if not self._sine_fuse_ok:
-            return None
-        if abs(float(src._phase)) + abs(w) * ((abs(start) + duration) / sr) >= SINE_FAST_RANGE:
+        ok = self._sine_supported.get(duration)
+        if ok is None:
+            ok = self._sine_supported[duration] = bool(L.pgx_biquad_sine_supported(duration, self._settle))
+        if not ok or abs(phase) + abs(w) * ((abs(start) + duration) / sr) >= SINE_FAST_RANGE:
             return None
         self._ensure_state(1)
         out = new_output(duration, 1)
-        check(L.pgx_biquad_sine(out.ptr, start, duration, sr, w, float(src._amplitude), float(src._phase),
-                                self._coef.ptr, self._tables.ptr, self._settle, self._state.ptr), "pgx_biquad_sine")
+        backup, self._backup_target = self._backup_target, None      # a look-ahead window's snapshot: the kernel fills it
+        check(L.pgx_biquad_sine(out.ptr, start, duration, sr, w, amp, phase, self._coef.ptr, self._tables.ptr,
+                                self._settle, self._state.ptr, ptr(backup)), "pgx_biquad_sine")
         return Snippet(start, out)
+
+    def _la_take_snapshot(self):
+        """look_ahead.take_snapshot: the state copy of a window over the fused sine chain is written by the window's
+        own kernel (pgx_biquad_sine(..., state_backup)) instead of a copy launch in front of it.  Any other render
+        that comes first fills the copy the ordinary way (_flush_backup)."""
+        if self._state is None or self._sine_chain() is None or not FUSE_SINE_SOURCE:
+            return None
+        self._backup_target = DeviceBuffer(self._state.shape, self._state.dtype)
+        return {"_state": self._backup_target, "_state_channels": self._state_channels}
+
+    def _flush_backup(self) -> None:
+        backup, self._backup_target = self._backup_target, None
+        if backup is not None and self._state is not None:
+            check(lib().pgx_memcpy_d2d(backup.ptr, self._state.ptr, backup.nbytes), "pgx_memcpy_d2d")
 
     def _render(self, start: int, duration: int) -> Snippet:
         fused = self._render_sine_source(start, duration)
         if fused is not None:
             return fused
+        if self._backup_target is not None:
+            self._flush_backup()
         src = self._source.render(start, duration)
         ch = src.channels
         self._ensure_state(ch)

@@ -577,8 +577,8 @@ __device__ __forceinline__ V2 dpp_v2(const V2 &v) {
 }
 
 struct SbShared {
-    V2 wave_tot[kSbWaves];
-};
+    V2 wave_tot[2][kSbWaves];        // two images used in turn: one barrier per tile (the readers of one image are
+};                                   // separated from its next writer by the barrier of the tile in between)
 
 // Staging of a wave's 1024 frames through wave-private LDS: HBM is touched with fully coalesced 16-byte
 // accesses (lane l of access i owns frames i*256 + 4l ..), the scan wants 16 consecutive frames per lane.
@@ -619,7 +619,8 @@ __device__ __forceinline__ void stage_store(float *lds, float *dst, int lane, co
 
 // Matrix-power tables of one section, computed once per coefficient set (pgx_biquad_tables):
 // A^(16*2^k) for k = 0..5, A^(16*64), then A^(16*j) for j = 0..63.
-constexpr int kBqTableDoubles = 28 + 4 * 64;
+constexpr int kBqTableDoubles = 28 + 4 * 64 + 2 * kBqT;     // ... then the first rows of A^j, j = 0..kBqT-1 (SINE pass 2)
+constexpr int kBqRowsAt = 28 + 4 * 64;
 
 __global__ void __launch_bounds__(64)
 k_biquad_tables(double *tables, const double *coef) {
@@ -644,6 +645,17 @@ k_biquad_tables(double *tables, const double *coef) {
         if (lane & (1 << k)) m = mm(ps[k], m);
     double *ml = tb + 28 + 4 * lane;
     ml[0] = m.a; ml[1] = m.b; ml[2] = m.c; ml[3] = m.d;
+    if (lane == 0) {
+        // first rows of A^j: what a carried state z contributes to the output of the j-th frame after it, y_h[j] =
+        // (A^j z).x (the sine-source variant adds it to the zero-state outputs it kept from pass 1)
+        M2 q = m_identity();
+        const M2 a1m{-coef[inst * 5 + 3], 1.0, -coef[inst * 5 + 4], 0.0};
+        for (int j = 0; j < kBqT; ++j) {
+            tb[kBqRowsAt + 2 * j] = q.a;
+            tb[kBqRowsAt + 2 * j + 1] = q.b;
+            q = mm(a1m, q);
+        }
+    }
 }
 
 __device__ __forceinline__ M2 load_m2(const double *p) { return M2{p[0], p[1], p[2], p[3]}; }
@@ -663,6 +675,7 @@ __device__ __forceinline__ V2 mv_add_fma(const M2 &p, const V2 &v, const V2 &q) 
 struct SbSine {
     double w, amp, phase0, sr, inv_sr, cos_d, sin_d;
     int64_t start;
+    double *state_backup;      // receives the carried state on entry (a look-ahead window's snapshot), or nullptr
 };
 
 #ifndef PGX_SB_SINE_WAVES
@@ -747,6 +760,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
     const M2 m16 = load_m2(tb + 28 + 4 * ((lane & 15) + 1));
     const M2 m32 = load_m2(tb + 28 + 4 * ((lane & 31) + 1));
 
+    int image = 0;
 #pragma nounroll
     for (int range = 0; range < 2; ++range) {
         if (range == 1) {
@@ -760,7 +774,13 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
         }
         if (hb >= he) continue;
         V2 carry{0.0, 0.0};
-        if (hb == 0) carry = V2{state[chain * 2 + 0], state[chain * 2 + 1]};
+        if (hb == 0) {
+            carry = V2{state[chain * 2 + 0], state[chain * 2 + 1]};
+            if (SINE && sine.state_backup && tid == 0) {          // workgroup 0 alone reads and writes the state
+                sine.state_backup[chain * 2 + 0] = carry.x;
+                sine.state_backup[chain * 2 + 1] = carry.y;
+            }
+        }
         const int64_t emit_from = hb * kSbHalf;
 
 #pragma nounroll
@@ -780,15 +800,19 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             // zero-state response of the 16-frame chunk
             V2 e{0.0, 0.0};
             const double na1 = -a1, na2 = -a2;
+            double yz[SINE ? kBqT : 1];                        // SINE: the zero-state outputs stay for pass 2
 #pragma unroll
             for (int j = 0; j < kBqT; ++j) {
                 const double x = (double)xf[j];
                 const double y = __builtin_fma(b0, x, e.x);
                 e.x = __builtin_fma(na1, y, __builtin_fma(b1, x, e.y));
                 e.y = __builtin_fma(na2, y, b2 * x);
+                if (SINE) yz[j] = y;
             }
+            if (!SINE) {
 #pragma unroll
-            for (int j = 0; j < kBqT; ++j) asm volatile("" : "+v"(xf[j]));   // re-convert in pass 2, keep VGPRs low
+                for (int j = 0; j < kBqT; ++j) asm volatile("" : "+v"(xf[j]));   // re-convert in pass 2, keep VGPRs low
+            }
             // inclusive scan over the wave: Kogge-Stone inside each 16-lane row (DPP row shifts) ...
             e = mv_add_fma(pstep[0], dpp_v2<0x111, 0xf>(e), e);
             e = mv_add_fma(pstep[1], dpp_v2<0x112, 0xf>(e), e);
@@ -797,15 +821,19 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             // ... then row 0 -> 1, row 2 -> 3 (lane 15 of the previous row), then rows 0-1 -> 2, 3 (lane 31)
             e = mv_add_fma(m16, dpp_v2<0x142, 0xa>(e), e);
             e = mv_add_fma(m32, dpp_v2<0x143, 0xc>(e), e);
-            if (lane == 63) sh.wave_tot[wave] = e;
+            V2 *tot = sh.wave_tot[image];
+            image ^= 1;
+            if (lane == 63) tot[wave] = e;
             __syncthreads();
             V2 cw = carry, run = carry;
 #pragma unroll
             for (int w = 0; w < kSbWaves; ++w) {
-                run = mv_add_fma(pwave, run, sh.wave_tot[w]);
+                run = mv_add_fma(pwave, run, tot[w]);
                 if (w + 1 == wave) cw = run;                   // wave-uniform pick of this wave's carry-in
             }
+#ifdef PGX_SB_TWO_BARRIERS
             __syncthreads();
+#endif
             carry = run;
 
             if (f0 >= emit_from && f0 < emit_to) {
@@ -813,6 +841,15 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
                 const V2 zin = mv_add_fma(mlane, cw, ex);
                 V2 z = zin;
                 float yf[kBqT];
+                if (SINE) {
+                    // the zero-state outputs of pass 1 plus what the carried state adds, (A^j zin).x: two
+                    // multiply-adds per frame instead of the recurrence again (the sine chain is within the rounding
+                    // noise of the reference's phase anyway; the plain filter below keeps scipy's operation order)
+                    const double *rows = tb + kBqRowsAt;          // uniform: scalar loads
+#pragma unroll
+                    for (int j = 0; j < kBqT; ++j)
+                        yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
+                } else {
                 // scipy lfilter DF-II-T operation order from the scanned carry-in
 #pragma unroll
                 for (int j = 0; j < kBqT; ++j) {
@@ -822,6 +859,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
                     z.y = b2 * x - a2 * y;
                     z.x = z0;
                     yf[j] = (float)y;
+                }
                 }
                 const int64_t w0 = f0 - lane * kBqT;
                 if (STAGED && io_aligned && w0 >= emit_from && w0 + 64 * kBqT <= emit_to)
@@ -3040,7 +3078,8 @@ int pgx_biquad_sine_supported(int64_t n, int64_t settle_frames) {
 }
 
 int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, double w, double amp, double phase0,
-                    const double *coef, const double *tables, int64_t settle_frames, double *state) {
+                    const double *coef, const double *tables, int64_t settle_frames, double *state,
+                    double *state_backup) {
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && coef && tables && state && sample_rate > 0, "pgx_biquad_sine: bad argument");
@@ -3059,6 +3098,7 @@ int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, do
     sine.cos_d = (double)cosl(d);
     sine.sin_d = (double)sinl(d);
     sine.start = start;
+    sine.state_backup = state_backup;
     const dim3 grid(sp.groups == 1 ? 1 : (sp.groups + 7) / 8 * 8, 1);
     hipLaunchKernelGGL((k_biquad_settled<true, true, true>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
                        (int64_t)0, (const float *)nullptr, (int64_t)0, n, 1, coef, tables, state, sp.seg, sp.head,

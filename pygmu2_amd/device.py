@@ -84,7 +84,7 @@ _SIGNATURES = [
     ("pgx_biquad_tables", _I, [_P, _P, _I]),
     ("pgx_biquad_const", _I, [_P, _L, _P, _L, _I, _L, _I, _P, _P, _L, _P, _P]),
     ("pgx_biquad_sine_supported", _I, [_L, _L]),
-    ("pgx_biquad_sine", _I, [_P, _L, _L, _D, _D, _D, _D, _P, _P, _L, _P]),
+    ("pgx_biquad_sine", _I, [_P, _L, _L, _D, _D, _D, _D, _P, _P, _L, _P, _P]),
     ("pgx_biquad_varying", _I, [_P, _P, _L, _I, _D, _P, _P, _P, _D, _D, _P, _P]),
     ("pgx_scan2_workspace_bytes", _Z, [_L, _I]),
     ("pgx_convolve_fft_size", _L, [_L]),

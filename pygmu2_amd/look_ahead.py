@@ -143,7 +143,11 @@ def take_snapshot(nodes):
     for pe in nodes:
         fields = getattr(pe, "_STATE_FIELDS", None)
         if fields:
-            snap.append((pe, {name: _copy_value(getattr(pe, name)) for name in fields}))
+            own = getattr(pe, "_la_take_snapshot", None)      # a PE whose next kernel can write the copy itself
+            saved = own() if own is not None else None
+            if saved is None:
+                saved = {name: _copy_value(getattr(pe, name)) for name in fields}
+            snap.append((pe, saved))
     return snap
 
 
@@ -212,6 +216,10 @@ def render(pe, start: int, duration: int):
         # request takes the block-by-block path -- the caller sees what it would have seen without look-ahead
         _tls.busy = False
         _tls.period = 0
+        for n, _ in snap:                             # a copy its kernel was to write and never did: made now
+            flush = getattr(n, "_flush_backup", None)
+            if flush is not None:
+                flush()
         restore_snapshot(snap)
         d["_la_ok"] = False
         return None

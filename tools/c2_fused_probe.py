@@ -17,6 +17,6 @@ w = 2.0 * np.pi * 440.0
 for frames, reps in ((1_000_000, 5), (16_000_000, 5), (33_000_000, 5), (1 << 26, 3)):
     out = device.DeviceBuffer((frames, 1), np.float32)
     for _ in range(reps):
-        device.check(lib.pgx_biquad_sine(out.ptr, 10 ** 9, frames, 44100.0, w, 1.0, 0.0, coef.ptr, tables.ptr, settle, state.ptr))
+        device.check(lib.pgx_biquad_sine(out.ptr, 10 ** 9, frames, 44100.0, w, 1.0, 0.0, coef.ptr, tables.ptr, settle, state.ptr, None))
     device.synchronize()
 print("done")
