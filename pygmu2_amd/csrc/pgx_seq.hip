@@ -255,26 +255,36 @@ __device__ __forceinline__ double ladder_tanh_mid(double x) {
     return copysign((1.0 - e) * y, x);
 }
 
-template <bool FAST, int OS>
+// STREAMS: cutoff / resonance / drive per sample from the control streams (the coefficient polynomials then sit in
+// the sample loop: ~15 more operations, none of them on the feedback chain).
+template <bool FAST, int OS, bool STREAMS = false>
 __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderState &s, int64_t i0, int64_t i1) {
     const double state_decay = 0.95, input_threshold = 1e-5, resonance_multiplier = 1.8;
     const double two_pi = 2.0 * 3.141592653589793;
-    double cutoff = c.p_freq;
-    if (cutoff < 5.0) cutoff = 5.0;
-    if (cutoff > c.max_cutoff) cutoff = c.max_cutoff;
-    const double wc = cutoff * two_pi / (c.sr * (double)c.oversample);
-    const double wc2 = wc * wc, wc3 = wc2 * wc, wc4 = wc3 * wc;
-    const double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
-    const double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
-    double res = c.p_res;
-    if (res < 0.0) res = 0.0;
-    if (res > 1.0) res = 1.0;
-    const double kq = 4.0 * res * resonance_multiplier * q_adjust;
-    const double drive_scaled = ladder_drive_scale(c.p_drive, c.pbg);
-    const double ac0 = alpha * 0.76923077, ac1 = alpha * 0.23076923, oma = 1.0 - alpha;
+    const double wc_scale = two_pi / (c.sr * (double)c.oversample);
+    double kq = 0.0, drive_scaled = 0.0, ac0 = 0.0, ac1 = 0.0, oma = 0.0;
+    auto coefficients = [&](int64_t i) {
+        double cutoff = (STREAMS && c.freq) ? (double)c.freq[i] : c.p_freq;
+        if (cutoff < 5.0) cutoff = 5.0;
+        if (cutoff > c.max_cutoff) cutoff = c.max_cutoff;
+        const double wc = STREAMS ? cutoff * wc_scale : cutoff * two_pi / (c.sr * (double)c.oversample);
+        const double wc2 = wc * wc, wc3 = wc2 * wc, wc4 = wc3 * wc;
+        const double alpha = 0.9892 * wc - 0.4324 * wc2 + 0.1381 * wc3 - 0.0202 * wc4;
+        const double q_adjust = 1.006 + 0.0536 * wc - 0.095 * wc2 - 0.05 * wc4;
+        double res = (STREAMS && c.resonance) ? (double)c.resonance[i] : c.p_res;
+        if (res < 0.0) res = 0.0;
+        if (res > 1.0) res = 1.0;
+        kq = 4.0 * res * resonance_multiplier * q_adjust;
+        drive_scaled = ladder_drive_scale((STREAMS && c.drive) ? (double)c.drive[i] : c.p_drive, c.pbg);
+        ac0 = alpha * 0.76923077;
+        ac1 = alpha * 0.23076923;
+        oma = 1.0 - alpha;
+    };
+    if (!STREAMS) coefficients(0);
     const int oversample = OS ? OS : c.oversample;               // OS = 2: a constant trip count, unrolled
 
-    auto sample = [&](float x) {
+    auto sample = [&](float x, int64_t i) {
+        if (STREAMS) coefficients(i);
         const double input_sample = (double)x * drive_scaled;
         const double decay = fabs(input_sample) < input_threshold ? state_decay : 1.0;   // a select: no branch
 #pragma unroll
@@ -316,14 +326,18 @@ __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderSt
             for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
             if (base + 2 * kLadderChunk <= i1) ladder_load8(c, base + kLadderChunk, xn);
 #pragma unroll
-            for (int j = 0; j < kLadderChunk; ++j) sample(xc[j]);
+            for (int j = 0; j < kLadderChunk; ++j) sample(xc[j], base + j);
         }
     }
-    for (; base < i1; ++base) sample(c.x[base * c.channels + c.ch]);
+    for (; base < i1; ++base) sample(c.x[base * c.channels + c.ch], base);
 }
 
 template <bool FAST>
 __device__ __forceinline__ void ladder_warm(const LadderConsts &c, LadderState &s, int64_t i0, int64_t i1) {
+    if (c.freq || c.resonance || c.drive) {                                      // kernel arguments: uniform
+        ladder_warm_impl<FAST, 0, true>(c, s, i0, i1);
+        return;
+    }
     if (__all(c.oversample == 2)) ladder_warm_impl<FAST, 2>(c, s, i0, i1);      // every active lane: wave-uniform
     else ladder_warm_impl<FAST, 0>(c, s, i0, i1);
 }
@@ -415,13 +429,10 @@ k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_st
         w0 = ws;
         w1 = sb - accurate > ws ? sb - accurate : ws;
     }
-    if (scalar_params) {
-        ladder_warm<true>(c, s, w0, w1);
-        ladder_warm<false>(c, s, w1, sb);
-        ladder_advance(c, s, sb, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
-    } else {
-        ladder_advance(c, s, w0, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
-    }
+    (void)scalar_params;             // (control streams take the same three phases: ladder_warm reads them per sample)
+    ladder_warm<true>(c, s, w0, w1);
+    ladder_warm<false>(c, s, w1, sb);
+    ladder_advance(c, s, sb, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
     ladder_store(ends + ((int64_t)chain * nseg + seg) * 9, s);
 }
 

@@ -115,6 +115,7 @@ class LadderPE(ProcessingElement):
         self._workspace: DeviceBuffer | None = None
         self._range_dev: DeviceBuffer | None = None          # (256, 2) float64: min / max pairs of a control stream
         self._stream_settle_cache: dict = {}
+        self._stream_accurate = 0
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -181,9 +182,10 @@ class LadderPE(ProcessingElement):
         need = L.pgx_ladder_workspace_bytes(1, duration, ch, settle)
         if need and (self._workspace is None or self._workspace.nbytes < need):
             self._workspace = DeviceBuffer((need,), np.uint8, zero=True)
+        accurate = self._stream_accurate if (self._freq_is_pe or self._res_is_pe) else self._accurate_frames()
         check(L.pgx_ladder(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate),
                            self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr, settle,
-                           self._accurate_frames(), ptr(self._workspace) if need else None), "pgx_ladder")
+                           accurate, ptr(self._workspace) if need else None), "pgx_ladder")
         return Snippet(start, out)
 
     def _settle_frames(self) -> int:
@@ -221,9 +223,12 @@ class LadderPE(ProcessingElement):
         key = (int(np.floor(np.log2(cutoff) * 8.0)), int(np.ceil(min(max(res, 0.0), 1.0) * 50.0)))
         hit = self._stream_settle_cache.get(key)
         if hit is None:
-            est = ladder_settle_frames(2.0 ** (key[0] / 8.0), key[1] / 50.0, self.sample_rate, self._oversample)
-            hit = self._stream_settle_cache[key] = int(est * 1.5) if est else 0
-        return hit
+            fc, rs = 2.0 ** (key[0] / 8.0), key[1] / 50.0
+            est = ladder_settle_frames(fc, rs, self.sample_rate, self._oversample)
+            tail = ladder_settle_frames(fc, rs, self.sample_rate, self._oversample, target=ACCURATE_TAIL_FACTOR)
+            hit = self._stream_settle_cache[key] = (int(est * 1.5), int(tail * 1.5)) if est else (0, 0)
+        self._stream_accurate = hit[1]
+        return hit[0]
 
     def _accurate_frames(self) -> int:
         """Tail of a segment's warm-up that needs the float64 tanh: long enough to contract the ~1e-7 the

@@ -145,7 +145,7 @@ def test_pe_driven_cutoff_and_resonance_run_in_time_segments():
             look_ahead.set_enabled(True)
 
     seg, pe = run(True)
-    assert pe._stream_settle_cache and all(v > 0 for v in pe._stream_settle_cache.values())
+    assert pe._stream_settle_cache and all(v[0] > 0 for v in pe._stream_settle_cache.values())
     seq, _ = run(False)
     g = graph_eval.Node(spec, 48000)
     for (s, n), a, b in zip(blocks, seg, seq):
