@@ -837,15 +837,17 @@ def suite_rows(pg, with_cpu):
     # every config of the reference's suite this build has a PE for (all but the three RandomPE rows); the rows
     # north_star words its target on get the longer CPU sample
     headline = ("BiquadPE", "SVFilterPE", "SinePE", "BlitSawPE (440 Hz, auto", "SuperSawPE (7")
+    # all device rows first, then all CPU rows: a second of CPU timing between two device rows lets the GPU clocks
+    # fall back, and the next row's five warm-up renders do not bring them up again
     rows = {}
     for name, spec in B.CONFIGS:
-        rates = B.device_rates(spec)
-        row = {k: round(v, 1) for k, v in rates.items()}
+        rows[name] = {k: round(v, 1) for k, v in B.device_rates(spec).items()}
+    for name, spec in B.CONFIGS:
+        row = rows[name]
         if with_cpu and "SVFilterPE (lowpass, modulated" not in name:     # that oracle loop is plain Python
             row["cpu"] = round(B.cpu_rate(spec, budget_s=1.5 if name.startswith(headline) else 0.5), 2)
-            row["pipelined_over_cpu"] = round(rates["pipelined"] / row["cpu"], 1)
-            row["sync_over_cpu"] = round(rates["sync"] / row["cpu"], 1)
-        rows[name] = row
+            row["pipelined_over_cpu"] = round(row["pipelined"] / row["cpu"], 1)
+            row["sync_over_cpu"] = round(row["sync"] / row["cpu"], 1)
     return {"protocol": "benchmark_pes.py:149-196: 44 100-frame renders, 5 warm-up + 50 timed contiguous renders "
                         "(started away from the warm-up: every timed frame is rendered inside the timed region), "
                         "Msamples/s; sync = device wait after every render, pipelined = one wait after the 50, "
@@ -879,15 +881,15 @@ def north_star_pe_rows(pg, with_cpu):
            sustain_level=0.7, release_time=0.2)),
     ]
     rows = {}
-    for name, spec in configs:
-        rates = B.device_rates(spec)
-        row = {k: round(v, 1) for k, v in rates.items()}
-        if with_cpu:
-            row["cpu"] = round(B.cpu_rate(spec, budget_s=1.0), 2)
-            row["pipelined_over_cpu"] = round(rates["pipelined"] / row["cpu"], 1)
-            row["sync_over_cpu"] = round(rates["sync"] / row["cpu"], 1)
-        rows[name] = row
+    for name, spec in configs:                       # device rows first, CPU rows after (see suite_rows)
+        rows[name] = {k: round(v, 1) for k, v in B.device_rates(spec).items()}
     dt = CP.bank_rate()
+    for name, spec in configs:
+        if with_cpu:
+            row = rows[name]
+            row["cpu"] = round(B.cpu_rate(spec, budget_s=1.0), 2)
+            row["pipelined_over_cpu"] = round(row["pipelined"] / row["cpu"], 1)
+            row["sync_over_cpu"] = round(row["sync"] / row["cpu"], 1)
     bank = {"ms_per_block": round(dt * 1e3, 4), "value": round(48000 / dt / 1e6, 3), "unit": "Msamples/s",
             "chain_msamples_s": round(512 * 48000 / dt / 1e6, 1),
             "workload": "512 x CombPE(BlitSawPE(f_i), 55*2^(i/96) Hz, fb 0.7) -> MixPE, 48 kHz, 48 000-frame blocks"}
