@@ -490,6 +490,11 @@ __device__ __forceinline__ long long adsr_settle_steps(double span, double rate)
     return (long long)q + 8;
 }
 
+#ifndef PGX_ADSR_DEBUG
+#define PGX_ADSR_DEBUG(slot, value)        /* tools/microbench/adsr_par_debug.hip records per-envelope facts */
+#define PGX_ADSR_CLOCK() 0ll
+#define PGX_ADSR_DEBUG_MAX(slot, value)
+#endif
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
@@ -552,12 +557,28 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
     __builtin_amdgcn_s_waitcnt(0);           // (wave-private LDS rows: the wave reads back what it wrote)
     __builtin_amdgcn_wave_barrier();
 
-    // ---- independent starts: which stretch is this wave's ----
-    // steps until the level is pinned (sustain after an attack edge, idle after a release edge), from the level the
-    // stretch starts at when that is known -- the carried level, S after a settled attack, 0 after a settled
-    // release -- else from the worst case
+    // ---- starts: where a wave may begin with a state it knows ----
+    // (a) pinned levels (round 2): an edge that comes after a stretch long enough for the level to be pinned -- exactly S
+    //     after an attack edge, exactly 0 after a release edge -- finds a known state: exact, no check needed.
+    // (b) attack completions (round 3): an attack always ends by pinning the level to exactly 1.0 (adsr_pe.py:160-163),
+    //     so the sample after it starts from (DECAY, 1.0) whatever came before -- what is not known is WHEN: K attack
+    //     steps after the edge, K from the level the edge found.  K is an integer that a real-arithmetic model of the
+    //     envelope gets right unless (1 - level) / slope sits within ~1e-10 of an integer, and a wrong K of one cycle
+    //     rarely changes the next one's (the level at the next attack edge moves by one decay step, 3 % of an attack
+    //     step for C5's envelopes).  So every attack edge whose gate stays on long enough for the attack to finish from
+    //     level 0 contributes a SPECULATIVE start at edge + K_guess, and the guesses are verified before anything is
+    //     written: the wave before each speculative start walks silently up to the attack completion it finds and
+    //     publishes where that was; a chain of equalities from wave 0 (the carried state: exact) proves every start, a
+    //     mismatch corrects the first wrong position and the round repeats (at most WAVES rounds, then wave 0 walks the
+    //     block alone).  Voices gated faster than ~4.5 Hz, which have no pinned start (the decay does not settle inside
+    //     the gate's on-time) and were one chain of ~180 runs per block, become one chain per gate cycle.
+    __shared__ int s_true[WAVES + 1];
+    // the start list (the same in every wave; each wave keeps its own copy in LDS: cheap dynamic indexing)
+    __shared__ int l_pos[WAVES][WAVES + 1], l_state[WAVES][WAVES + 1], l_edge[WAVES][WAVES + 1], l_watch[WAVES][WAVES + 1];
+    __shared__ double l_env[WAVES][WAVES + 1];
     const double S = p.sustain_level;
-    const bool tame = S >= 0.0 && S <= 1.0;
+    const bool tame = S >= 0.0 && S <= 1.0 && p.attack_dvdt > 0.0 && p.decay_dvdt <= 0.0 && p.release_dvdt < 0.0 &&
+                      p.attack_dvdt == p.attack_dvdt && p.decay_dvdt == p.decay_dvdt && p.release_dvdt == p.release_dvdt;
     const long long bD = tame ? adsr_settle_steps(1.0 - S, -p.decay_dvdt) : kNeverSettles;
     auto attack_from = [&](double level) -> long long {
         const long long a = adsr_settle_steps(level < 1.0 ? 1.0 - level : 0.0, p.attack_dvdt);
@@ -565,102 +586,287 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
     };
     auto release_from = [&](double level) -> long long { return adsr_settle_steps(level, -p.release_dvdt) + 2; };
     const double top = S > 1.0 ? S : 1.0;                 // no level ever exceeds it
-    int seg_start = 0, seg_end = n32, first_edge = 0;
+
+    // the walk of [from, to): k_adsr_walk's loop over this wave's edge list.  emit = false: nothing is written, and the
+    // walk stops right after the attack that edge `watch` starts has pinned the level (returns that position + 1 -- the
+    // first sample of the decay -- or -1 if it reaches `to` first).
+    auto walk = [&](AdsrCtx &c, int from, int to, int next_k, bool emit, int watch) -> int {
+        const int *my_pos = e_pos[j];
+        const unsigned char *my_att = e_att[j];
+        bool edge_attack = false;
+        int next_edge = __builtin_amdgcn_readfirstlane(my_pos[next_k]);
+        edge_attack = __builtin_amdgcn_readfirstlane((int)my_att[next_k]) != 0;
+        if (next_edge > to) next_edge = to;
+        int pos = from;
+        c.have = false;
+        c.dir = 0;
+        c.dq = 0.0;
+        c.lim = 0.0;
+        while (pos < to) {
+            if (pos == next_edge) {                                   // gate edge on this sample
+                c.s = edge_attack ? kAttack : kRelease;
+                c.have = false;
+                ++next_k;
+                next_edge = __builtin_amdgcn_readfirstlane(my_pos[next_k]);      // my_pos[ne] = n
+                edge_attack = __builtin_amdgcn_readfirstlane((int)my_att[next_k]) != 0;
+                if (next_edge > to) next_edge = to;
+            }
+            const long long now = (long long)start + pos;
+            if (!c.have) c.have = adsr_derive(c, p, false, now);
+            if (c.have) {
+                const int room = next_edge - pos;                     // >= 1
+                const int cnt = adsr_run_length(c, false, now, room + 1);
+                const int take = cnt < room ? cnt : room;
+                const double env = c.env, dq = c.dq;
+                if (emit) {
+                    float *dst = o + pos;
+                    for (int t = lane; t < take; t += 64) dst[t] = (float)(env + (double)t * dq);
+                }
+                c.env = env + (double)take * dq;
+                pos += take;
+                if (cnt <= room) {
+                    if (pos < to && pos != next_edge) {
+                        if (emit && lane == 0) o[pos] = (float)c.env;
+                        const int before = c.s;
+                        adsr_step(c, p, false, (long long)start + pos);
+                        pos += 1;
+                        if (!emit && before == kAttack && c.s == kDecay && next_k > watch) return pos;
+                    } else {
+                        c.have = false;
+                    }
+                }
+                continue;
+            }
+            if (emit && lane == 0) o[pos] = (float)c.env;              // literal step for one sample
+            const int before = c.s;
+            adsr_step(c, p, false, now);
+            pos += 1;
+            if (!emit && before == kAttack && c.s == kDecay && next_k > watch) return pos;
+        }
+        return -1;
+    };
+
     AdsrCtx c;
     c.s = s0;
     c.env = env0;
     c.ends_at = 0;
-    bool mine = j == 0;
-    if (sequential) {
-        if (j != 0) return;
-    } else {
+    if (sequential) {                                     // a crowded group: wave 0 walks the block with k_adsr_walk's
+        if (j != 0) return;                               // edge search (masks fetched from memory)
+        c.have = false;
+        c.dir = 0;
+        c.dq = 0.0;
+        c.lim = 0.0;
+        bool edge_attack = false;
+        int next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, 0, edge_attack, lane);
+        int pos = 0;
+        while (pos < n32) {
+            if (pos == next_edge) {
+                c.s = edge_attack ? kAttack : kRelease;
+                c.have = false;
+                next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, pos + 1, edge_attack, lane);
+            }
+            const long long now = (long long)start + pos;
+            if (!c.have) c.have = adsr_derive(c, p, false, now);
+            if (c.have) {
+                const int room = next_edge - pos;
+                const int cnt = adsr_run_length(c, false, now, room + 1);
+                const int take = cnt < room ? cnt : room;
+                const double env = c.env, dq = c.dq;
+                float *dst = o + pos;
+                for (int t = lane; t < take; t += 64) dst[t] = (float)(env + (double)t * dq);
+                c.env = env + (double)take * dq;
+                pos += take;
+                if (cnt <= room) {
+                    if (pos < n32 && pos != next_edge) {
+                        if (lane == 0) o[pos] = (float)c.env;
+                        adsr_step(c, p, false, (long long)start + pos);
+                        pos += 1;
+                    } else {
+                        c.have = false;
+                    }
+                }
+                continue;
+            }
+            if (lane == 0) o[pos] = (float)c.env;
+            adsr_step(c, p, false, now);
+            pos += 1;
+        }
+        if (lane == 0) {
+            st[0] = (double)c.s;
+            st[1] = c.env;
+            st[2] = (double)last_gate[inst];
+        }
+        return;
+    }
+
+    const long long t_list = PGX_ADSR_CLOCK();
+    // ---- the start list: every wave derives the same one from the same edges ----
+    int *sp_pos = l_pos[j], *sp_state = l_state[j], *sp_edge = l_edge[j], *sp_watch = l_watch[j];
+    double *sp_env = l_env[j];
+    int ns = 1;
+    if (lane == 0) { sp_pos[0] = 0; sp_state[0] = s0; sp_env[0] = env0; sp_edge[0] = 0; sp_watch[0] = -1; }
+    {
         const bool sane0 = env0 >= 0.0 && env0 <= top;
         bool prev_up = s0 == kAttack || s0 == kDecay || s0 == kSustain;
         long long need = !sane0 ? kNeverSettles
                          : s0 == kAttack ? attack_from(env0)
                          : s0 == kDecay ? (tame ? adsr_settle_steps(env0 > S ? env0 - S : 0.0, -p.decay_dvdt) + 2 : kNeverSettles)
                          : s0 == kRelease ? release_from(env0) : 2;
-        int prev_pos = 0, starts = 1;
-        for (int k = 0; k < ne; ++k) {
-            const int pos = __builtin_amdgcn_readfirstlane(my_pos[k]);
-            const bool att = __builtin_amdgcn_readfirstlane((int)my_att[k]) != 0;
-            const bool settled = (long long)(pos - prev_pos) >= need;
-            if (settled && starts < WAVES) {
-                if (starts == j) {
-                    mine = true;
-                    seg_start = pos;
-                    first_edge = k;
-                    c.s = prev_up ? kSustain : kIdle;
-                    c.env = prev_up ? S : 0.0;
-                } else if (starts == j + 1) {
-                    seg_end = pos;
+        // a carried state that is pinned already (idle at 0, sustaining at S) makes an edge on the block's very first
+        // samples a pinned start like any other
+        if (sane0 && ((s0 == kIdle && env0 == 0.0) || (s0 == kSustain && env0 == S))) need = 0;
+        // the real-arithmetic model: (ms, ml) at the beginning of sample mp.  Step counts by multiplication with the
+        // slopes' reciprocals (a division per phase and edge was most of the 12 us this list took at first): a count
+        // that is one off at an exact boundary is a wrong guess like any other -- the verification below decides.
+        int ms = s0, mp = 0;
+        double ml = env0;
+        const bool model_ok = tame && sane0 && p.attack_dvdt > 1e-9;
+        const double a_up = p.attack_dvdt, d_dn = -p.decay_dvdt, r_dn = -p.release_dvdt;
+        const double inv_a = model_ok ? 1.0 / a_up : 0.0, inv_d = (model_ok && d_dn > 0.0) ? 1.0 / d_dn : 0.0,
+                     inv_r = model_ok ? 1.0 / r_dn : 0.0;
+        const int k_worst = model_ok ? (int)inv_a + 3 : 0x3fffffff;
+        const long long a_full = model_ok ? (long long)inv_a + 8 : kNeverSettles;          // attack from 0, decay from 1:
+        const long long d_full = (model_ok && d_dn > 0.0) ? (long long)((1.0 - S) * inv_d) + 8 : (d_dn > 0.0 ? kNeverSettles : 8);
+        auto steps_to = [&](double span, double inv) -> double {    // ceil(span / rate), at least 1
+            double kk = ceil(span * inv);
+            return kk < 1.0 ? 1.0 : kk;
+        };
+        auto model_advance = [&](int steps) {
+            while (steps > 0) {
+                if (ms == kAttack) {
+                    const double kk = steps_to(1.0 - ml, inv_a);
+                    if ((double)steps >= kk) { ml = 1.0; ms = kDecay; steps -= (int)kk; }
+                    else { ml += a_up * steps; steps = 0; }
+                } else if (ms == kDecay) {
+                    if (!(d_dn > 0.0)) { steps = 0; break; }
+                    const double kk = steps_to(ml - S, inv_d);
+                    if ((double)steps >= kk) { ml = S; ms = kSustain; steps -= (int)kk; }
+                    else { ml -= d_dn * steps; steps = 0; }
+                } else if (ms == kRelease) {
+                    const double kk = steps_to(ml, inv_r);
+                    if ((double)steps >= kk) { ml = 0.0; ms = kIdle; steps -= (int)kk; }
+                    else { ml -= r_dn * steps; steps = 0; }
+                } else {
+                    steps = 0;
                 }
-                ++starts;
+            }
+        };
+        (void)a_full; (void)d_full;
+        const long long need_att_0 = attack_from(0.0), need_att_s = attack_from(S), need_rel_s = release_from(S),
+                        need_rel_0 = release_from(0.0), need_rel_top = release_from(top);
+        int prev_pos = 0, prev_start = 0;                       // prev_start: position of the last start listed
+        const int *my_pos_l = e_pos[j];
+        const unsigned char *my_att_l = e_att[j];
+        int nxt = __builtin_amdgcn_readfirstlane(my_pos_l[0]);
+        for (int k = 0; k < ne; ++k) {
+            const int pos = nxt;
+            const bool att = __builtin_amdgcn_readfirstlane((int)my_att_l[k]) != 0;
+            nxt = __builtin_amdgcn_readfirstlane(my_pos_l[k + 1]);                // my_pos[ne] = n
+            const bool settled = (long long)(pos - prev_pos) >= need;
+            if (settled && ns < WAVES) {                          // (a) pinned level at this edge
+                if (lane == 0) {
+                    sp_pos[ns] = pos; sp_state[ns] = prev_up ? kSustain : kIdle; sp_env[ns] = prev_up ? S : 0.0;
+                    sp_edge[ns] = k; sp_watch[ns] = -1;
+                }
+                ++ns;
+                prev_start = pos;
+            }
+            if (model_ok) {
+                // (a settled edge pins the model as well: nothing to advance -- envelopes whose edges all settle, the
+                // slow gates, never run the model)
+                if (settled) { ms = prev_up ? kSustain : kIdle; ml = prev_up ? S : 0.0; }
+                else model_advance(pos - mp);
+                mp = pos;
+                ms = att ? kAttack : kRelease;
+                // (an attack edge that found a pinned level already starts a wave of its own; from exactly 0 the guess
+                // would also sit on the boundary -- 1 / slope attack steps in real arithmetic, one more in float64 when
+                // attack_time * sr is an integer -- and cost a verification round for nothing)
+                if (att && !settled && ns < WAVES && nxt - pos >= k_worst && ml < 1.0) {      // (b) attack completion
+                    const int ta = pos + (int)steps_to(1.0 - ml, inv_a);
+                    if (ta < n32 && ta > prev_start) {
+                        if (lane == 0) {
+                            sp_pos[ns] = ta; sp_state[ns] = kDecay; sp_env[ns] = 1.0;
+                            sp_edge[ns] = k + 1; sp_watch[ns] = k;
+                        }
+                        ++ns;
+                        prev_start = ta;
+                    }
+                }
             }
             // the level this edge starts from: pinned if the stretch before it settled, else anything up to `top`
-            const double from = settled ? (prev_up ? S : 0.0) : (att ? 0.0 : top);
+            // (three possible levels per edge kind: their step bounds are made once, outside this loop)
+            const bool from_s = settled && prev_up, from_0 = settled ? !prev_up : att;
             prev_pos = pos;
             prev_up = att;
-            need = att ? attack_from(from) : release_from(from);
+            need = att ? (from_s ? need_att_s : need_att_0) : (from_s ? need_rel_s : from_0 ? need_rel_0 : need_rel_top);
         }
-        if (!mine) return;
     }
-    c.have = false;
-    c.dir = 0;
-    c.dq = 0.0;
-    c.lim = 0.0;
+    if (lane == 0) { sp_pos[ns] = n32; sp_watch[ns] = -1; }
+    __builtin_amdgcn_s_waitcnt(0);           // (wave-private LDS rows: the wave reads back what it wrote)
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- the walk of [seg_start, seg_end): k_adsr_walk's loop ----
-    bool edge_attack = false;
-    int next_k = first_edge;                 // list mode: index of the next edge at or after the position
-    int next_edge;
-    if (sequential) {
-        next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, 0, edge_attack, lane);
-    } else {
-        next_edge = __builtin_amdgcn_readfirstlane(my_pos[next_k]);
-        edge_attack = __builtin_amdgcn_readfirstlane((int)my_att[next_k]) != 0;
-        if (next_edge > seg_end) next_edge = seg_end;
-    }
-    int pos = seg_start;
-    while (pos < seg_end) {
-        if (pos == next_edge) {                                   // gate edge on this sample
-            c.s = edge_attack ? kAttack : kRelease;
-            c.have = false;
-            if (sequential) {
-                next_edge = adsr_next_edge(mk, gb, nch32, gw32, n32, pos + 1, edge_attack, lane);
-            } else {
-                ++next_k;
-                next_edge = __builtin_amdgcn_readfirstlane(my_pos[next_k]);      // my_pos[ne] = n
-                edge_attack = __builtin_amdgcn_readfirstlane((int)my_att[next_k]) != 0;
-                if (next_edge > seg_end) next_edge = seg_end;
+    const long long t_verify = PGX_ADSR_CLOCK();
+    PGX_ADSR_DEBUG_MAX(5, t_verify - t_list);
+    // ---- verify the speculative positions (nothing is written yet) ----
+    auto L_int = [&](const int *row, int q) { return __builtin_amdgcn_readfirstlane(row[q]); };
+    bool any_spec = false;
+    for (int q = 1; q < ns; ++q) any_spec = any_spec || L_int(sp_watch, q) >= 0;
+    bool give_up = false;
+    if (any_spec) {
+        for (int round = 0; round < WAVES + 1; ++round) {
+            PGX_ADSR_DEBUG(4, round + 1);
+            int found = -2;                                       // -2: this wave has nothing to check
+            if (j + 1 < ns && L_int(sp_watch, j + 1) >= 0) {      // the start after this wave's is speculative
+                AdsrCtx t;
+                t.s = L_int(sp_state, j);
+                t.env = sp_env[j];
+                t.ends_at = 0;
+                // (a wrong guess can put the true completion beyond the next start's position: walk on to the block's end)
+                found = walk(t, L_int(sp_pos, j), n32, L_int(sp_edge, j), false, L_int(sp_watch, j + 1));
             }
-        }
-        const long long now = (long long)start + pos;
-        if (!c.have) c.have = adsr_derive(c, p, false, now);
-        if (c.have) {
-            const int room = next_edge - pos;                     // >= 1
-            const int cnt = adsr_run_length(c, false, now, room + 1);
-            const int take = cnt < room ? cnt : room;
-            const double env = c.env, dq = c.dq;
-            float *dst = o + pos;
-            for (int t = lane; t < take; t += 64) dst[t] = (float)(env + (double)t * dq);
-            c.env = env + (double)take * dq;
-            pos += take;
-            if (cnt <= room) {
-                if (pos < seg_end && pos != next_edge) {
-                    if (lane == 0) o[pos] = (float)c.env;
-                    adsr_step(c, p, false, (long long)start + pos);
-                    pos += 1;
-                } else {
-                    c.have = false;
+            if (lane == 0) s_true[j + 1] = found;
+            __syncthreads();
+            // the chain of equalities, the same in every wave
+            int first_bad = -1, fix = -1;
+            bool ok_prev = true;
+            for (int q = 1; q < ns; ++q) {
+                bool ok = true;
+                if (L_int(sp_watch, q) >= 0) {
+                    const int tr = s_true[q];
+                    ok = ok_prev && tr == L_int(sp_pos, q);
+                    if (!ok && first_bad < 0) { first_bad = q; fix = ok_prev ? tr : -1; }
                 }
+                ok_prev = ok;
             }
-            continue;
+            __syncthreads();                                      // s_true is rewritten in the next round
+            if (first_bad < 0) break;
+            if (fix < 0 || round == WAVES) { give_up = true; break; }
+            if (fix <= L_int(sp_pos, first_bad - 1) || fix >= L_int(sp_pos, first_bad + 1)) { give_up = true; break; }
+            if (lane == 0) sp_pos[first_bad] = fix;               // (every wave corrects its own copy)
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) o[pos] = (float)c.env;                      // literal step for one sample
-        adsr_step(c, p, false, now);
-        pos += 1;
     }
+    if (give_up) {                                                // (never seen; keeps the result exact whatever the model did)
+        ns = 1;
+        if (lane == 0) sp_pos[1] = n32;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    PGX_ADSR_DEBUG(0, ns);
+    PGX_ADSR_DEBUG(1, give_up ? 1 : 0);
+    PGX_ADSR_DEBUG(2, ne);
+    PGX_ADSR_DEBUG(3, any_spec ? 1 : 0);
+
+    const long long t_emit = PGX_ADSR_CLOCK();
+    PGX_ADSR_DEBUG_MAX(6, t_emit - t_verify);
+    // ---- the walk of this wave's stretch, written out ----
+    if (j >= ns) return;
+    const int seg_start = L_int(sp_pos, j), seg_end = L_int(sp_pos, j + 1);
+    c.s = L_int(sp_state, j);
+    c.env = sp_env[j];
+    walk(c, seg_start, seg_end, L_int(sp_edge, j), true, -1);
+    PGX_ADSR_DEBUG_MAX(7, PGX_ADSR_CLOCK() - t_emit);
     if (seg_end == n32 && lane == 0) {                            // the wave that walked to the block's end
         st[0] = (double)c.s;
         st[1] = c.env;

@@ -101,6 +101,13 @@ class _BlitSawNode(_Node):
         self.state = DeviceBuffer((self.k, 2), np.float64)
         self.ch = pes[0]._channels
         self.last_end = None
+        # a few oscillators in concurrent time segments: the SuperSaw bank kernel with one voice per instance
+        # (_SuperSawNode.segmented); needs the automatic (odd) M and a leak below 1 for the closed-form carries
+        self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
+                                   and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
+        self.state_alt = None
+        self.tables = None
+        self.unit_amp = None
 
     def reset(self):
         self.last_end = None
@@ -113,7 +120,32 @@ class _BlitSawNode(_Node):
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
 
+    def segmented(self, n: int) -> bool:
+        return (SEGMENTED_SUPERSAW and self.closed_form_ok and 4 <= self.k < FUSED_SUPERSAW_MIN
+                and lib().pgx_supersaw_bank_segments(self.k, n) > 1)
+
+    def _render_segments(self, start, n):
+        """pgx_supersaw_bank_seg with one voice per instance and unit instance amplitude: float32(float64(float32(
+        y * 2 amp)) * 1.0) is the oscillator's own sample."""
+        L = lib()
+        self.prepare(start)
+        if self.state_alt is None:
+            self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
+            self.unit_amp = DeviceBuffer.from_host(np.ones(self.k, dtype=np.float64))
+            self.tables = DeviceBuffer((L.pgx_supersaw_bank_table_bytes(self.k, 1),), np.uint8)
+            check(L.pgx_supersaw_bank_tables(self.tables.ptr, self.k, 1, self.sr, self.params.ptr),
+                  "pgx_supersaw_bank_tables")
+        out = DeviceBuffer((self.k, n, self.ch), np.float32)
+        check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, 1, n, self.ch, self.sr, self.params.ptr,
+                                      self.state.ptr, self.state_alt.ptr, self.unit_amp.ptr, self.tables.ptr),
+              "pgx_supersaw_bank_seg")
+        self.state, self.state_alt = self.state_alt, self.state
+        self.last_end = start + n
+        return out
+
     def render(self, start, n):
+        if self.segmented(n):
+            return self._render_segments(start, n)
         self.prepare(start)
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
         ws = blitsaw_workspace(self, self.k, n, False)

@@ -71,7 +71,23 @@ def _gates_sparse(rng, k, n):
     return g
 
 
-@pytest.mark.parametrize("case", ["gated", "triggered", "gated_small_bank_sparse_gates"])
+def _gates_fast(rng, k, n):
+    """Gates of 3 .. 12 Hz with jitter: on- and off-times too short for the level to be pinned at sustain / zero, long
+    enough (mostly) for the attack to reach 1.0 -- the stretches k_adsr_walk_par starts speculatively at the attack
+    completions -- with a few short blips in between."""
+    g = np.zeros((k, n), np.float32)
+    for i in range(k):
+        pos, level = 0, float(rng.integers(0, 2))
+        half = int(rng.integers(2000, 8000))
+        while pos < n:
+            run = int(rng.integers(1, 60)) if rng.random() < 0.03 else int(half * rng.uniform(0.7, 1.3))
+            g[i, pos:pos + run] = level
+            pos += run
+            level = 1.0 - level
+    return g
+
+
+@pytest.mark.parametrize("case", ["gated", "triggered", "gated_small_bank_sparse_gates", "gated_small_bank_fast_gates"])
 def test_adsr_batch_bit_exact_random(case):
     lib = device.ensure_init()
     triggered = case == "triggered"
@@ -83,6 +99,14 @@ def test_adsr_batch_bit_exact_random(case):
         rec = _params(rng, k, False)
         ctl = _gates_sparse(rng, k, n)
         blocks = [48000, 48000, 1, 4097, 30000, 65536 - 48000]
+    elif case == "gated_small_bank_fast_gates":
+        rng = np.random.default_rng(7)
+        k, n = 96, 200000
+        rec = _params(rng, k, False)
+        for i in range(0, k, 2):                # half of them C5's envelope (10 / 100 / 200 ms, sustain 0.7)
+            rec[i] = (*O.adsr_slopes(0.01, 0.1, 0.7, 0.2, SR), 0.7, 0)
+        ctl = _gates_fast(rng, k, n)
+        blocks = [48000, 48000, 48000, 5000, 33333]
     else:
         k, n = 192, 20000
         rec = _params(rng, k, triggered)

@@ -287,7 +287,7 @@ def test_random_voice_bank_matches_oracle_and_per_voice_rendering(seed):
     # its own: both are converged to ~1e-11, which can still flip the last bit of a float32 sample now and then.
     text = __import__("json").dumps(case["graph"])
     # (and a bank of SuperSawPEs runs in concurrent time segments whose integrator carries come from a closed form)
-    ladder = '"LadderPE"' in text or '"SuperSawPE"' in text
+    ladder = '"LadderPE"' in text or '"SuperSawPE"' in text or '"BlitSawPE"' in text     # (a few BlitSawPEs: the same kernel)
     for i, (b, p, w) in enumerate(zip(banked, plain, want)):
         if ladder:
             assert float(np.max(np.abs(b.astype(np.float64) - p))) <= 1e-6 * float(np.max(np.abs(p))), (case["name"], i)
