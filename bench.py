@@ -348,8 +348,19 @@ def bench_c2(pg, dist, steps, warmup, frames=1_000_000):
             pos = origin + (i - warmup) * frames       # i = warmup - 1: the block just before the timed ones
         keep["s"] = pe.render(pos, frames)             # stays in HBM
 
-    dt = timed_steps(dist, step, steps, warmup)
+    from pygmu2_amd import look_ahead
+    before = dict(look_ahead.STATS)
+
+    def warm_done(i, _step=step):
+        if i == warmup:                                 # the first timed step: everything before it is warm-up
+            before.update(look_ahead.STATS)
+        _step(i)
+
+    dt = timed_steps(dist, warm_done, steps, warmup)
     r.stop()
+    bench_c2.rendered = {"frames_rendered_in_timed_region": look_ahead.STATS["window_frames"] - before["window_frames"],
+                         "frames_counted": frames * steps,
+                         "windows_opened_in_timed_region": look_ahead.STATS["windows"] - before["windows"]}
     return dt, frames
 
 
@@ -980,6 +991,7 @@ def main():
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": name, "frames_per_step": frames,
+                   **(getattr(bench_c2, "rendered", {}) if args.workload == "c2" else {}),
                    "parallelism": (f"inputs of the root MixPE dealt i mod {n_gpus} over the ranks, one RCCL all-reduce "
                                    "of the partial mix per block (pgx_allreduce_sum)" if sharded else
                                    ("single chain" if n_gpus == 1 else f"{n_gpus} independent replicas (replicas only)"))},

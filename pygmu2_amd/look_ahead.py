@@ -41,6 +41,8 @@ AHEAD_BLOCKS = 64           # ... at most this many blocks per window ...
 AHEAD_FRAMES = 1 << 25      # ... and about this many frames (1 M-frame pulls: 32 blocks per window, 128 MB per
                             # channel of every PE in it: C2 3.8 us per step at 2^24, 3.5 at 2^25, 3.3 at 2^26)
 
+STATS = {"window_frames": 0, "windows": 0}     # frames rendered into windows since the process started (bench.py reports
+                                               # how many frames a timed region really rendered next to those it counts)
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_LOOK_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")
 
@@ -227,6 +229,8 @@ def render(pe, start: int, duration: int):
         _tls.busy = False
         _tls.period = 0
     d["_la_grow"] = grow * WINDOW_GROWTH
+    STATS["window_frames"] += duration * blocks
+    STATS["windows"] += 1
     if not big.on_device:                             # host-side graph: nothing to gain, nothing was assumed
         restore_snapshot(snap)
         _tls.busy = True
