@@ -108,7 +108,9 @@ class CombPE(ProcessingElement):
         b_s, b_buf = self._control_stream(self._feedback, start, duration)
         L = lib()
         delay = 0 if self._freq_is_pe else self._scalar_delay()
-        need = L.pgx_comb_workspace_bytes(1, duration, ch, delay, 1 if self._freq_is_pe else 0)
+        # (with a frequency stream the size depends on the ring's rows, not on a delay)
+        need = L.pgx_comb_workspace_bytes(1, duration, ch, self._buffer_len if self._freq_is_pe else delay,
+                                          1 if self._freq_is_pe else 0)
         if need and (self._ws is None or self._ws.nbytes < need):
             self._ws = DeviceBuffer((need,), np.uint8)
         out = new_output(duration, ch)

@@ -239,7 +239,7 @@ k_comb_poly(float *out, int64_t out_stride, const float *in, int64_t in_stride, 
 // ------------------------------------------------------------------------------------------------ PE-driven frequency
 constexpr int kCtlThreads = 1024, kCtlT = 4, kCtlTile = kCtlThreads * kCtlT;
 
-constexpr int kCtlSegTiles = 16;                              // a workgroup's share of a long block: 65 536 samples
+constexpr int kCtlSegTiles = 1;                               // a workgroup's share of a block: one tile of 4096 samples
 
 // delay[i] = clip(rint(sr / max(sm_i, 1)), 1, len - 1) with sm the one-pole of comb_pe.py:61-68;
 // gmin / gmax[g] = min / max of the delays of samples [64 g, 64 g + 64).  state[0] = smoothed frequency (-1: unset).
@@ -481,6 +481,233 @@ k_comb_ring(float *out, const float *in, int64_t n, int channels, const double *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PE-driven frequency, long blocks: time segments.  y[n] = x[n] + f[n] y[n - D[n]] has ONE tap, so following the tap
+// back from any frame of a segment ends on exactly one frame before the segment: y[n] = Z[n] + P[n] * y[src[n]] with Z
+// the frame's zero-state value, P the product of the feedbacks along the way and src the frame the chain lands on
+// (all three built chunk by chunk like k_comb_ring builds y: Z[n] = x[n] + f Z[n - D], P[n] = f P[n - D], src[n] =
+// src[n - D] while n - D is inside the segment).  Segments are kSegLen frames (>= the longest delay: a chain lands
+// in the segment just before), so
+//   k_comb_seg_a     every segment at once: (Z, P, src) of its frames, in LDS, left in HBM;
+//   the tails        each segment's last `tail` frames (tail = buffer_len - 1 >= any delay) as a function of the tail
+//                    before it, composed over groups of segments (k_comb_seg_compose, k_comb_seg_groups below);
+//   k_comb_seg_b     every frame at once: y = Z + P * (previous segment's tail)[src], float32 out, new ring.
+// The combination y = Z + P * y_prev rounds differently from the loop (<= 1e-7 of peak asserted, ~1e-16 observed in
+// float64); blocks of fewer than three segments keep k_comb_ring, which is the loop.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSegLen = 4096, kSegThreads = 256, kSegGroups = kSegLen / 64;
+inline bool comb_stream_segmented(int64_t n, int64_t buffer_len) {
+    return buffer_len >= 2 && buffer_len - 1 <= kSegLen - 1 && n >= 3 * (int64_t)kSegLen;
+}
+
+template <bool FBS>
+__global__ void __launch_bounds__(kSegThreads)
+k_comb_seg_a(const float *in, int64_t n, int channels, const int32_t *delay, const int32_t *gmin,
+             const pgx_comb_params *params, const float *fbs, double *Zg, double *Pg, int32_t *srcg) {
+    extern __shared__ double s_dyn[];                              // Z, P (float64), src, d (int32), x, f (float32): 128 KB
+    double *Zs = s_dyn, *Ps = s_dyn + kSegLen;
+    int32_t *s_src = reinterpret_cast<int32_t *>(Ps + kSegLen), *s_d = s_src + kSegLen;
+    float *s_x = reinterpret_cast<float *>(s_d + kSegLen), *s_f = s_x + kSegLen;
+    __shared__ int32_t s_chunk[kSegGroups];
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const int64_t seg0 = (int64_t)blockIdx.x * kSegLen;
+    const int sl = (int)((n - seg0) < kSegLen ? (n - seg0) : kSegLen);
+    const double fbc = FBS ? 0.0 : comb_fb(params[0].feedback);
+    const int64_t groups_total = (n + 63) >> 6;
+    // the segment's samples, delays and feedback: one coalesced sweep into LDS
+#pragma unroll
+    for (int k = 0; k < kSegLen / kSegThreads; ++k) {
+        const int idx = tid + k * kSegThreads;
+        int64_t i = seg0 + idx;
+        i = i < n ? i : n - 1;
+        s_x[idx] = in[i * channels + ch];
+        s_d[idx] = delay[i];
+        if (FBS) s_f[idx] = fbs[i];
+    }
+    __syncthreads();
+    // chunk length for a chunk starting in group g (it covers at most kSegThreads frames = groups g .. g + 4): S <= min D
+    if (tid < kSegGroups) {
+        int lo = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k <= kSegThreads / 64; ++k) {
+            const int64_t g = (seg0 >> 6) + tid + k;
+            if (g < groups_total) lo = min(lo, gmin[g]);
+        }
+        s_chunk[tid] = min(max(lo, 1), kSegThreads);
+    }
+    __syncthreads();
+    const int my_chunk = s_chunk[(tid & 63) < kSegGroups ? (tid & 63) : 0];
+    int p = 0;
+    int S = min(__builtin_amdgcn_readlane(my_chunk, 0), sl);
+    while (p < sl) {
+        const int pn = p + S;
+        int Sn = 0;
+        if (pn < sl) Sn = min(__builtin_amdgcn_readlane(my_chunk, pn >> 6), sl - pn);
+        if (tid < S) {
+            const int i = p + tid;
+            const int j = i - s_d[i];                              // the frame the tap reads, segment-local
+            const double f = FBS ? comb_fb((double)s_f[i]) : fbc;
+            double z = (double)s_x[i], pr = f;
+            int sr = j;
+            if (j >= 0) {
+                z = z + f * Zs[j];                                 // comb_pe.py:97 on the zero-state values
+                pr = f * Ps[j];
+                sr = s_src[j];
+            }
+            Zs[i] = z;
+            Ps[i] = pr;
+            s_src[i] = sr;                                         // < 0: frames before the segment's first
+        }
+        __syncthreads();
+        p = pn;
+        S = Sn;
+    }
+    const int64_t base = ((int64_t)ch * ((n + kSegLen - 1) / kSegLen) + blockIdx.x) * kSegLen;
+#pragma unroll
+    for (int k = 0; k < kSegLen / kSegThreads; ++k) {
+        const int idx = tid + k * kSegThreads;
+        if (idx < sl) {
+            Zg[base + idx] = Zs[idx];
+            Pg[base + idx] = Ps[idx];
+            srcg[base + idx] = s_src[idx];
+        }
+    }
+}
+
+// The tails.  tail(s) = the last `tail` outputs of segment s is a gather-affine function of tail(s - 1):
+// tail(s)[t] = Z[t] + P[t] * tail(s - 1)[tail + src[t]], and two such maps compose into one of the same form
+// (Z'' = Z + P Z'[src], P'' = P P'[src], src'' = src'[src]).  Walking 689 segments of a look-ahead window one after the other
+// cost 2 us each; instead
+//   k_comb_seg_compose  groups of kSegGroupLen segments, all groups at once: segment s's map composed onto its group's
+//                       earlier ones -> comp(s): tail(s) as a function of the tail before the group;
+//   k_comb_seg_groups   one workgroup per channel walks the GROUPS: T(g + 1) = comp(last of g)(T(g)), T(0) = the ring;
+//   k_comb_seg_b        every frame at once: y = Z + P * tail(s - 1)[src], tail(s - 1)[k] = comp(s - 1)(T(group))[k].
+constexpr int kSegGroupLen = 32, kFoldThreads = 1024, kFoldPer = 4;          // tail <= 4095 = 4 x 1024 - 1
+
+__global__ void __launch_bounds__(kFoldThreads)
+k_comb_seg_compose(int64_t n, int64_t len, const double *Zg, const double *Pg, const int32_t *srcg, double *Zc,
+                   double *Pc, int32_t *srcc) {
+    extern __shared__ double s_dyn[];                              // two images of (Z, P: float64; src: int32) x tail
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const int tail = (int)len - 1;
+    const int64_t nseg = (n + kSegLen - 1) / kSegLen;
+    const int64_t s_first = (int64_t)blockIdx.x * kSegGroupLen;
+    int64_t s_end = s_first + kSegGroupLen;
+    if (s_end > nseg - 1) s_end = nseg - 1;                        // the last segment's tail is never needed
+    if (s_first >= s_end) return;
+    double *zi[2] = {s_dyn, s_dyn + 2 * tail};
+    double *pi[2] = {s_dyn + tail, s_dyn + 3 * tail};
+    int32_t *si[2] = {reinterpret_cast<int32_t *>(s_dyn + 4 * tail), reinterpret_cast<int32_t *>(s_dyn + 4 * tail) + tail};
+    double zr[kFoldPer], pr[kFoldPer];
+    int sr[kFoldPer];
+    auto fetch = [&](int64_t sgm) {
+        const int64_t base = ((int64_t)ch * nseg + sgm) * kSegLen + (kSegLen - tail);
+#pragma unroll
+        for (int k = 0; k < kFoldPer; ++k) {
+            int t = tid + k * kFoldThreads;
+            t = t < tail ? t : tail - 1;
+            zr[k] = Zg[base + t];
+            pr[k] = Pg[base + t];
+            sr[k] = srcg[base + t];
+        }
+    };
+    fetch(s_first);
+    int img = 0;
+    for (int64_t sgm = s_first; sgm < s_end; ++sgm) {
+        double zc[kFoldPer], pc[kFoldPer];
+        int sc[kFoldPer];
+#pragma unroll
+        for (int k = 0; k < kFoldPer; ++k) { zc[k] = zr[k]; pc[k] = pr[k]; sc[k] = sr[k]; }
+        if (sgm + 1 < s_end) fetch(sgm + 1);                        // the next segment's map, in flight during this one
+        const int64_t ob = ((int64_t)ch * nseg + sgm) * tail;
+#pragma unroll
+        for (int k = 0; k < kFoldPer; ++k) {
+            const int t = tid + k * kFoldThreads;
+            if (t < tail) {
+                double z = zc[k], pp = pc[k];
+                int sidx = sc[k];
+                if (sgm > s_first) {                                // onto the maps composed so far
+                    const int at = tail + sidx;
+                    z = __builtin_fma(pp, zi[img ^ 1][at], z);
+                    pp = pp * pi[img ^ 1][at];
+                    sidx = si[img ^ 1][at];
+                }
+                zi[img][t] = z;
+                pi[img][t] = pp;
+                si[img][t] = sidx;
+                Zc[ob + t] = z;
+                Pc[ob + t] = pp;
+                srcc[ob + t] = sidx;
+            }
+        }
+        __syncthreads();
+        img ^= 1;
+    }
+}
+
+// Tg[ch][g][t]: the tail in front of group g (g = 0: the ring).  One workgroup per channel.
+__global__ void __launch_bounds__(kFoldThreads)
+k_comb_seg_groups(int64_t n, int channels, const double *ring_old, int64_t len, int64_t wp0, const double *Zc,
+                  const double *Pc, const int32_t *srcc, double *Tg) {
+    extern __shared__ double s_dyn[];                              // two images of `tail` doubles
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    const int tail = (int)len - 1;
+    const int64_t nseg = (n + kSegLen - 1) / kSegLen;
+    const int64_t ngroups = (nseg - 1 + kSegGroupLen - 1) / kSegGroupLen;       // groups of segments that have successors
+    double *prev = s_dyn, *cur = s_dyn + tail;
+    for (int t = tid; t < tail; t += kFoldThreads) {                // frame -tail + t sits in ring row (wp0 - tail + t) mod len
+        int64_t row = (wp0 - tail + t) % len;
+        row = row < 0 ? row + len : row;
+        const double v = ring_old[row * channels + ch];
+        prev[t] = v;
+        Tg[((int64_t)ch * ngroups + 0) * tail + t] = v;
+    }
+    __syncthreads();
+    for (int64_t g = 0; g + 1 < ngroups; ++g) {
+        int64_t last = (g + 1) * kSegGroupLen - 1;                  // the group's last segment (it has successors)
+        const int64_t cb = ((int64_t)ch * nseg + last) * tail;
+        for (int t = tid; t < tail; t += kFoldThreads) {
+            const double y = __builtin_fma(Pc[cb + t], prev[tail + srcc[cb + t]], Zc[cb + t]);
+            cur[t] = y;
+            Tg[((int64_t)ch * ngroups + g + 1) * tail + t] = y;
+        }
+        __syncthreads();
+        double *sw = prev;
+        prev = cur;
+        cur = sw;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_comb_seg_b(float *out, int64_t n, int channels, const double *ring_old, double *ring_new, int64_t len, int64_t wp0,
+             const double *Zg, const double *Pg, const int32_t *srcg, const double *Zc, const double *Pc,
+             const int32_t *srcc, const double *Tg) {
+    const int ch = blockIdx.y;
+    const int tail = (int)len - 1;
+    const int64_t nseg = (n + kSegLen - 1) / kSegLen;
+    const int64_t ngroups = (nseg - 1 + kSegGroupLen - 1) / kSegGroupLen;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t sgm = i / kSegLen;
+    const int local = (int)(i - sgm * kSegLen);
+    const int64_t at = ((int64_t)ch * nseg + sgm) * kSegLen + local;
+    const int sr = srcg[at];                                        // -tail .. -1
+    double yp;
+    if (sgm == 0) {
+        int64_t row = (wp0 + sr) % len;
+        row = row < 0 ? row + len : row;
+        yp = ring_old[row * channels + ch];
+    } else {
+        // tail(sgm - 1)[k] = comp(sgm - 1)(T(group of sgm - 1))[k]
+        const int64_t ps = sgm - 1, g = ps / kSegGroupLen;
+        const int64_t cb = ((int64_t)ch * nseg + ps) * tail + (tail + sr);
+        yp = __builtin_fma(Pc[cb], Tg[((int64_t)ch * ngroups + g) * tail + (tail + srcc[cb])], Zc[cb]);
+    }
+    const double y = __builtin_fma(Pg[at], yp, Zg[at]);
+    out[i * channels + ch] = (float)y;
+    if (i >= n - len) ring_new[((wp0 + i) % len) * channels + ch] = y;      // (n >= 3 segments > len: every row is rewritten)
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -488,9 +715,17 @@ extern "C" {
 
 size_t pgx_comb_workspace_bytes(int batch, int64_t n, int channels, int delay_max, int freq_stream) {
     if (batch <= 0 || n <= 0 || channels <= 0) return 0;
-    if (freq_stream)       // delays, group minima / maxima, segment ends of the control one-pole
-        return (size_t)(n + 2 * ((n + 63) / 64) + 64) * sizeof(int32_t) +
-               (size_t)(pgx::ceil_div(n, (int64_t)kCtlSegTiles * kCtlTile) + 2) * sizeof(double);
+    if (freq_stream) {     // delays, group minima / maxima, segment ends of the control one-pole; then per frame and
+        // channel Z, P (float64), src (int32) and the segment tails of the three-pass path (delay_max = buffer_len here)
+        size_t b = (size_t)(n + 2 * ((n + 63) / 64) + 64) * sizeof(int32_t) +
+                   (size_t)(pgx::ceil_div(n, (int64_t)kCtlSegTiles * kCtlTile) + 4) * sizeof(double);
+        if (comb_stream_segmented(n, delay_max)) {
+            const size_t nseg = (size_t)pgx::ceil_div(n, kSegLen);
+            b += 16 + (size_t)channels * nseg * ((size_t)kSegLen * 20 + (size_t)delay_max * 20) +
+                 (size_t)channels * ((size_t)pgx::ceil_div((int64_t)nseg, kSegGroupLen) + 1) * (size_t)delay_max * 8;
+        }
+        return b;
+    }
     if (delay_max < 1) return 0;
     return (size_t)batch * (size_t)poly_ws_doubles(n, channels, delay_max) * sizeof(double);
 }
@@ -531,6 +766,54 @@ int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride,
         const double *ring_old = ring + (int64_t)parity * ring_rows * channels;
         double *ring_new = ring + (int64_t)(parity ^ 1) * ring_rows * channels;
         const int64_t wp0 = total_frames % len;
+        PGX_CHECK_ARG(fb || params, "pgx_comb: params required for a scalar feedback");
+        static const bool seg_on = !(getenv("PGX_COMB_SEGMENTS") && atoi(getenv("PGX_COMB_SEGMENTS")) == 0);
+        if (seg_on && comb_stream_segmented(n, len)) {
+            // ---- three passes over time segments (comment above k_comb_seg_a)
+            const int64_t nseg = pgx::ceil_div(n, kSegLen);
+            const int tail = (int)len - 1;
+            double *Zg = (double *)(((uintptr_t)(ends + ctl_segs + 2) + 7) & ~(uintptr_t)7);
+            double *Pg = Zg + (size_t)channels * nseg * kSegLen;
+            double *Zc = Pg + (size_t)channels * nseg * kSegLen;
+            double *Pc = Zc + (size_t)channels * nseg * tail;
+            const int64_t ngroups = pgx::ceil_div(nseg - 1, kSegGroupLen);
+            double *Tg = Pc + (size_t)channels * nseg * tail;
+            int32_t *srcg = (int32_t *)(Tg + (size_t)channels * ngroups * tail);
+            int32_t *srcc = srcg + (size_t)channels * nseg * kSegLen;
+            static bool allowed = false;
+            if (!allowed) {
+                PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_comb_seg_a<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSegLen * 32));
+                PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_comb_seg_a<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSegLen * 32));
+                PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_comb_seg_compose),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 40));
+                PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_comb_seg_groups),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * 8));
+                allowed = true;
+            }
+            const dim3 ga((unsigned)nseg, (unsigned)channels);
+            if (fb)
+                hipLaunchKernelGGL(k_comb_seg_a<true>, ga, dim3(kSegThreads), kSegLen * 32, pgx::stream(), in, n, channels,
+                                   (const int32_t *)delay, (const int32_t *)gmin, params, fb, Zg, Pg, srcg);
+            else
+                hipLaunchKernelGGL(k_comb_seg_a<false>, ga, dim3(kSegThreads), kSegLen * 32, pgx::stream(), in, n, channels,
+                                   (const int32_t *)delay, (const int32_t *)gmin, params, fb, Zg, Pg, srcg);
+            PGX_LAUNCH_CHECK("k_comb_seg_a");
+            hipLaunchKernelGGL(k_comb_seg_compose, dim3((unsigned)ngroups, (unsigned)channels), dim3(kFoldThreads),
+                               (size_t)tail * 40, pgx::stream(), n, len, (const double *)Zg, (const double *)Pg,
+                               (const int32_t *)srcg, Zc, Pc, srcc);
+            PGX_LAUNCH_CHECK("k_comb_seg_compose");
+            hipLaunchKernelGGL(k_comb_seg_groups, dim3(channels), dim3(kFoldThreads), (size_t)2 * tail * 8, pgx::stream(), n,
+                               channels, ring_old, len, wp0, (const double *)Zc, (const double *)Pc, (const int32_t *)srcc, Tg);
+            PGX_LAUNCH_CHECK("k_comb_seg_groups");
+            hipLaunchKernelGGL(k_comb_seg_b, dim3((unsigned)pgx::ceil_div(n, 256), (unsigned)channels), dim3(256), 0,
+                               pgx::stream(), out, n, channels, ring_old, ring_new, len, wp0, (const double *)Zg,
+                               (const double *)Pg, (const int32_t *)srcg, (const double *)Zc, (const double *)Pc,
+                               (const int32_t *)srcc, (const double *)Tg);
+            PGX_LAUNCH_CHECK("k_comb_seg_b");
+            return PGX_OK;
+        }
         const size_t lds = (size_t)len * sizeof(double);
         const bool in_lds = lds <= 96 * 1024;
         if (in_lds && lds > 32 * 1024) {
@@ -546,7 +829,6 @@ int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride,
     hipLaunchKernelGGL((k_comb_ring<LDS, FBS>), dim3(channels), dim3(kRingThreads), (LDS) ? lds : 0, pgx::stream(), \
                        out, in, n, channels, ring_old, ring_new, len, wp0, (const int32_t *)delay,                \
                        (const int32_t *)gmin, (const int32_t *)gmax, params, fb)
-        PGX_CHECK_ARG(fb || params, "pgx_comb: params required for a scalar feedback");
         if (in_lds) {
             if (fb) PGX_RING(true, true);
             else PGX_RING(true, false);
