@@ -15,12 +15,13 @@
 //     is double buffered ([2][rows][channels], `parity` names the half to read): lanes that finish early write the
 //     new half while late lanes still read their carry-in from the old one.
 //
-// (2) frequency from a PE: k_comb_delays turns the control stream into integer delays with a time-parallel scan of
-//     the one-pole (the literal update on each thread's samples, affine composition across threads), then
-//     k_comb_ring runs one workgroup per channel with the ring in LDS: chunks of samples that do not reach into
-//     themselves (chunk length from a sliding minimum of the delays made by k_comb_delays -- no search in the loop)
-//     are read, computed and written by the lanes at once, one barrier per chunk; samples, delays and feedback are
-//     staged through LDS tile by tile so that the chunk loop never waits for HBM.
+// (2) frequency from a PE: k_comb_delays turns the control stream into integer delays with a time-parallel evaluation
+//     of the one-pole (the literal update on each thread's samples, affine composition across threads and, over the
+//     4096-sample tiles of a block, across workgroups).  Short blocks: k_comb_ring, one workgroup per channel with the
+//     ring in LDS -- chunks of samples that do not reach into themselves (chunk length from a sliding minimum of the
+//     delays made by k_comb_delays: no search in the loop) are read, computed and written by the lanes at once, one
+//     barrier per chunk; samples, delays and feedback are staged through LDS tile by tile.  Blocks of three 4096-frame
+//     segments and more: k_comb_seg_a / _compose / _groups / _b -- every segment at once (comment above k_comb_seg_a).
 #include "pgx_common.h"
 
 namespace {
@@ -28,8 +29,8 @@ namespace {
 constexpr double kMaxFeedback = 0.995;                  // comb_pe.py:32 (max_feedback passed by _render)
 constexpr int kPolySingleSteps = 1024;                  // up to this many steps per lane: one segment (exact)
 constexpr int kPolySegSteps = 64;                       // steps per lane and segment when segmented
-constexpr int kPolyMaxSeg = 512;
-constexpr int kPolyBatch = 32;                          // loads in flight per lane (and as many being consumed)                        // the apply pass folds up to this many (P, Z) pairs per lane
+constexpr int kPolyMaxSeg = 512;                        // the apply pass folds up to this many (P, Z) pairs per lane
+constexpr int kPolyBatch = 32;                          // loads in flight per lane (and as many being consumed)
 
 __device__ __forceinline__ double comb_fb(double f) {   // comb_pe.py:87-95
     f = isfinite(f) ? f : 0.0;
