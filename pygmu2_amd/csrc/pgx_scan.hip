@@ -1561,7 +1561,7 @@ struct SsShared {
     // per voice and thread, made once per launch (inner tiles: every frame live, so a thread's 8 increments, their
     // wave scan and the folds over the waves are the same numbers tile after tile -- ~70 instructions per voice and
     // tile of the ~600), and per voice and lane the powers of the leak the integrator scan multiplies with
-    double run8[kSsMaxVoices];
+    double amp2[kSsMaxVoices];            // 2 * amplitude (the table slot a never-read run8 used to occupy)
     double tot[kSsMaxVoices];
     double offset[kSsMaxVoices][NW * 64];
     double lane_pw[kSsMaxVoices][64][3];
@@ -1572,7 +1572,7 @@ struct SsShared {
 // constants, the rotation sines, the powers of the leak, and per thread / lane the prefix offsets and scan powers.
 // ss_make_tables computes them (as every launch did); k_supersaw_tables leaves them in HBM once per bank so that
 // the workgroups of later launches -- four per instance in the time-segmented form -- only load them (26 KB, L2).
-// Per voice: rot[4], rot_ok, kc[0..4], lam[8], run8, tot, offset[256], lane_pw[64][3].
+// Per voice: rot[4], rot_ok, kc[0..4], lam[8] (lam[7] = leak), 2 * amp, tot, offset[256], lane_pw[64][3].
 constexpr int kSsTabDoubles = 4 + 1 + 5 + 8 + 2 + 256 + 192;
 
 template <int NW>
@@ -1594,6 +1594,7 @@ __device__ __forceinline__ void ss_make_tables(SsShared<NW> &sh, const pgx_blits
             l = l * l;
         }
         sh.lam[tid][7] = pt.leak;
+        sh.amp2[tid] = 2.0 * pt.amp;
     }
     __syncthreads();
     for (int v = 0; v < nv; ++v) {                          // the per-thread tables (all threads, every voice)
@@ -1603,10 +1604,7 @@ __device__ __forceinline__ void ss_make_tables(SsShared<NW> &sh, const pgx_blits
         for (int j = 0; j < kSawT; ++j) run = run + inc;
         const UniformPrefix u = uniform_prefix(run);
         sh.offset[v][tid] = u.offset;
-        if (tid == 0) {
-            sh.run8[v] = run;
-            sh.tot[v] = u.tot;
-        }
+        if (tid == 0) sh.tot[v] = u.tot;
         if (tid < 64) {
             double lamp[6];
 #pragma unroll
@@ -1640,7 +1638,7 @@ __device__ __forceinline__ void ss_load_tables(SsShared<NW> &sh, const double *t
             else if (o < 5) sh.rot_ok[v] = x != 0.0 ? 1 : 0;
             else if (o < 10) sh.kc[v][o - 5] = x;
             else if (o < 18) sh.lam[v][o - 10] = x;
-            else if (o < 19) sh.run8[v] = x;
+            else if (o < 19) sh.amp2[v] = x;
             else if (o < 20) sh.tot[v] = x;
             else if (o < 276) {
 #pragma unroll
@@ -1667,7 +1665,7 @@ k_supersaw_tables(double *tables, int nv, double sr, const pgx_blitsaw_params *p
         else if (o < 5) x = (double)sh.rot_ok[v];
         else if (o < 10) x = sh.kc[v][o - 5];
         else if (o < 18) x = sh.lam[v][o - 10];
-        else if (o < 19) x = sh.run8[v];
+        else if (o < 19) x = sh.amp2[v];
         else if (o < 20) x = sh.tot[v];
         else if (o < 276) x = sh.offset[v][o - 20];
         else {
@@ -1808,13 +1806,13 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         constexpr bool INNER = true;
 #pragma unroll 1
         for (int v = 0; v < nv; ++v, ++parity) {
-            const pgx_blitsaw_params p = pv[v];
-            // the voice's constants come from LDS (made once per launch: per tile they were a third of the work)
+            // the voice's constants come from LDS (made once per launch: per tile they were a third of the work; leak and
+            // amplitude too: a global load per voice and tile sat at the head of every voice's chain)
             SawConst k0;
             k0.inc = sh.kc[v][0]; k0.m = sh.kc[v][1]; k0.P = sh.kc[v][2]; k0.invP = sh.kc[v][3];
             const double phase0 = sh.kc[v][5];
-            const double leak = p.leak;
-            const double amp2 = 2.0 * p.amp;
+            const double leak = sh.lam[v][7];
+            const double amp2 = sh.amp2[v];
             double lamp[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) lamp[k] = sh.lam[v][k];
