@@ -24,6 +24,10 @@
 
 #include "pgx_common.h"
 
+#ifndef PGX_FFT_STAMP
+#define PGX_FFT_STAMP(k, i)        /* tools/microbench/fft_phases.hip defines it to record wall_clock64() */
+#endif
+
 namespace {
 
 constexpr int kFBlock = 256;
@@ -164,20 +168,99 @@ __device__ __forceinline__ void first_stage(const cplx &x0, const cplx &x1, cons
     at4j[3] = csub(s1, s3);
 }
 
-// The last Stockham stage (Ns = q: k = j) into registers.  A thread that will consume X[j0 + u*jstep], u < PT,
-// jstep = M/PT, of a sequence computes exactly the butterflies j = j0 + bf*jstep whose outputs those are.
-template <int PT>
-__device__ __forceinline__ void last_stage(const cplx *seq, const cplx *st, int lm, int j0, int jstep, cplx (&v)[PT]) {
-    constexpr int U4 = PT / 4, U2 = PT / 2;
-    const int last = (lm & 1) ? lm - 1 : lm - 2;                // lns of the final stage
-    const int Ns = 1 << last;
-    const cplx *tws = st + (Ns - 1);
-    if (lm & 1) {                                               // radix 2: outputs j, j + M/2
+// The stage twiddles of a thread.  A thread's butterfly of a middle stage (sub-transform length Ns) is w = tid + u*256,
+// position j = w & (M/4 - 1), twiddle index k = j & (Ns - 1): the same three factors W_4Ns^(k*t) in every transform
+// the workgroup runs, and so are those of the last stage (the thread's own outputs).  They are gathered once from the
+// global table g[p] = W_M^p into registers: no table in LDS (16 KB less per workgroup: five workgroups per CU
+// instead of three), and a radix-4 butterfly reads four LDS words instead of seven.
+template <int TILE, int LM>
+struct StageTwiddles {
+    static constexpr int PT = TILE / kFBlock, U4 = PT / 4, U2 = PT / 2;
+    static constexpr int LAST = (LM & 1) ? LM - 1 : LM - 2;       // lns of the final stage
+    static constexpr int MID = (LAST - 2) / 2;                    // stages lns = 2, 4 .. LAST - 2 go through LDS
+    static constexpr int NLAST = (LM & 1) ? U2 : 3 * U4;
+    cplx mid[MID > 0 ? MID : 1][U4][3];
+    cplx last[NLAST];
+
+    // j0, jstep: the thread consumes X[j0 + u*jstep] (see tile_fft_regs)
+    __device__ __forceinline__ void load(const cplx *g, int j0, int jstep) {
+#pragma unroll
+        for (int m = 0; m < MID; ++m) {
+            const int lns = 2 + 2 * m, Ns = 1 << lns;
+#pragma unroll
+            for (int u = 0; u < U4; ++u) {
+                const int w = threadIdx.x + u * kFBlock;
+                const int k = w & ((1 << (LM - 2)) - 1) & (Ns - 1);
+#pragma unroll
+                for (int t = 1; t <= 3; ++t) mid[m][u][t - 1] = g[(k * t) << (LM - 2 - lns)];
+            }
+        }
+        if constexpr (LM & 1) {
+#pragma unroll
+            for (int bf = 0; bf < U2; ++bf) last[bf] = g[j0 + bf * jstep];
+        } else {
+#pragma unroll
+            for (int bf = 0; bf < U4; ++bf) {
+                const int j = j0 + bf * jstep;
+#pragma unroll
+                for (int t = 1; t <= 3; ++t) last[3 * bf + t - 1] = g[j * t];
+            }
+        }
+    }
+};
+
+// DFT of the sequences (length M = 2^LM, `stride` apart) of a tile with the first and the last stage in registers:
+// those are the butterflies whose operands / results are the thread's own elements x[j0 + u*jstep] (u < PT,
+// jstep = M/PT) of the sequence at `seq_off`, so of the LM/2 LDS round trips (write, barrier, read) two disappear.
+// `a`, `b`: the two LDS images (contents irrelevant; nobody may still be reading `a`).  Returns the image last read
+// (the other one is free to write), with X[j0 + u*jstep] in v[u].
+template <int TILE, int LM>
+__device__ __forceinline__ cplx *tile_fft_regs(cplx (&v)[TILE / kFBlock], cplx *a, cplx *b,
+                                               const StageTwiddles<TILE, LM> &tw, int stride, int seq_off, int j0,
+                                               int jstep) {
+    using TW = StageTwiddles<TILE, LM>;
+    constexpr int PT = TW::PT, U4 = TW::U4, U2 = TW::U2;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int bf = 0; bf < U4; ++bf)
+        first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], a + seq_off + 4 * (j0 + bf * jstep));
+    __syncthreads();
+    cplx *src = a, *dst = b;
+    constexpr int lq = LM - 2, q = 1 << lq;                      // radix-4 butterflies per sequence
+#pragma unroll
+    for (int m = 0; m < TW::MID; ++m) {
+        const int Ns = 1 << (2 + 2 * m);
+#pragma unroll
+        for (int u = 0; u < U4; ++u) {
+            const int w = tid + u * kFBlock;
+            const int s = w >> lq, j = w & (q - 1);
+            const int k = j & (Ns - 1);
+            const cplx *bi = src + s * stride;
+            const cplx x0 = bi[j];
+            const cplx c1 = cmul(bi[j + q], tw.mid[m][u][0]);
+            const cplx c2 = cmul(bi[j + 2 * q], tw.mid[m][u][1]);
+            const cplx c3 = cmul(bi[j + 3 * q], tw.mid[m][u][2]);
+            const cplx s0 = cadd(x0, c2), s1 = csub(x0, c2), s2 = cadd(c1, c3), s3 = mul_neg_i(csub(c1, c3));
+            cplx *bo = dst + s * stride + (j - k) * 4 + k;
+            bo[0] = cadd(s0, s2);
+            bo[Ns] = cadd(s1, s3);
+            bo[2 * Ns] = csub(s0, s2);
+            bo[3 * Ns] = csub(s1, s3);
+        }
+        __syncthreads();
+        cplx *t = src;
+        src = dst;
+        dst = t;
+    }
+    // the last stage (Ns = q or M/2: k = j) into registers: exactly the butterflies whose outputs are the thread's
+    const cplx *seq = src + seq_off;
+    constexpr int Ns = 1 << TW::LAST;
+    if constexpr (LM & 1) {                                     // radix 2: outputs j, j + M/2
 #pragma unroll
         for (int bf = 0; bf < U2; ++bf) {
             const int j = j0 + bf * jstep;
             const cplx x0 = seq[j];
-            const cplx c1 = cmul(seq[j + Ns], tws[j]);
+            const cplx c1 = cmul(seq[j + Ns], tw.last[bf]);
             v[bf] = cadd(x0, c1);
             v[bf + U2] = csub(x0, c1);
         }
@@ -186,9 +269,9 @@ __device__ __forceinline__ void last_stage(const cplx *seq, const cplx *st, int 
         for (int bf = 0; bf < U4; ++bf) {
             const int j = j0 + bf * jstep;
             const cplx x0 = seq[j];
-            const cplx c1 = cmul(seq[j + Ns], tws[j]);
-            const cplx c2 = cmul(seq[j + 2 * Ns], tws[Ns + j]);
-            const cplx c3 = cmul(seq[j + 3 * Ns], tws[2 * Ns + j]);
+            const cplx c1 = cmul(seq[j + Ns], tw.last[3 * bf]);
+            const cplx c2 = cmul(seq[j + 2 * Ns], tw.last[3 * bf + 1]);
+            const cplx c3 = cmul(seq[j + 3 * Ns], tw.last[3 * bf + 2]);
             const cplx s0 = cadd(x0, c2), s1 = csub(x0, c2), s2 = cadd(c1, c3), s3 = mul_neg_i(csub(c1, c3));
             v[bf] = cadd(s0, s2);
             v[bf + U4] = cadd(s1, s3);
@@ -196,24 +279,6 @@ __device__ __forceinline__ void last_stage(const cplx *seq, const cplx *st, int 
             v[bf + 3 * U4] = csub(s1, s3);
         }
     }
-}
-
-// DFT of the sequences of a tile with the first and the last stage in registers: those are the butterflies whose
-// operands / results are the thread's own elements x[j0 + u*jstep] (u < PT, jstep = M/PT) of the sequence at
-// `seq_off`, so of the lm/2 LDS round trips (write, barrier, read) two disappear.  `a`, `b`: the two LDS images
-// (contents irrelevant; nobody may still be reading `a`), `stride` between sequences.  Returns the image last
-// read (the other one is free to write), with X[j0 + u*jstep] in v[u].
-template <int TILE>
-__device__ cplx *tile_fft_regs(cplx (&v)[TILE / kFBlock], cplx *a, cplx *b, const cplx *st, int lm, int stride,
-                               int seq_off, int j0, int jstep) {
-    constexpr int PT = TILE / kFBlock, U4 = PT / 4;
-#pragma unroll
-    for (int bf = 0; bf < U4; ++bf)
-        first_stage(v[bf], v[bf + U4], v[bf + 2 * U4], v[bf + 3 * U4], a + seq_off + 4 * (j0 + bf * jstep));
-    __syncthreads();
-    const int last = (lm & 1) ? lm - 1 : lm - 2;
-    cplx *src = lds_fft_stages<TILE>(a, b, st, lm, stride, 2, last);
-    last_stage<PT>(src + seq_off, st, lm, j0, jstep, v);
     return src;
 }
 
@@ -229,6 +294,7 @@ struct ConvGeom {
     int src_ch, out_ch;
     int hist_zero;        // the overlap history is all zeros (fresh stream): its buffer is not read
     int mixed;            // one filter for every channel: any two (channel, block) items may share a transform
+    int stereo;           // mixed, two interleaved channels in and out: a transform = (left, right) of one block
 };
 
 // Twiddle tables, made once per filter next to its spectrum (pgx_convolve_fft_prepare):
@@ -269,6 +335,23 @@ __device__ __forceinline__ double conv_input(const ConvGeom &g, const float *x, 
     return (double)__uint_as_float(bits);
 }
 
+// Stereo pairs: frame (left, right) of block b as one complex sample -- one 8-byte load where the general form
+// needs two 4-byte ones from two places (and one 8-byte store on the way out).
+__device__ __forceinline__ cplx conv_input_stereo(const ConvGeom &g, const float2 *x, const float2 *hist, int64_t b,
+                                                  int64_t pos) {
+    const int64_t e = b * g.V + pos;
+    const bool in_hist = e < g.L - 1;
+    const int64_t i = e - (g.L - 1);
+    const bool from_hist = in_hist && !g.hist_zero;
+    const bool from_x = !in_hist && i < g.n;
+    const float2 hv = hist[from_hist ? e : 0];
+    const float2 xv = x[from_x ? i : 0];
+    const unsigned hm = from_hist ? 0xffffffffu : 0u, xm = from_x ? 0xffffffffu : 0u;
+    const unsigned re = (__float_as_uint(hv.x) & hm) | (__float_as_uint(xv.x) & xm);
+    const unsigned im = (__float_as_uint(hv.y) & hm) | (__float_as_uint(xv.y) & xm);
+    return cplx{(double)__uint_as_float(re), (double)__uint_as_float(im)};
+}
+
 // The two real sequences packed into transform `pair` as real and imaginary part.  The filter is real, so they
 // never mix.  With one filter for all channels the items (channel, block), numbered ch*nblocks + b, are paired as
 // they come -- a single 65 537-frame stereo block is one transform, not two half-empty ones; with a filter per
@@ -279,7 +362,11 @@ struct PairItems {
 };
 __device__ __forceinline__ PairItems pair_items(const ConvGeom &g, int64_t pair) {
     PairItems it;
-    if (g.mixed) {
+    if (g.stereo) {
+        it.ch0 = 0;
+        it.ch1 = 1;
+        it.b0 = it.b1 = pair;
+    } else if (g.mixed) {
         const int64_t q0 = 2 * pair, q1 = q0 + 1;
         it.ch0 = (int)(q0 / g.nblocks);
         it.b0 = q0 - (int64_t)it.ch0 * g.nblocks;
@@ -299,18 +386,18 @@ __device__ __forceinline__ PairItems pair_items(const ConvGeom &g, int64_t pair)
 
 // MODE 0: forward, input = packed signal blocks; MODE 1: forward, input = filter taps (spectrum
 // preparation); MODE 2: inverse, output = float32 samples.
-template <int MODE, int TILE>
+// (L1 = log2 N1, known at compile time: 6 up to N = 2^16, 7 above)
+template <int MODE, int TILE, int L1>
 __global__ void __launch_bounds__(kFBlock)
 k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist, const float *h, int fir_ch,
            float *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PT = TILE / kFBlock;                             // points per thread
-    const int N1 = (int)g.N1;
-    const int CW = TILE >> g.l1, lcw = __builtin_ctz(CW);          // columns per workgroup
-    const int stride = N1 + 1;                                     // +1: spread the columns over the banks
+    constexpr int N1 = 1 << L1;
+    constexpr int CW = TILE >> L1, lcw = __builtin_ctz(CW);        // columns per workgroup
+    constexpr int stride = N1 + 1;                                 // +1: spread the columns over the banks
     cplx *buf = reinterpret_cast<cplx *>(smem);
     cplx *alt = buf + CW * stride;
-    cplx *tw = alt + CW * stride;
     const int tid = threadIdx.x;
     const int64_t pair = blockIdx.y;
     const int64_t col0 = (int64_t)blockIdx.x * CW;
@@ -319,20 +406,31 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
     PairItems it{};
     if (MODE != 1) it = pair_items(g, pair);
     const double inv_n = 1.0 / (double)g.N;
+    PGX_FFT_STAMP(MODE, 0);
 
     // everything that comes from HBM is requested first: the inputs, then the twiddles used at the very end
     cplx v[PT];
+    if (MODE == 0 && g.stereo) {
 #pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * kFBlock;
-        const int c = e & (CW - 1), i1 = e >> lcw;
-        const int64_t pos = ((int64_t)i1 << g.l2) + col0 + c;
-        if (MODE == 0) {
-            v[u] = cplx{conv_input(g, x, hist, it.b0, it.ch0, pos), conv_input(g, x, hist, it.b1, it.ch1, pos)};
-        } else if (MODE == 1) {
-            v[u] = cplx{pos < g.L ? (double)h[pos * fir_ch + ch] : 0.0, 0.0};
-        } else {
-            v[u] = cconj(wk[pos]);                                 // inverse = conj(FFT(conj(.)))
+        for (int u = 0; u < PT; ++u) {
+            const int e = tid + u * kFBlock;
+            const int c = e & (CW - 1), i1 = e >> lcw;
+            v[u] = conv_input_stereo(g, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(hist),
+                                     it.b0, ((int64_t)i1 << g.l2) + col0 + c);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int e = tid + u * kFBlock;
+            const int c = e & (CW - 1), i1 = e >> lcw;
+            const int64_t pos = ((int64_t)i1 << g.l2) + col0 + c;
+            if (MODE == 0) {
+                v[u] = cplx{conv_input(g, x, hist, it.b0, it.ch0, pos), conv_input(g, x, hist, it.b1, it.ch1, pos)};
+            } else if (MODE == 1) {
+                v[u] = cplx{pos < g.L ? (double)h[pos * fir_ch + ch] : 0.0, 0.0};
+            } else {
+                v[u] = cconj(wk[pos]);                             // inverse = conj(FFT(conj(.)))
+            }
         }
     }
     cplx bigtw[MODE != 2 ? PT : 1];
@@ -344,10 +442,13 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
             bigtw[u] = tb.big[((int64_t)k1 << g.l2) + col0 + c];
         }
     }
-    fill_stage_twiddles<(TILE / 8 + kFBlock - 1) / kFBlock>(tw, tb.t1, g.l1);        // N1 <= TILE / 8
     // the thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT -- in the time domain and, in
     // the same registers, in the frequency domain
-    tile_fft_regs<TILE>(v, buf, alt, tw, g.l1, stride, (tid & (CW - 1)) * stride, tid >> lcw, N1 / PT);
+    StageTwiddles<TILE, L1> tw;
+    tw.load(tb.t1, tid >> lcw, N1 / PT);
+    PGX_FFT_STAMP(MODE, 1);
+    tile_fft_regs<TILE, L1>(v, buf, alt, tw, stride, (tid & (CW - 1)) * stride, tid >> lcw, N1 / PT);
+    PGX_FFT_STAMP(MODE, 2);
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
         const int e = tid + u * kFBlock;
@@ -360,12 +461,18 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
             // natural order: k1 is the row i1 of the time-domain block
             const int64_t pos = ((int64_t)k1 << g.l2) + i2;
             if (pos < g.L - 1) continue;                           // the wrapped-around part of overlap-save
+            if (g.stereo) {
+                const int64_t o = it.b0 * g.V + pos - (g.L - 1);
+                if (o < g.n) reinterpret_cast<float2 *>(out)[o] = make_float2((float)(r.x * inv_n), (float)(-r.y * inv_n));
+                continue;
+            }
             const int64_t o0 = it.b0 * g.V + pos - (g.L - 1);
             if (o0 < g.n) out[o0 * g.out_ch + it.ch0] = (float)(r.x * inv_n);
             const int64_t o1 = it.b1 * g.V + pos - (g.L - 1);
             if (it.b1 < g.nblocks && o1 < g.n) out[o1 * g.out_ch + it.ch1] = (float)(-r.y * inv_n);   // conj
         }
     }
+    PGX_FFT_STAMP(MODE, 3);
 }
 
 // FULL = false: forward row FFTs only (filter spectrum).  FULL = true: forward, times H, inverse,
@@ -378,36 +485,70 @@ k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PT = TILE / kFBlock;
     const int N2 = (int)g.N2;
+    constexpr int LT = __builtin_ctz(TILE);
     cplx *buf = reinterpret_cast<cplx *>(smem);
     cplx *alt = buf + TILE;
-    cplx *tw = alt + TILE;
     const int tid = threadIdx.x;
     const int64_t pair = blockIdx.y;
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     cplx *wk = work + pair * g.N + tile0;
     cplx v[PT], hv[FULL ? PT : 1], bigtw[FULL ? PT : 1];
+    PGX_FFT_STAMP(4, 0);
 #pragma unroll
     for (int u = 0; u < PT; ++u) v[u] = wk[tid + u * kFBlock];
     if (FULL) {
         const int ch = (int)(pair / g.npairs);
         const cplx *Hc = H + (int64_t)(fir_ch == 1 ? 0 : ch) * g.N + tile0;
 #pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            hv[u] = Hc[tid + u * kFBlock];
-            bigtw[u] = tb.big[tile0 + tid + u * kFBlock];
-        }
+        for (int u = 0; u < PT; ++u) hv[u] = Hc[tid + u * kFBlock];
     }
-    fill_stage_twiddles<TILE / kFBlock>(tw, tb.t2, g.l2);                           // N2 <= TILE
+    // the workgroup's share of the new history: requested now, stored at the very end (a copy loop after the
+    // transforms was 0.75 us of every workgroup's life: one more memory round trip)
+    constexpr int HP = 4;
+    float hval[FULL ? HP : 1];
+    unsigned hdst[FULL ? HP : 1];
+    unsigned hist_next = 0, hist_end = 0;
+    if (FULL) {
+        const unsigned oc = (unsigned)g.out_ch;
+        const unsigned total = hist_dst != nullptr ? (unsigned)(g.L - 1) * oc : 0u;
+        const unsigned groups = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned share = (total + groups - 1) / groups;
+        hist_end = (me + 1) * share < total ? (me + 1) * share : total;
+#pragma unroll
+        for (int u = 0; u < HP; ++u) {
+            const unsigned e = me * share + tid + u * kFBlock;
+            const bool mine = e < hist_end;
+            const unsigned j = e / oc, c = e - j * oc;
+            hval[u] = x[mine ? (g.n + j - (g.L - 1)) * g.src_ch + (g.src_ch == 1 ? 0 : c) : 0];
+            hdst[u] = mine ? e : ~0u;
+        }
+        hist_next = me * share + tid + HP * kFBlock;
+    }
     if (FULL && N2 == TILE) {
-        // one row per workgroup: first and last stage of both transforms in registers (tile_fft_regs)
-        cplx *read_last = tile_fft_regs<TILE>(v, buf, alt, tw, g.l2, TILE, 0, tid, kFBlock);
+        // one row per workgroup: first and last stage of both transforms in registers, and their twiddles too
+        StageTwiddles<TILE, LT> tw;
+        tw.load(tb.t2, tid, kFBlock);
+        PGX_FFT_STAMP(4, 1);
+        cplx *read_last = tile_fft_regs<TILE, LT>(v, buf, alt, tw, TILE, 0, tid, kFBlock);
+        PGX_FFT_STAMP(4, 2);
+        // (the conjugate twiddles of the way back are requested here, behind the spectrum that has just been used up:
+        // sixteen registers fewer while both are alive, and the inverse transform covers the latency)
+#pragma unroll
+        for (int u = 0; u < PT; ++u) bigtw[FULL ? u : 0] = tb.big[tile0 + tid + u * kFBlock];
 #pragma unroll
         for (int u = 0; u < PT; ++u) v[u] = cconj(cmul(v[u], hv[FULL ? u : 0]));
-        tile_fft_regs<TILE>(v, read_last == buf ? alt : buf, read_last, tw, g.l2, TILE, 0, tid, kFBlock);
+        tile_fft_regs<TILE, LT>(v, read_last == buf ? alt : buf, read_last, tw, TILE, 0, tid, kFBlock);
+        PGX_FFT_STAMP(4, 3);
         // conj() completes the inverse row transform; the conjugate twiddle undoes step (1)'s
 #pragma unroll
         for (int u = 0; u < PT; ++u) wk[tid + u * kFBlock] = cmul(cconj(v[u]), cconj(bigtw[FULL ? u : 0]));
     } else {
+        cplx *tw = alt + TILE;                                      // short rows: stage tables in LDS
+        if (FULL) {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) bigtw[FULL ? u : 0] = tb.big[tile0 + tid + u * kFBlock];
+        }
+        fill_stage_twiddles<TILE / kFBlock>(tw, tb.t2, g.l2);       // N2 <= TILE
 #pragma unroll
         for (int u = 0; u < PT; ++u) buf[tid + u * kFBlock] = v[u];
         __syncthreads();
@@ -430,18 +571,17 @@ k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *
             wk[e] = cmul(cconj(fin[e]), cconj(bigtw[FULL ? u : 0]));
         }
     }
-    if (hist_dst != nullptr) {
-        const int64_t total = (g.L - 1) * g.out_ch;
-        const int64_t groups = (int64_t)gridDim.x * gridDim.y;
-        const int64_t me = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        const int64_t share = (total + groups - 1) / groups;
-        const int64_t end = (me + 1) * share < total ? (me + 1) * share : total;
-        for (int64_t e = me * share + tid; e < end; e += kFBlock) {
-            const int64_t j = e / g.out_ch;
-            const int c = (int)(e - j * g.out_ch);
+    PGX_FFT_STAMP(4, 4);
+    if (FULL) {
+#pragma unroll
+        for (int u = 0; u < HP; ++u)
+            if (hdst[u] != ~0u) hist_dst[hdst[u]] = hval[u];
+        for (unsigned e = hist_next; e < hist_end; e += kFBlock) {      // (few workgroups, a long filter)
+            const unsigned j = e / (unsigned)g.out_ch, c = e - j * (unsigned)g.out_ch;
             hist_dst[e] = x[(g.n + j - (g.L - 1)) * g.src_ch + (g.src_ch == 1 ? 0 : c)];
         }
     }
+    PGX_FFT_STAMP(4, 5);
 }
 
 // new history = the last L-1 samples of (history | x), per output channel, for blocks shorter than L-1
@@ -480,8 +620,11 @@ bool fft_geometry(int64_t fft_size, int64_t L, ConvGeom &g) {
     return true;
 }
 
-size_t cols_smem(const ConvGeom &g, int tile) { return (2 * (tile / g.N1) * (g.N1 + 1) + g.N1) * sizeof(cplx); }
-size_t rows_smem(const ConvGeom &g, int tile) { return (2 * tile + g.N2) * sizeof(cplx); }
+size_t cols_smem(const ConvGeom &g, int tile) { return 2 * (tile / g.N1) * (g.N1 + 1) * sizeof(cplx); }
+// (rows as long as the tile keep their stage twiddles in registers; shorter ones in an LDS table of N2 entries)
+size_t rows_smem(const ConvGeom &g, int tile, bool full) {
+    return (2 * tile + (full && g.N2 == tile ? 0 : g.N2)) * sizeof(cplx);
+}
 
 // the spectrum blob: [H: fir_channels x N][big: N][t1: N1][t2: N2] complex doubles
 Tables tables_of(const cplx *spectrum, const ConvGeom &g, int fir_channels) {
@@ -498,44 +641,59 @@ int allow_lds(K kernel, size_t bytes) {
     return PGX_OK;
 }
 
-template <int TILE>
+template <int TILE, int L1>
 int launch_prepare(cplx *H, const ConvGeom &g, const float *h, int fir_channels) {
     const Tables tb = tables_of(H, g, fir_channels);
     hipLaunchKernelGGL(k_fft_tables, dim3(pgx::grid_for(g.N, kFBlock)), dim3(kFBlock), 0, pgx::stream(),
                        const_cast<cplx *>(tb.big), const_cast<cplx *>(tb.t1), const_cast<cplx *>(tb.t2), g);
     PGX_LAUNCH_CHECK("k_fft_tables");
     const dim3 grid((unsigned)(g.N / TILE), (unsigned)fir_channels);
-    if (int rc = allow_lds(k_fft_cols<1, TILE>, cols_smem(g, TILE))) return rc;
-    if (int rc = allow_lds(k_fft_rows<false, TILE>, rows_smem(g, TILE))) return rc;
-    hipLaunchKernelGGL((k_fft_cols<1, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), pgx::stream(), H, g, tb,
+    const size_t cols_lds = cols_smem(g, TILE), rows_lds = rows_smem(g, TILE, false);
+    if (int rc = allow_lds(k_fft_cols<1, TILE, L1>, cols_lds)) return rc;
+    if (int rc = allow_lds(k_fft_rows<false, TILE>, rows_lds)) return rc;
+    hipLaunchKernelGGL((k_fft_cols<1, TILE, L1>), grid, dim3(kFBlock), cols_lds, pgx::stream(), H, g, tb,
                        (const float *)nullptr, (const float *)nullptr, h, fir_channels, (float *)nullptr);
     PGX_LAUNCH_CHECK("k_fft_cols<filter>");
-    hipLaunchKernelGGL((k_fft_rows<false, TILE>), grid, dim3(kFBlock), rows_smem(g, TILE), pgx::stream(), H, g, tb,
+    hipLaunchKernelGGL((k_fft_rows<false, TILE>), grid, dim3(kFBlock), rows_lds, pgx::stream(), H, g, tb,
                        (const cplx *)nullptr, fir_channels, (float *)nullptr, (const float *)nullptr);
     PGX_LAUNCH_CHECK("k_fft_rows<filter>");
     return PGX_OK;
 }
 
-template <int TILE>
-int launch_convolve(float *out, const float *x, const cplx *H, float *hist, float *hist_in_place, cplx *work,
-                    const ConvGeom &g, int fir_channels, int64_t pairs) {
+struct ConvCall {
+    float *out;
+    const float *x;
+    const cplx *H;
+    float *hist, *hist_in_place;
+    cplx *work;
+    int fir_channels;
+    int64_t pairs;
+};
+
+template <int TILE, int L1>
+int launch_convolve(const ConvCall &c, const ConvGeom &g) {
     hipStream_t st = pgx::stream();
-    const Tables tb = tables_of(H, g, fir_channels);
-    const dim3 grid((unsigned)(g.N / TILE), (unsigned)pairs);
-    if (int rc = allow_lds(k_fft_cols<0, TILE>, cols_smem(g, TILE))) return rc;
-    if (int rc = allow_lds(k_fft_cols<2, TILE>, cols_smem(g, TILE))) return rc;
-    if (int rc = allow_lds(k_fft_rows<true, TILE>, rows_smem(g, TILE))) return rc;
-    hipLaunchKernelGGL((k_fft_cols<0, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), st, work, g, tb, x,
-                       (const float *)hist, (const float *)nullptr, fir_channels, (float *)nullptr);
+    const Tables tb = tables_of(c.H, g, c.fir_channels);
+    const dim3 grid((unsigned)(g.N / TILE), (unsigned)c.pairs);
+    const size_t cols_lds = cols_smem(g, TILE), rows_lds = rows_smem(g, TILE, true);
+    if (int rc = allow_lds(k_fft_cols<0, TILE, L1>, cols_lds)) return rc;
+    if (int rc = allow_lds(k_fft_cols<2, TILE, L1>, cols_lds)) return rc;
+    if (int rc = allow_lds(k_fft_rows<true, TILE>, rows_lds)) return rc;
+    hipLaunchKernelGGL((k_fft_cols<0, TILE, L1>), grid, dim3(kFBlock), cols_lds, st, c.work, g, tb, c.x,
+                       (const float *)c.hist, (const float *)nullptr, c.fir_channels, (float *)nullptr);
     PGX_LAUNCH_CHECK("k_fft_cols<forward>");
-    hipLaunchKernelGGL((k_fft_rows<true, TILE>), grid, dim3(kFBlock), rows_smem(g, TILE), st, work, g, tb, H,
-                       fir_channels, hist_in_place, x);
+    hipLaunchKernelGGL((k_fft_rows<true, TILE>), grid, dim3(kFBlock), rows_lds, st, c.work, g, tb, c.H,
+                       c.fir_channels, c.hist_in_place, c.x);
     PGX_LAUNCH_CHECK("k_fft_rows");
-    hipLaunchKernelGGL((k_fft_cols<2, TILE>), grid, dim3(kFBlock), cols_smem(g, TILE), st, work, g, tb,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, fir_channels, out);
+    hipLaunchKernelGGL((k_fft_cols<2, TILE, L1>), grid, dim3(kFBlock), cols_lds, st, c.work, g, tb,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, c.fir_channels, c.out);
     PGX_LAUNCH_CHECK("k_fft_cols<inverse>");
     return PGX_OK;
 }
+
+// the three geometries fft_geometry() produces: (tile, log2 N1) = (2048, 7) for 2^18, (1024, 7) for 2^17, (1024, 6) below
+#define PGX_FFT_BY_GEOMETRY(g, call)                                         \
+    (fft_tile((g).N) == 2048 ? call<2048, 7> : (g).l1 == 7 ? call<1024, 7> : call<1024, 6>)
 
 }  // namespace
 
@@ -569,9 +727,9 @@ int pgx_convolve_fft_prepare(void *spectrum, const float *h, int64_t fir_len, in
     PGX_CHECK_ARG(spectrum && h && fir_len >= 1 && fir_channels >= 1, "pgx_convolve_fft_prepare: bad argument");
     PGX_CHECK_ARG(fft_geometry(fft_size, fir_len, g), "pgx_convolve_fft_prepare: unsupported fft size");
     g.n = 0; g.nblocks = 0; g.npairs = 1; g.src_ch = 1; g.out_ch = fir_channels; g.hist_zero = 0; g.mixed = 0;
+    g.stereo = 0;
     cplx *H = (cplx *)spectrum;
-    return fft_tile(fft_size) == 2048 ? launch_prepare<2048>(H, g, h, fir_channels)
-                                      : launch_prepare<1024>(H, g, h, fir_channels);
+    return PGX_FFT_BY_GEOMETRY(g, launch_prepare)(H, g, h, fir_channels);
 }
 
 int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, const void *spectrum,
@@ -593,6 +751,8 @@ int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, co
     g.out_ch = out_channels;
     g.hist_zero = hist_is_zero ? 1 : 0;
     g.mixed = fir_channels == 1 ? 1 : 0;
+    g.stereo = g.mixed && src_channels == 2 && out_channels == 2 &&
+               (((uintptr_t)x | (uintptr_t)out | (uintptr_t)hist) & 7) == 0;
     const int64_t pairs = g.mixed ? (g.nblocks * out_channels + 1) / 2 : g.npairs * out_channels;
     PGX_CHECK_ARG(pairs <= 65535, "pgx_convolve_fft: block too long for one call");
     cplx *work = (cplx *)workspace;
@@ -601,9 +761,8 @@ int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, co
     hipStream_t st = pgx::stream();
     const bool in_place = n >= fir_len - 1;                     // then nothing of the old history survives:
     float *hip = in_place ? hist : nullptr;                     // the row pass rewrites it on the side
-    const int rc = fft_tile(fft_size) == 2048
-                       ? launch_convolve<2048>(out, x, H, hist, hip, work, g, fir_channels, pairs)
-                       : launch_convolve<1024>(out, x, H, hist, hip, work, g, fir_channels, pairs);
+    const ConvCall call{out, x, H, hist, hip, work, fir_channels, pairs};
+    const int rc = PGX_FFT_BY_GEOMETRY(g, launch_convolve)(call, g);
     if (rc != PGX_OK) return rc;
     if (!in_place) {
         const int64_t hist_elems = (fir_len - 1) * out_channels;

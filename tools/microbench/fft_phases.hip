@@ -1,115 +1,89 @@
-// Where do the cycles of the row pass of the FFT convolution go?  A copy of k_fft_rows<true, 1024> with
-// s_memtime stamps between its phases, launched in the C3 shape (128 x 2 workgroups).
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I include -I pygmu2_amd/csrc tools/microbench/fft_phases.hip -o /tmp/fft_phases
+// Where do the three launches of pgx_convolve_fft spend a call?  The library's own kernels (source included) with
+// wall_clock64() stamps (100 MHz) between their phases: C3's 96 000-frame stereo call by default.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I include -I pygmu2_amd/csrc tools/microbench/fft_phases.hip -o tools/microbench/fft_phases
+#include <hip/hip_runtime.h>
+__device__ long long g_stamps[5][4096][8];
+#define PGX_FFT_STAMP(k, i)                                                                               \
+    do {                                                                                                  \
+        if (threadIdx.x == 0) {                                                                           \
+            const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                     \
+            if (wg_ < 4096) g_stamps[(k)][wg_][(i)] = wall_clock64();                                     \
+        }                                                                                                 \
+    } while (0)
 #include "../../pygmu2_amd/csrc/pgx_fftconv.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
 
 namespace pgx {
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
-int fail(int code, const std::string &m) { g_err = m; return code; }
+int fail(int code, const std::string &m) { g_err = m; fprintf(stderr, "pgx error: %s\n", m.c_str()); return code; }
 hipStream_t stream() { return nullptr; }
 hipStream_t main_stream() { return nullptr; }
 bool initialised() { return true; }
 int device_index() { return 0; }
 }  // namespace pgx
 
-namespace {
-constexpr int kStamps = 10;
-template <int TILE>
-__global__ void __launch_bounds__(kFBlock)
-k_rows_timed(cplx *work, ConvGeom g, Tables tb, const cplx *H, long long *stamps) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PT = TILE / kFBlock;
-    const int N2 = (int)g.N2;
-    cplx *buf = reinterpret_cast<cplx *>(smem);
-    cplx *alt = buf + TILE;
-    cplx *tw = alt + TILE;
-    const int tid = threadIdx.x;
-    const int64_t pair = blockIdx.y;
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    cplx *wk = work + pair * g.N + tile0;
-    long long t[kStamps];
-    int ns = 0;
-    t[ns++] = wall_clock64();
-    cplx v[PT], hv[PT], bigtw[PT];
-#pragma unroll
-    for (int u = 0; u < PT; ++u) v[u] = wk[tid + u * kFBlock];
-    const cplx *Hc = H + tile0;
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        hv[u] = Hc[tid + u * kFBlock];
-        bigtw[u] = tb.big[tile0 + tid + u * kFBlock];
-    }
-    fill_stage_twiddles(tw, tb.t2, g.l2);
-    t[ns++] = wall_clock64();
-#pragma unroll
-    for (int u = 0; u < PT; ++u) buf[tid + u * kFBlock] = v[u];
-    __syncthreads();
-    t[ns++] = wall_clock64();
-    cplx *res = lds_fft<TILE>(buf, alt, tw, g.l2, N2);
-    t[ns++] = wall_clock64();
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * kFBlock;
-        res[e] = cconj(cmul(res[e], hv[u]));
-    }
-    __syncthreads();
-    t[ns++] = wall_clock64();
-    const cplx *fin = lds_fft<TILE>(res, res == buf ? alt : buf, tw, g.l2, N2);
-    t[ns++] = wall_clock64();
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * kFBlock;
-        wk[e] = cmul(cconj(fin[e]), cconj(bigtw[u]));
-    }
-    __threadfence();
-    t[ns++] = wall_clock64();
-    if (tid == 0)
-        for (int i = 0; i < ns; ++i) stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kStamps + i] = t[i];
-}
-}  // namespace
-
-int main() {
-    ConvGeom g{};
-    fft_geometry(131072, 65536, g);
-    g.n = 96000; g.nblocks = 2; g.npairs = 1; g.src_ch = 2; g.out_ch = 2;
-    const int pairs = 2;
-    cplx *work, *spec;
-    long long *stamps;
-    hipMalloc(&work, sizeof(cplx) * g.N * pairs);
-    hipMemset(work, 0, sizeof(cplx) * g.N * pairs);
-    const size_t spec_elems = g.N + g.N + g.N1 + g.N2;
-    hipMalloc(&spec, sizeof(cplx) * spec_elems);
-    hipMemset(spec, 0, sizeof(cplx) * spec_elems);
-    hipMalloc(&stamps, sizeof(long long) * kStamps * 256);
-    const Tables tb = tables_of(spec, g, 1);
-    hipLaunchKernelGGL(k_fft_tables, dim3(512), dim3(kFBlock), 0, 0, const_cast<cplx *>(tb.big), const_cast<cplx *>(tb.t1),
-                       const_cast<cplx *>(tb.t2), g);
-    hipDeviceSynchronize();
-    int rate = 0;
-    hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0);      // kHz
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 96000, L = 65536;
+    const int64_t nfft = argc > 2 ? atoll(argv[2]) : 131072;
+    const int reps = 6;
+    std::vector<float> hx(n * 2), hh(L);
+    for (int64_t i = 0; i < n * 2; ++i) hx[i] = 0.1f * (float)std::sin(0.37 * i);
+    for (int64_t i = 0; i < L; ++i) hh[i] = (float)(std::cos(1.3 * i) * std::exp(-i / 8000.0));
+    float *x, *h, *out, *hist;
+    void *spec, *ws;
+    const size_t sb = pgx_convolve_fft_spectrum_bytes(nfft, 1), wb = pgx_convolve_fft_workspace_bytes(n, L, 2, nfft);
+    hipMalloc(&x, hx.size() * 4);
+    hipMalloc(&h, hh.size() * 4);
+    hipMalloc(&out, hx.size() * 4);
+    hipMalloc(&hist, (L - 1) * 2 * 4);
+    hipMalloc(&spec, sb);
+    hipMalloc(&ws, wb);
+    hipMemset(hist, 0, (L - 1) * 2 * 4);
+    hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(h, hh.data(), hh.size() * 4, hipMemcpyHostToDevice);
+    if (pgx_convolve_fft_prepare(spec, h, L, 1, nfft)) return 1;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k_rows_timed<1024>), dim3(128, pairs), dim3(kFBlock), rows_smem(g, 1024), 0, work, g, tb, spec, stamps);
-        hipEventRecord(e1, 0);
-        hipDeviceSynchronize();
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < reps; ++rep) {
+        if (rep == 1) hipEventRecord(e0, nullptr);
+        if (pgx_convolve_fft(out, x, n, 2, spec, L, 1, 2, nfft, hist, ws, 0)) return 1;
     }
+    hipEventRecord(e1, nullptr);
+    hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    static long long h[kStamps * 256];
-    hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
-    const char *names[] = {"global loads + twiddle fill", "to LDS + barrier", "forward FFT (5 stages)", "x H + barrier",
-                           "inverse FFT (5 stages)", "twiddle + store"};
-    printf("kernel (events): %.2f us; wall clock %d kHz\n", ms * 1e3, rate);
-    for (int wg : {0, 1, 77, 200}) {
-        printf("workgroup %3d:", wg);
-        for (int i = 0; i + 1 < 7; ++i) printf("  %s %.2f us;", names[i], (h[wg * kStamps + i + 1] - h[wg * kStamps + i]) / (rate * 1e-3));
+    static long long st[5][4096][8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+    const int64_t V = nfft - (L - 1), nblocks = (n + V - 1) / V, pairs = (nblocks * 2 + 1) / 2;
+    const int tile = nfft >= (1 << 18) ? 2048 : 1024;
+    const int wgs = (int)std::min<int64_t>(4096, nfft / tile * pairs);
+    printf("n %lld nfft %lld: %lld transforms, %d workgroups per launch, %.2f us per call by events\n", (long long)n,
+           (long long)nfft, (long long)pairs, wgs, ms * 1000.0 / (reps - 1));
+    long long t0 = st[0][0][0];
+    for (int w = 0; w < wgs; ++w) t0 = std::min(t0, st[0][w][0]);
+    const struct { int k, last; const char *name; const char *phases[5]; } ks[3] = {
+        {0, 3, "k_fft_cols<0>", {"loads+table", "fft", "twiddle+store", "", ""}},
+        {4, 5, "k_fft_rows   ", {"loads+table", "fft", "xH+fft", "twiddle+store", "history"}},
+        {2, 3, "k_fft_cols<2>", {"loads+table", "fft", "store", "", ""}}};
+    for (const auto &k : ks) {
+        double s_min = 1e30, s_avg = 0, s_max = 0, e_max = 0, ph[5] = {0};
+        for (int w = 0; w < wgs; ++w) {
+            const long long *r = st[k.k][w];
+            const double s = (r[0] - t0) * 0.01, e = (r[k.last] - t0) * 0.01;
+            s_min = std::min(s_min, s);
+            s_max = std::max(s_max, s);
+            s_avg += s / wgs;
+            e_max = std::max(e_max, e);
+            for (int p = 0; p < k.last; ++p) ph[p] += (r[p + 1] - r[p]) * 0.01 / wgs;
+        }
+        printf(" %s: workgroups start %.2f .. %.2f (mean %.2f) us, last one ends %.2f us;", k.name, s_min, s_max, s_avg, e_max);
+        for (int p = 0; p < k.last; ++p) printf("  %s %.2f", k.phases[p], ph[p]);
         printf("\n");
     }
-    long long lo = h[0], hi = h[6];
-    for (int w = 0; w < 256; ++w) { if (h[w * kStamps] < lo) lo = h[w * kStamps]; if (h[w * kStamps + 6] > hi) hi = h[w * kStamps + 6]; }
-    printf("first start -> last end over all workgroups: %.2f us\n", (hi - lo) / (rate * 1e-3));
     return 0;
 }
