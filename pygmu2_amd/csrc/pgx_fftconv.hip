@@ -344,12 +344,11 @@ __device__ __forceinline__ cplx conv_input_stereo(const ConvGeom &g, const float
     const int64_t i = e - (g.L - 1);
     const bool from_hist = in_hist && !g.hist_zero;
     const bool from_x = !in_hist && i < g.n;
-    const float2 hv = hist[from_hist ? e : 0];
-    const float2 xv = x[from_x ? i : 0];
-    const unsigned hm = from_hist ? 0xffffffffu : 0u, xm = from_x ? 0xffffffffu : 0u;
-    const unsigned re = (__float_as_uint(hv.x) & hm) | (__float_as_uint(xv.x) & xm);
-    const unsigned im = (__float_as_uint(hv.y) & hm) | (__float_as_uint(xv.y) & xm);
-    return cplx{(double)__uint_as_float(re), (double)__uint_as_float(im)};
+    // one load from a selected address (x[0] when the sample is nobody's), masked afterwards
+    const float2 *src = from_hist ? hist + e : x + (from_x ? i : 0);
+    const float2 val = *src;
+    const unsigned m = (from_hist || from_x) ? 0xffffffffu : 0u;
+    return cplx{(double)__uint_as_float(__float_as_uint(val.x) & m), (double)__uint_as_float(__float_as_uint(val.y) & m)};
 }
 
 // The two real sequences packed into transform `pair` as real and imaginary part.  The filter is real, so they
@@ -367,18 +366,20 @@ __device__ __forceinline__ PairItems pair_items(const ConvGeom &g, int64_t pair)
         it.ch1 = 1;
         it.b0 = it.b1 = pair;
     } else if (g.mixed) {
-        const int64_t q0 = 2 * pair, q1 = q0 + 1;
-        it.ch0 = (int)(q0 / g.nblocks);
-        it.b0 = q0 - (int64_t)it.ch0 * g.nblocks;
-        it.ch1 = (int)(q1 / g.nblocks);
-        it.b1 = q1 - (int64_t)it.ch1 * g.nblocks;
+        // (items and pairs fit 32 bits -- pairs <= 65535 per call -- and 64-bit divisions are long loops)
+        const unsigned nb = (unsigned)g.nblocks, q0 = 2u * (unsigned)pair, q1 = q0 + 1u;
+        it.ch0 = (int)(q0 / nb);
+        it.b0 = q0 - (unsigned)it.ch0 * nb;
+        it.ch1 = (int)(q1 / nb);
+        it.b1 = q1 - (unsigned)it.ch1 * nb;
         if (it.ch1 >= g.out_ch) {
             it.ch1 = it.ch0;
             it.b1 = g.nblocks;
         }
     } else {
-        it.ch0 = it.ch1 = (int)(pair / g.npairs);
-        it.b0 = 2 * (pair - (int64_t)it.ch0 * g.npairs);
+        const unsigned np = (unsigned)g.npairs;
+        it.ch0 = it.ch1 = (int)((unsigned)pair / np);
+        it.b0 = 2u * ((unsigned)pair - (unsigned)it.ch0 * np);
         it.b1 = it.b0 + 1;
     }
     return it;
@@ -408,7 +409,22 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
     const double inv_n = 1.0 / (double)g.N;
     PGX_FFT_STAMP(MODE, 0);
 
-    // everything that comes from HBM is requested first: the inputs, then the twiddles used at the very end
+    // everything that comes from HBM is requested first.  The twiddles go in front of the inputs: the input loads sit
+    // in a branch (stereo / general form) whose float -> double conversions the compiler keeps there, with a wait for
+    // everything issued so far -- issued behind it, the twiddles were a second memory round trip.
+    // The thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT -- in the time domain and, in
+    // the same registers, in the frequency domain
+    StageTwiddles<TILE, L1> tw;
+    tw.load(tb.t1, tid >> lcw, N1 / PT);
+    cplx bigtw[MODE != 2 ? PT : 1];
+    if (MODE != 2) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int e = tid + u * kFBlock;
+            const int c = e & (CW - 1), k1 = e >> lcw;
+            bigtw[u] = tb.big[((int64_t)k1 << g.l2) + col0 + c];
+        }
+    }
     cplx v[PT];
     if (MODE == 0 && g.stereo) {
 #pragma unroll
@@ -433,19 +449,6 @@ k_fft_cols(cplx *work, ConvGeom g, Tables tb, const float *x, const float *hist,
             }
         }
     }
-    cplx bigtw[MODE != 2 ? PT : 1];
-    if (MODE != 2) {
-#pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            const int e = tid + u * kFBlock;
-            const int c = e & (CW - 1), k1 = e >> lcw;
-            bigtw[u] = tb.big[((int64_t)k1 << g.l2) + col0 + c];
-        }
-    }
-    // the thread's elements are column tid & (CW-1), rows (tid >> lcw) + u * N1/PT -- in the time domain and, in
-    // the same registers, in the frequency domain
-    StageTwiddles<TILE, L1> tw;
-    tw.load(tb.t1, tid >> lcw, N1 / PT);
     PGX_FFT_STAMP(MODE, 1);
     tile_fft_regs<TILE, L1>(v, buf, alt, tw, stride, (tid & (CW - 1)) * stride, tid >> lcw, N1 / PT);
     PGX_FFT_STAMP(MODE, 2);
@@ -497,8 +500,9 @@ k_fft_rows(cplx *work, ConvGeom g, Tables tb, const cplx *H, int fir_ch, float *
 #pragma unroll
     for (int u = 0; u < PT; ++u) v[u] = wk[tid + u * kFBlock];
     if (FULL) {
-        const int ch = (int)(pair / g.npairs);
-        const cplx *Hc = H + (int64_t)(fir_ch == 1 ? 0 : ch) * g.N + tile0;
+        // (32-bit: a 64-bit division is a loop of a hundred instructions in front of the first transform)
+        const unsigned ch = fir_ch == 1 ? 0u : (unsigned)blockIdx.y / (unsigned)g.npairs;
+        const cplx *Hc = H + (int64_t)ch * g.N + tile0;
 #pragma unroll
         for (int u = 0; u < PT; ++u) hv[u] = Hc[tid + u * kFBlock];
     }
