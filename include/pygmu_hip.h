@@ -399,6 +399,19 @@ int pgx_supersaw_bank_seg(float *out, int64_t out_stride, int batch, int nvoices
 size_t pgx_supersaw_bank_table_bytes(int batch, int nvoices);
 int pgx_supersaw_bank_tables(double *tables, int batch, int nvoices, double sample_rate,
                              const pgx_blitsaw_params *params);
+/* The bank with sixteen frames per thread: the per-thread part of the work (anchor sines, the voice's constants,
+ * the integrator scan) is paid half as often -- the bank is bound by instruction issue.  Scalar frequencies with
+ * 0 <= f <= sr/2 and the automatic (odd) M only: the CALLER checks that (the rotation form of the Dirichlet kernel
+ * is the only one here).  Frame phases are frac(phase0 + (i+1) * inc), not k_blitsaw's running sums: the output
+ * agrees with pgx_supersaw_bank to ~1e-9 of peak, not to the bit.  Time segments (pgx_supersaw_wide_segments) as in
+ * pgx_supersaw_bank_seg; tables from pgx_supersaw_wide_tables (their own layout); state_in != state_out. */
+size_t pgx_supersaw_wide_table_bytes(int batch, int nvoices);
+int pgx_supersaw_wide_tables(double *tables, int batch, int nvoices, double sample_rate,
+                             const pgx_blitsaw_params *params);
+int pgx_supersaw_wide_segments(int batch, int64_t n);
+int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                      const double *state_in, double *state_out, const double *amp_scalar /* [batch] */,
+                      const double *tables);
 
 /* ------------------------------------------------------------------ LadderPE
  * _ladder_process_numba (ladder_pe.py:31-203), the reference's float64 operation order.

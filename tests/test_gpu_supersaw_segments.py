@@ -1,8 +1,12 @@
 """
 GPU: a small bank of SuperSawPEs under a MixPE (a rank's share of the sharded 512-voice SuperSaw mix) rendered by the
-fused bank kernel in concurrent TIME SEGMENTS (pgx_supersaw_bank_seg: phase sums replayed, integrator levels from
-the closed form of the leaky integrator's response to the BLIT harmonics, blit_saw_pe.py:196-235) against the same
-bank rendered oscillator by oscillator (pgx_blitsaw + pgx_supersaw_sum, whose samples are the single PE's).
+fused bank kernels in concurrent TIME SEGMENTS (integrator levels from the closed form of the leaky integrator's
+response to the BLIT harmonics, blit_saw_pe.py:196-235) against the same bank rendered oscillator by oscillator
+(pgx_blitsaw + pgx_supersaw_sum, whose samples are the single PE's):
+* pgx_supersaw_bank_seg (8 frames per thread, k_blitsaw's own phase sums replayed): the same float32 samples up to a
+  rounding flip in ~1e-7 of them;
+* pgx_supersaw_wide (16 frames per thread, phases frac(phase0 + (i+1) inc), voices not rounded to float32 before the
+  sum): <= 1e-6 of the peak (measured ~1e-7: one or two float32 ulps).
 """
 
 import numpy as np
@@ -16,12 +20,13 @@ def _mix(pg, count, voices=7, base=55.0, channels=1):
                                     channels=channels) for i in range(count)])
 
 
-def _run(segmented, count, blocks, **kw):
+def _run(segmented, count, blocks, wide=False, **kw):
     import pygmu2_amd as pg
     from pygmu2_amd import voice_bank
     pg.set_sample_rate(48000)
-    keep = voice_bank.SEGMENTED_SUPERSAW, voice_bank.PREFETCH_SUPERSAW_VOICES
+    keep = voice_bank.SEGMENTED_SUPERSAW, voice_bank.PREFETCH_SUPERSAW_VOICES, voice_bank.WIDE_SUPERSAW
     voice_bank.SEGMENTED_SUPERSAW = segmented
+    voice_bank.WIDE_SUPERSAW = wide
     voice_bank.PREFETCH_SUPERSAW_VOICES = False        # (the pipelined path keeps its states one block ahead)
     try:
         mix = _mix(pg, count, **kw)
@@ -29,27 +34,59 @@ def _run(segmented, count, blocks, **kw):
         r.set_source(mix)
         r.start()
         bank = mix._voice_bank()
-        assert bank and bank.root.segmented(blocks[0][1]) == segmented
+        assert bank and bank.root.segmented(blocks[0][1]) == segmented and bank.root.wide() == wide
         outs = [mix.render(s, n).data.copy() for s, n in blocks]
         state = bank.root.state.to_host().copy()
         r.stop()
         return outs, state
     finally:
-        voice_bank.SEGMENTED_SUPERSAW, voice_bank.PREFETCH_SUPERSAW_VOICES = keep
+        voice_bank.SEGMENTED_SUPERSAW, voice_bank.PREFETCH_SUPERSAW_VOICES, voice_bank.WIDE_SUPERSAW = keep
 
 
-@pytest.mark.parametrize("count,kw", [(64, {}), (16, dict(voices=3)), (100, dict(voices=5, base=110.0, channels=2))])
-def test_time_segments_render_the_sequential_bank(count, kw):
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("count,kw", [(64, {}), (16, dict(voices=3)), (100, dict(voices=5, base=27.5, channels=2))])
+def test_time_segments_render_the_sequential_bank(count, kw, wide):
     blocks = [(0, 48_000), (48_000, 48_000), (96_000, 30_001), (500_000, 48_000)]       # a stream, then a seek (reset)
-    got, st_got = _run(True, count, blocks, **kw)
+    got, st_got = _run(True, count, blocks, wide=wide, **kw)
     want, st_want = _run(False, count, blocks, **kw)
     for g, w in zip(got, want):
         peak = float(np.max(np.abs(w)))
         err = float(np.max(np.abs(g.astype(np.float64) - w)))
         assert err <= 1e-6 * peak, (err, peak)
-        assert np.mean(g != w) < 2e-3
-    # phases are the same additions; integrator levels agree to the closed form's ~1e-14
-    assert np.allclose(st_got, st_want, rtol=0, atol=1e-11)
+        if not wide:
+            assert np.mean(g != w) < 2e-3
+    # 8 frames per thread: phases are the same additions, integrator levels agree to the closed form's ~1e-14;
+    # 16 frames per thread: phases are products, not running sums (~1e-10 apart after 1e5 frames)
+    assert np.allclose(st_got, st_want, rtol=0, atol=1e-9 if wide else 1e-11)
+
+
+def test_full_bank_of_512_in_the_wide_form():
+    """512 instances (one time segment each): pgx_supersaw_wide against pgx_supersaw_bank, whose samples are the
+    per-voice ones bit for bit (test_gpu_voice_bank)."""
+    import pygmu2_amd as pg
+    from pygmu2_amd import voice_bank
+    pg.set_sample_rate(48000)
+    blocks = [(0, 48_000), (48_000, 20_000), (68_000, 4097)]
+
+    def run(wide):
+        keep = voice_bank.WIDE_SUPERSAW
+        voice_bank.WIDE_SUPERSAW = wide
+        try:
+            mix = pg.MixPE(*[pg.SuperSawPE(frequency=55.0 * 2 ** (i / 96.0), voices=7, detune_cents=20.0, seed=i)
+                             for i in range(512)])
+            r = pg.NullRenderer(sample_rate=48000)
+            r.set_source(mix)
+            r.start()
+            assert mix._voice_bank().root.wide() == wide
+            outs = [mix.render(s, n).data.copy() for s, n in blocks]
+            r.stop()
+            return outs
+        finally:
+            voice_bank.WIDE_SUPERSAW = keep
+
+    for g, w in zip(run(True), run(False)):
+        peak = float(np.max(np.abs(w)))
+        assert float(np.max(np.abs(g.astype(np.float64) - w))) <= 1e-6 * peak
 
 
 def test_segment_plan_and_fallbacks():
@@ -59,6 +96,9 @@ def test_segment_plan_and_fallbacks():
     assert lib.pgx_supersaw_bank_segments(64, 48_000) == 4          # 12 tiles of 4096 frames, 3 per segment
     assert lib.pgx_supersaw_bank_segments(512, 48_000) == 1
     assert lib.pgx_supersaw_bank_segments(64, 4096) == 1
+    assert lib.pgx_supersaw_wide_segments(64, 48_000) == 4          # 12 tiles of 4096 frames too (4 waves x 16)
+    assert lib.pgx_supersaw_wide_segments(512, 48_000) == 1
+    assert lib.pgx_supersaw_wide_segments(128, 48_000) == 4          # two workgroups per CU beat one with six tiles
     pg.set_sample_rate(48000)
     # an explicit leak of 1.0 has no steady state: the bank keeps the oscillator-by-oscillator path
     mix = pg.MixPE(*[pg.SuperSawPE(frequency=110.0 + i, voices=3, seed=i) for i in range(8)])

@@ -192,7 +192,8 @@ def test_supersaw_bank_summed_on_chip_is_the_two_launch_path_bit_for_bit(voices,
     carried state (a second and a third block, a gap that resets, an unaligned tail)."""
     from pygmu2_amd import voice_bank
     pg.set_sample_rate(48000)
-    n_inst = 258 if voices == 7 else 256
+    monkeypatch.setattr(voice_bank, "WIDE_SUPERSAW", False)           # the 8-frames-per-thread bank: k_blitsaw's bits
+    n_inst = 258 if voices == 7 else 256                              # (pgx_supersaw_wide: test_gpu_supersaw_segments.py)
 
     def make():
         return pg.MixPE(*[pg.SuperSawPE(55.0 * 2 ** (i / 24.0), amplitude=0.5 + 0.001 * i, voices=voices,

@@ -52,6 +52,18 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_supersaw_tables, dim3(batch), dim3(256), 0, 0, dt, nv, 48000.0, dp);
     const int64_t tiles = (n + 4095) / 4096;
     const int seg_tiles = (int)((tiles + nseg - 1) / nseg);
+    const bool wide = argc > 4 && atoi(argv[4]) != 0;        // 4th argument 1: k_supersaw_wide (16 frames per thread)
+    int seg_tiles_w = 0;
+    if (wide) {
+        double *dtw;
+        hipMalloc(&dtw, (size_t)batch * nv * kSswTabDoubles * 8);
+        hipLaunchKernelGGL(k_supersaw_wide_tables, dim3(batch), dim3(64), 0, 0, dtw, nv, 48000.0, dp);
+        const int64_t tiles_w = (n + 4095) / 4096;
+        seg_tiles_w = (int)((tiles_w + nseg - 1) / nseg);
+        for (int rep = 0; rep < 3; ++rep)
+            hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(256), 0, 0, out, n, nv, n, 1,
+                               (const double *)ds, ds2, (const double *)da, seg_tiles_w, (const double *)dtw);
+    } else
     for (int rep = 0; rep < 3; ++rep)
         hipLaunchKernelGGL(k_supersaw_bank<8>, dim3(batch, nseg), dim3(512), 0, 0, out, n, nv, n, 1, 48000.0, dp,
                            (const double *)ds, ds2, (const double *)da, seg_tiles, (const double *)dt);
