@@ -408,7 +408,7 @@ int pgx_supersaw_bank_tables(double *tables, int batch, int nvoices, double samp
 size_t pgx_supersaw_wide_table_bytes(int batch, int nvoices);
 int pgx_supersaw_wide_tables(double *tables, int batch, int nvoices, double sample_rate,
                              const pgx_blitsaw_params *params);
-int pgx_supersaw_wide_segments(int batch, int64_t n);
+int pgx_supersaw_wide_segments(int batch, int nvoices, int64_t n);
 int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, int64_t n, int channels,
                       const double *state_in, double *state_out, const double *amp_scalar /* [batch] */,
                       const double *tables);

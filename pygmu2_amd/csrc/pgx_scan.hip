@@ -3602,9 +3602,12 @@ int pgx_supersaw_wide_tables(double *tables, int batch, int nvoices, double samp
 // How many time segments: the count with the smallest estimated makespan.  Measured on MI355X (tools/ssw_probe.py,
 // tools/microbench/ss_phases.hip): a 4096-frame tile of 7 voices takes a workgroup 9.8 us when it has its CU to
 // itself (one wave per SIMD), 15.4 us for two workgroups sharing a CU (x1.57), ~x2.25 for three, x0.75 per
-// workgroup beyond; entering a later segment costs ~0.6 of a tile (tables + closed-form carries), the first 0.1.
-int pgx_supersaw_wide_segments(int batch, int64_t n) {
-    if (batch <= 0 || n <= 0) return 1;
+// workgroup beyond; entering a later segment costs the tables (0.9 us) and the closed-form carries (1.9 us per round
+// of four voices) against 1.4 us per voice and tile -- 0.5 of a tile for 7 voices, 2 tiles for a lone oscillator;
+// taken a quarter higher (a plan with more segments has to win clearly).
+int pgx_supersaw_wide_segments(int batch, int nvoices, int64_t n) {
+    if (batch <= 0 || n <= 0 || nvoices <= 0) return 1;
+    const double entry = 1.25 * (0.9 + 1.9 * (double)((nvoices + 3) / 4)) / (1.4 * (double)nvoices);
     constexpr int64_t tile = 4 * 64 * kSswT;
     const int64_t tiles = pgx::ceil_div(n, tile);
     static const int forced = getenv("PGX_SSW_SEGS") ? atoi(getenv("PGX_SSW_SEGS")) : 0;      // experiments
@@ -3616,8 +3619,8 @@ int pgx_supersaw_wide_segments(int batch, int64_t n) {
         if (nseg != k) continue;                                // (the same plan as a smaller k)
         const int64_t per_cu = pgx::ceil_div((int64_t)batch * nseg, pgx::kNumCU);
         const double share = per_cu <= 1 ? 1.0 : per_cu == 2 ? 1.57 : per_cu == 3 ? 2.25 : 0.75 * (double)per_cu;
-        const double cost = ((double)seg_tiles + (nseg > 1 ? 0.6 : 0.1)) * share;
-        if (k == 1 || cost < best_cost - 1e-9) {
+        const double cost = ((double)seg_tiles + (nseg > 1 ? entry : 0.1)) * share;
+        if (k == 1 || cost < 0.97 * best_cost) {                // (more segments have to win clearly)
             best = k;
             best_cost = cost;
         }
@@ -3637,7 +3640,7 @@ int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, in
     PGX_CHECK_ARG(batch <= 65535, "pgx_supersaw_wide: too many instances");
     constexpr int64_t tile = 4 * 64 * kSswT;
     const int64_t tiles = pgx::ceil_div(n, tile);
-    const int nseg = pgx_supersaw_wide_segments(batch, n);
+    const int nseg = pgx_supersaw_wide_segments(batch, nvoices, n);
     const int seg_tiles = (int)pgx::ceil_div(tiles, nseg);
     hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(4 * 64), 0, pgx::stream(), out, out_stride, nvoices,
                        n, channels, state_in, state_out, amp_scalar, seg_tiles, tables);

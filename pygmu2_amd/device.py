@@ -121,7 +121,7 @@ _SIGNATURES = [
     ("pgx_supersaw_bank_tables", _I, [_P, _I, _I, _D, _P]),
     ("pgx_supersaw_wide_table_bytes", _Z, [_I, _I]),
     ("pgx_supersaw_wide_tables", _I, [_P, _I, _I, _D, _P]),
-    ("pgx_supersaw_wide_segments", _I, [_I, _L]),
+    ("pgx_supersaw_wide_segments", _I, [_I, _I, _L]),
     ("pgx_supersaw_wide", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _P]),
     ("pgx_ladder", _I, [_P, _L, _P, _L, _I, _L, _I, _D, _P, _P, _P, _P, _P, _L, _L, _P]),
     ("pgx_ladder_workspace_bytes", _Z, [_I, _L, _I, _L]),

@@ -106,8 +106,9 @@ class _BlitSawNode(_Node):
         # (_SuperSawNode.segmented); needs the automatic (odd) M and a leak below 1 for the closed-form carries
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
+        self.wide_ok = self.closed_form_ok and bool(np.all(rec["freq"] <= 0.5 * self.sr))   # (_SuperSawNode.wide)
         self.state_alt = None
-        self.tables = None
+        self.tables = {}
         self.unit_amp = None
 
     def reset(self):
@@ -121,25 +122,38 @@ class _BlitSawNode(_Node):
         if self.last_end is None or start != self.last_end:
             self.state.upload(self.init_state)
 
+    def wide(self) -> bool:
+        return WIDE_SUPERSAW and self.wide_ok
+
     def segmented(self, n: int) -> bool:
-        return (SEGMENTED_SUPERSAW and self.closed_form_ok and 4 <= self.k < FUSED_SUPERSAW_MIN
-                and lib().pgx_supersaw_bank_segments(self.k, n) > 1)
+        L = lib()
+        segments = (L.pgx_supersaw_wide_segments(self.k, 1, n) if self.wide()
+                    else L.pgx_supersaw_bank_segments(self.k, n))
+        return SEGMENTED_SUPERSAW and self.closed_form_ok and 4 <= self.k < FUSED_SUPERSAW_MIN and segments > 1
 
     def _render_segments(self, start, n):
-        """pgx_supersaw_bank_seg with one voice per instance and unit instance amplitude: float32(float64(float32(
-        y * 2 amp)) * 1.0) is the oscillator's own sample."""
+        """The SuperSaw bank kernels with one voice per instance and unit instance amplitude: float32(y * 2 amp * 1.0)
+        is the oscillator's own sample (pgx_supersaw_wide; pgx_supersaw_bank_seg rounds to float32 twice, the same)."""
         L = lib()
         self.prepare(start)
         if self.state_alt is None:
             self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
             self.unit_amp = DeviceBuffer.from_host(np.ones(self.k, dtype=np.float64))
-            self.tables = DeviceBuffer((L.pgx_supersaw_bank_table_bytes(self.k, 1),), np.uint8)
-            check(L.pgx_supersaw_bank_tables(self.tables.ptr, self.k, 1, self.sr, self.params.ptr),
-                  "pgx_supersaw_bank_tables")
+        kind = "wide" if self.wide() else "bank"
+        tables = self.tables.get(kind)
+        if tables is None:
+            size, make = ((L.pgx_supersaw_wide_table_bytes, L.pgx_supersaw_wide_tables) if kind == "wide"
+                          else (L.pgx_supersaw_bank_table_bytes, L.pgx_supersaw_bank_tables))
+            tables = self.tables[kind] = DeviceBuffer((size(self.k, 1),), np.uint8)
+            check(make(tables.ptr, self.k, 1, self.sr, self.params.ptr), f"pgx_supersaw_{kind}_tables")
         out = DeviceBuffer((self.k, n, self.ch), np.float32)
-        check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, 1, n, self.ch, self.sr, self.params.ptr,
-                                      self.state.ptr, self.state_alt.ptr, self.unit_amp.ptr, self.tables.ptr),
-              "pgx_supersaw_bank_seg")
+        if kind == "wide":
+            check(L.pgx_supersaw_wide(out.ptr, n * self.ch, self.k, 1, n, self.ch, self.state.ptr,
+                                      self.state_alt.ptr, self.unit_amp.ptr, tables.ptr), "pgx_supersaw_wide")
+        else:
+            check(L.pgx_supersaw_bank_seg(out.ptr, n * self.ch, self.k, 1, n, self.ch, self.sr, self.params.ptr,
+                                          self.state.ptr, self.state_alt.ptr, self.unit_amp.ptr, tables.ptr),
+                  "pgx_supersaw_bank_seg")
         self.state, self.state_alt = self.state_alt, self.state
         self.last_end = start + n
         return out
@@ -193,9 +207,10 @@ class _SuperSawNode(_Node):
         segments (pgx_supersaw_wide / pgx_supersaw_bank_seg), carries from the integrator's closed form -- automatic
         (odd) M, leak < 1."""
         L = lib()
-        segments = L.pgx_supersaw_wide_segments if self.wide() else L.pgx_supersaw_bank_segments
+        segments = (L.pgx_supersaw_wide_segments(self.k, self.nv, n) if self.wide()
+                    else L.pgx_supersaw_bank_segments(self.k, n))
         return (SEGMENTED_SUPERSAW and not self.fused() and self.nv <= 16 and self.closed_form_ok
-                and segments(self.k, n) > 1)
+                and segments > 1)
 
     def _forget_ahead(self, restore: bool) -> None:
         ahead, self.ahead = self.ahead, None

@@ -96,9 +96,9 @@ def test_segment_plan_and_fallbacks():
     assert lib.pgx_supersaw_bank_segments(64, 48_000) == 4          # 12 tiles of 4096 frames, 3 per segment
     assert lib.pgx_supersaw_bank_segments(512, 48_000) == 1
     assert lib.pgx_supersaw_bank_segments(64, 4096) == 1
-    assert lib.pgx_supersaw_wide_segments(64, 48_000) == 4          # 12 tiles of 4096 frames too (4 waves x 16)
-    assert lib.pgx_supersaw_wide_segments(512, 48_000) == 1
-    assert lib.pgx_supersaw_wide_segments(128, 48_000) == 4          # two workgroups per CU beat one with six tiles
+    assert lib.pgx_supersaw_wide_segments(64, 7, 48_000) == 4          # 12 tiles of 4096 frames too (4 waves x 16)
+    assert lib.pgx_supersaw_wide_segments(512, 7, 48_000) == 1
+    assert lib.pgx_supersaw_wide_segments(128, 7, 48_000) == 4          # two workgroups per CU beat one with six tiles
     pg.set_sample_rate(48000)
     # an explicit leak of 1.0 has no steady state: the bank keeps the oscillator-by-oscillator path
     mix = pg.MixPE(*[pg.SuperSawPE(frequency=110.0 + i, voices=3, seed=i) for i in range(8)])

@@ -36,7 +36,7 @@ for b, n in enumerate(blocks):
     sdiff = float(np.max(np.abs(ref_state.to_host() - st[0].to_host())))
     worst = max(worst, err / peak)
     print(f"block {b} n {n}: max|d| {err:.3e} of peak {peak:.3f} ({err / peak:.2e}), state difference {sdiff:.2e}, "
-          f"segments {lib.pgx_supersaw_wide_segments(batch, n)}", flush=True)
+          f"segments {lib.pgx_supersaw_wide_segments(batch, nv, n)}", flush=True)
 print(f"worst relative difference {worst:.2e}")
 for n in (48000, 49152, 24576, 98304):
     out = device.DeviceBuffer((batch, n, 1), np.float32)
@@ -47,4 +47,4 @@ for n in (48000, 49152, 24576, 98304):
         device.check(lib.pgx_supersaw_wide(out.ptr, n, batch, nv, n, 1, st[0].ptr, st[1].ptr, amp.ptr, tab.ptr))
     t_old, t_new = bench.event_avg_ms(old, 20) * 1e3, bench.event_avg_ms(new, 20) * 1e3
     print(f"batch {batch} n {n:6d}: bank_seg {t_old:7.2f} us ({lib.pgx_supersaw_bank_segments(batch, n)} segments), "
-          f"wide {t_new:7.2f} us ({lib.pgx_supersaw_wide_segments(batch, n)} segments)", flush=True)
+          f"wide {t_new:7.2f} us ({lib.pgx_supersaw_wide_segments(batch, nv, n)} segments)", flush=True)
