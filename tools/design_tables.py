@@ -98,7 +98,7 @@ sub_row("| **C5** 512-voice mix, 48 000-frame blocks (`voice_mix`) |",
 sub_row("| **SuperSaw mix** 512 × SuperSawPE(7) → MixPE (`supersaw_mix`, north_star's scaling case) |",
         "| **SuperSaw mix** 512 × SuperSawPE(7) → MixPE (`supersaw_mix`, north_star's scaling case) | 1.105 ms = 43.4 | "
         f"**{sm['ms_per_block']:.3f} ms = {sm['value']:.1f} Msamples/s** = {n(round(sm['oscillator_msamples_s'], -2))} "
-        f"oscillator-Msamples/s | {sm['cpu_baseline']['value']:.5f} ({n(round(sm['over_cpu'], -2))}×) | `k_supersaw_bank` "
+        f"oscillator-Msamples/s | {sm['cpu_baseline']['value']:.5f} ({n(round(sm['over_cpu'], -2))}×) | `k_supersaw_wide` "
         "330 µs (round 1: 880 + 154): voices summed on chip, branch-free sines, rotations, per-voice constants and "
         "per-thread prefix / lane-power tables in LDS, DPP scans, inner tiles without bounds selects, carries on fused "
         "multiply-adds, no per-sample singularity select (§4); ≈46 VALU instructions per sample (75 when the round's "

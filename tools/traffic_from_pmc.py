@@ -114,7 +114,7 @@ for (k, g), v in sorted(f.items()):
     md.append(f"| `{k}` | {g} | {v:,.1f} | {w.get((k, g), 0.0):,.1f} |")
 # (k_mix_batch runs at two sizes in the probe -- 512 inputs for the SuperSaw mix, 64 for C4 -- its largest launch is the 512-input one)
 mix512 = max(v for (n_, k, g), v in MAXES.items() if n_ == "mixes_FETCH_SIZE" and k.startswith("k_mix_batch"))
-ss = (kib(w, "k_supersaw_bank<4>", 131072) + 2 * mix512) * 1024
+ss = (kib(w, "k_supersaw_wide<4>", 131072) + 2 * mix512) * 1024
 c5 = (kib(w, "k_blitsaw_biquad", 131072) + kib(w, "k_adsr_walk<false, 1>", 32768) + 2 * kib(f, "k_gain_mix_batch", 48128)) * 1024
 md += ["", f"SuperSaw mix (512 x 7 oscillators): the `[512][48000]` float32 layer under the MixPE is written once and read once "
        f"(x2 on the wide reads of `k_mix_batch`; the 512-input launch is the table's maximum, its mean blends in C4's 64-input mix): about **{ss / 1e6:.0f} MB** per block against "
