@@ -682,13 +682,16 @@ struct SbSine {
 #ifndef PGX_SB_SINE_WAVES
 #define PGX_SB_SINE_WAVES 3        // waves per SIMD the sine-source variant is compiled for: 166 VGPRs, no spill (4: 128 + 28 B of scratch per lane, 6 MB of extra HBM traffic per 33 M frames and 5 % slower)
 #endif
-template <bool MONO, bool STAGED, bool SINE = false>
-__global__ void __launch_bounds__(kSbBlock, MONO ? (SINE ? PGX_SB_SINE_WAVES : 4) : 2)
+// BLOCK: threads per workgroup -- 512 (a tile = two halves), or 256 for the sine-source variant (a tile = one half: at its
+// 166 VGPRs a CU holds one 8-wave workgroup, whose single barrier per tile then idles the whole CU, or three 4-wave ones)
+template <bool MONO, bool STAGED, bool SINE = false, int BLOCK = kSbBlock>
+__global__ void __launch_bounds__(BLOCK, MONO ? (SINE ? PGX_SB_SINE_WAVES : 4) : 2)
 k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__restrict__ in, int64_t in_stride,
                  int64_t n, int channels_arg, const double *__restrict__ coef, const double *__restrict__ tables,
                  double *state, int seg, int head, int tail, int warm, int groups, SbSine sine = SbSine{}) {
+    constexpr int kTileHalves = BLOCK * kBqT / kSbHalf;         // halves a tile covers: 2, or 1
     __shared__ SbShared sh;
-    __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? kSbWaves * kStageWords : 4];
+    __shared__ __attribute__((aligned(16))) float stage_lds[STAGED ? (BLOCK / 64) * kStageWords : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int channels = MONO ? 1 : channels_arg;
     const int chain = blockIdx.y;
@@ -801,7 +804,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
         const int64_t emit_from = hb * kSbHalf;
 
 #pragma nounroll
-        for (; h < he; h += 2) {
+        for (; h < he; h += kTileHalves) {
             const int64_t f0 = h * kSbHalf + (int64_t)tid * kBqT;
             float xf[kBqT];
             if (SINE) {
@@ -812,7 +815,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
 #pragma unroll
                 for (int j = 0; j < kBqT; ++j) xf[j] = xn[j];
                 if (STAGED && xn_staged) stage_to_chunks(wlds, lane, xf);
-                if (h + 2 < he) request(h + 2);                // next tile's frames, in flight during this one
+                if (h + kTileHalves < he) request(h + kTileHalves);                // next tile's frames, in flight during this one
             }
             // zero-state response of the 16-frame chunk
             V2 e{0.0, 0.0};
@@ -844,7 +847,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             __syncthreads();
             V2 cw = carry, run = carry;
 #pragma unroll
-            for (int w = 0; w < kSbWaves; ++w) {
+            for (int w = 0; w < BLOCK / 64; ++w) {
                 run = mv_add_fma(pwave, run, tot[w]);
                 if (w + 1 == wave) cw = run;                   // wave-uniform pick of this wave's carry-in
             }
@@ -910,14 +913,15 @@ struct BqSettledPlan {
     int seg, head, tail, warm, groups;        // in 4096-frame halves
 };
 
-BqSettledPlan biquad_settled_plan(int batch, int64_t n, int channels, int64_t settle_frames, bool have_tables) {
+BqSettledPlan biquad_settled_plan(int batch, int64_t n, int channels, int64_t settle_frames, bool have_tables,
+                                  int workgroups = 512) {
     BqSettledPlan p{};
     if (!have_tables) return p;
     const int64_t halves = pgx::ceil_div(n, kSbHalf);
     const int64_t chains = (int64_t)batch * channels;
     const int64_t warm = pgx::ceil_div(settle_frames, kSbHalf);
     if (settle_frames > 0 && warm <= kSbMaxWarm) {
-        int64_t want = 512 / chains;                           // two resident workgroups per CU, one round
+        int64_t want = workgroups / chains;                    // 512: two resident workgroups per CU, one round
         if (want < 1) want = 1;
         int64_t seg = pgx::ceil_div(halves, want);
         if (seg < warm) seg = warm;                            // warm-up never exceeds the rendered part
@@ -3365,8 +3369,19 @@ int pgx_biquad_const(float *out, int64_t out_stride, const float *in, int64_t in
     return PGX_OK;
 }
 
+// The sine-source variant: 4-wave workgroups, three per CU (PGX_SB_SINE_BLOCK=512: the 8-wave form, one per CU --
+// experiments)
+static int sine_block() {
+    static const int block = getenv("PGX_SB_SINE_BLOCK") ? atoi(getenv("PGX_SB_SINE_BLOCK")) : 256;
+    return block == 512 ? 512 : 256;
+}
+static BqSettledPlan biquad_sine_plan(int64_t n, int64_t settle_frames) {
+    static const int want = getenv("PGX_SB_SINE_WGS") ? atoi(getenv("PGX_SB_SINE_WGS")) : (sine_block() == 256 ? 1024 : 512);
+    return biquad_settled_plan(1, n, 1, settle_frames, true, want);
+}
+
 int pgx_biquad_sine_supported(int64_t n, int64_t settle_frames) {
-    return (n > 0 && biquad_settled_plan(1, n, 1, settle_frames, true).ok) ? 1 : 0;
+    return (n > 0 && biquad_sine_plan(n, settle_frames).ok) ? 1 : 0;
 }
 
 int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, double w, double amp, double phase0,
@@ -3375,7 +3390,8 @@ int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, do
     PGX_REQUIRE_INIT();
     if (n <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && coef && tables && state && sample_rate > 0, "pgx_biquad_sine: bad argument");
-    const BqSettledPlan sp = biquad_settled_plan(1, n, 1, settle_frames, true);
+    const int block = sine_block();
+    const BqSettledPlan sp = biquad_sine_plan(n, settle_frames);
     PGX_CHECK_ARG(sp.ok, "pgx_biquad_sine: block too short for the single-launch plan (pgx_biquad_sine_supported)");
     // the largest phase of the render has to stay in the bounded sine's range
     const double far = fabs(phase0) + fabs(w) * ((double)(llabs(start) + n) / sample_rate);
@@ -3393,9 +3409,14 @@ int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, do
     sine.start = start;
     sine.state_backup = state_backup;
     const dim3 grid(sp.groups == 1 ? 1 : (sp.groups + 7) / 8 * 8, 1);
-    hipLaunchKernelGGL((k_biquad_settled<true, true, true>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
-                       (int64_t)0, (const float *)nullptr, (int64_t)0, n, 1, coef, tables, state, sp.seg, sp.head,
-                       sp.tail, sp.warm, sp.groups, sine);
+    if (block == 256)
+        hipLaunchKernelGGL((k_biquad_settled<true, true, true, 256>), grid, dim3(256), 0, pgx::stream(), out,
+                           (int64_t)0, (const float *)nullptr, (int64_t)0, n, 1, coef, tables, state, sp.seg, sp.head,
+                           sp.tail, sp.warm, sp.groups, sine);
+    else
+        hipLaunchKernelGGL((k_biquad_settled<true, true, true>), grid, dim3(kSbBlock), 0, pgx::stream(), out,
+                           (int64_t)0, (const float *)nullptr, (int64_t)0, n, 1, coef, tables, state, sp.seg, sp.head,
+                           sp.tail, sp.warm, sp.groups, sine);
     PGX_LAUNCH_CHECK("k_biquad_settled<sine>");
     return PGX_OK;
 }
