@@ -374,6 +374,16 @@ int pgx_blitsaw_biquad_bank(float *out, int64_t out_stride, int batch, int64_t n
                             const pgx_blitsaw_params *params, double *saw_state /* [batch][2] */,
                             const double *coef, double *biquad_state /* [batch][2] */);
 
+/* The same chain with sixteen frames per thread: pgx_supersaw_wide's oscillator (under its conditions, which the
+ * CALLER checks; saw_tables from pgx_supersaw_wide_tables with one voice per instance) and
+ * the settled biquad's filter section on the tables of pgx_biquad_tables.  Agrees with pgx_blitsaw_biquad_bank to a
+ * float32 ulp or two (<= 1e-6 of peak asserted), not to the bit. */
+int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n,
+                            const double *saw_tables /* [batch] pgx_supersaw_wide_tables(nvoices = 1) */,
+                            double *saw_state /* [batch][2] */, const double *coef /* [batch][5] */,
+                            const double *biquad_tables /* [batch] pgx_biquad_tables */,
+                            double *biquad_state /* [batch][2] */);
+
 /* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
  * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the
  * [batch*nvoices][frames] intermediate (one workgroup per instance, one wave per oscillator; nvoices <= 16).
@@ -400,9 +410,9 @@ size_t pgx_supersaw_bank_table_bytes(int batch, int nvoices);
 int pgx_supersaw_bank_tables(double *tables, int batch, int nvoices, double sample_rate,
                              const pgx_blitsaw_params *params);
 /* The bank with sixteen frames per thread: the per-thread part of the work (anchor sines, the voice's constants,
- * the integrator scan) is paid half as often -- the bank is bound by instruction issue.  Scalar frequencies with
- * 0 <= f <= sr/2 and the automatic (odd) M only: the CALLER checks that (the rotation form of the Dirichlet kernel
- * is the only one here).  Frame phases are frac(phase0 + (i+1) * inc), not k_blitsaw's running sums: the output
+ * the integrator scan) is paid half as often -- the bank is bound by instruction issue.  Scalar frequencies >= 1 Hz
+ * with the automatic (odd) M and |sin(M pi f/sr)| >= 0.05 only (always true below Nyquist): the CALLER checks that
+ * (the rotation / recurrence form of the Dirichlet kernel is the only one here).  Frame phases are frac(phase0 + (i+1) * inc), not k_blitsaw's running sums: the output
  * agrees with pgx_supersaw_bank to ~1e-9 of peak, not to the bit.  Time segments (pgx_supersaw_wide_segments) as in
  * pgx_supersaw_bank_seg; tables from pgx_supersaw_wide_tables (their own layout); state_in != state_out. */
 size_t pgx_supersaw_wide_table_bytes(int batch, int nvoices);

@@ -34,7 +34,7 @@ constexpr double kTwo52 = 4503599627370496.0;        // 2^52
 constexpr double kTwo53 = 9007199254740992.0;        // 2^53
 constexpr int kGroupChunks = 8;                       // fast path granularity: 8 x 64 samples
 constexpr int kParWaves = 8;                          // k_adsr_walk_par: stretches of a block walked at once
-constexpr int kParWalkBatch = 256;                    // up to here the stretches of a block are walked at once (k_adsr_walk_par)
+constexpr int kParWalkBatch = 512;                    // up to here the stretches of a block are walked at once (k_adsr_walk_par)
 constexpr int kWideWalkBatch = 128;                   // up to here an envelope gets a whole workgroup (see k_adsr_walk)
 
 // ------------------------------------------------------------------------------------------------
@@ -920,8 +920,10 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
         if (rc != PGX_OK) return rc;
     }
     static const bool par_on = !(getenv("PGX_ADSR_PAR") && atoi(getenv("PGX_ADSR_PAR")) == 0);
-    // (a bank that fills the chip with one wave per envelope gains nothing from eight: 512 envelopes 0.177 -> 0.186 ms
-    // per C5 block; 256 envelopes -- a rank's share at two ranks -- 146 -> 122 us; a rank's 64: walk 100 -> 60 us)
+    // (512 envelopes: the walk 101 -> 62 us.  While C5's oscillator + filter kernel took 115 us next to it that only
+    // slowed the block down, 0.177 -> 0.186 ms -- the walk was hidden and eight times the waves competed for the SIMDs;
+    // with that kernel at 80 us the walk is the critical path: 0.172 -> 0.142 ms.  256 envelopes -- a rank's share at two
+    // ranks -- 146 -> 122 us; a rank's 64: walk 100 -> 60 us)
     static const int par_max_batch = getenv("PGX_ADSR_PAR_MAX_BATCH") ? atoi(getenv("PGX_ADSR_PAR_MAX_BATCH")) : kParWalkBatch;
     if (MODE != 1 && par_on && batch <= par_max_batch && pgx::ceil_div(w.nchunks, kGroupChunks) <= kParMaxGroups)
         hipLaunchKernelGGL(k_adsr_walk_par<kParWaves>, dim3(batch), dim3(kParWaves * 64), 0, pgx::stream(), out,

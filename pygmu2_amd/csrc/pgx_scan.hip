@@ -2170,6 +2170,132 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
     PGX_SS_STAMP(15);
 }
 
+// ------------------------------------------------------------------------------------------------
+// BlitSawPE -> BiquadPE (scalar parameters) with sixteen frames per thread: k_blitsaw_biquad's chain with
+// k_supersaw_wide's oscillator (phases as products, numerator by the three-term recurrence, one Newton step) and the
+// filter section of the settled biquad kernels -- zero-state pass, DPP scan on the per-voice tables of A^(16 * 2^k)
+// (pgx_biquad_tables), then the carried state's contribution (A^j z).x added to the zero-state outputs (two fused
+// multiply-adds per frame instead of the recurrence again).  One workgroup of NW waves per voice walks the block;
+// the oscillator's float32 rounding is BlitSawPE's ((y * 2) * amp).  Held to a tolerance like k_supersaw_wide
+// (<= 1e-6 of peak against the two-launch bank), not to bits.
+template <int NW>
+struct SawBqWideShared {
+    double aff[2 * NW];
+    V2 tot[2][NW];
+};
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *saw_tables, double *saw_state,
+                      const double *coef, const double *bq_tables, double *bq_state) {
+    constexpr int T = kSswT, kTile = NW * 64 * T;
+    static_assert(kSswT == kBqT, "the filter tables are made for 16 frames per thread");
+    __shared__ SawBqWideShared<NW> sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int inst = blockIdx.x;
+    float *ob = out + (int64_t)inst * out_stride;
+    // uniform loads: the voice's constants live in scalar registers
+    const double *st = saw_tables + (int64_t)inst * kSswTabDoubles;
+    const double inc = st[0], m = st[1], invP = st[3], m_over_p = st[4], leak = st[5], amp2 = st[6];
+    const double rsd = st[8], rcd = st[9], rsm = st[10], rcm = st[11], two_cm = st[19];
+    double lamp[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lamp[k] = st[12 + k];
+    const double lam_wave = st[18];
+    const LanePowers lane_pw{st[20 + lane], st[20 + 64 + lane], st[20 + 128 + lane]};
+    const double phase0 = saw_state[inst * 2 + 0];
+    double carry_y = saw_state[inst * 2 + 1];
+    const double b0 = coef[inst * 5 + 0], b1 = coef[inst * 5 + 1], b2 = coef[inst * 5 + 2];
+    const double na1 = -coef[inst * 5 + 3], na2 = -coef[inst * 5 + 4];
+    const double *tb = bq_tables + (int64_t)inst * kBqTableDoubles;
+    M2 pstep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pstep[k] = load_m2(tb + 4 * k);
+    const M2 pwave = load_m2(tb + 24);
+    const M2 mlane = load_m2(tb + 28 + 4 * lane);
+    const M2 m16 = load_m2(tb + 28 + 4 * ((lane & 15) + 1));
+    const M2 m32 = load_m2(tb + 28 + 4 * ((lane & 31) + 1));
+    const double *rows = tb + kBqRowsAt;
+    V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
+    int parity = 0;
+    for (int64_t base = 0; base < n; base += kTile, ++parity) {
+        const int64_t f0 = base + (int64_t)tid * T;
+        // ---- the oscillator (frames past the block's end are rendered like the others and never stored)
+        const double ph = pgx::pgx_mod1(phase0 + (double)(f0 + 1) * inc);
+        const double theta = kPi * ph;
+        double sd, cd, sn, cn;
+        pgx::pgx_sincos_bounded(theta, sd, cd);
+        pgx::pgx_sincos_bounded(m * theta, sn, cn);
+        double xb[T];
+        if (saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb))
+            saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) e = __builtin_fma(leak, e, xb[j]);           // feeds the scan only
+        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
+        const double y_in = y;
+        // ---- BlitSawPE's float32 sample, and the filter's zero-state pass over the 16 frames
+        V2 ez{0.0, 0.0};
+        double yz[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const double z = leak * y;
+            y = z + xb[j];
+            const double x = (double)(float)(y * amp2);           // (y * 2) * amp, the doubling exact
+            const double yy = __builtin_fma(b0, x, ez.x);
+            ez.x = __builtin_fma(na1, yy, __builtin_fma(b1, x, ez.y));
+            ez.y = __builtin_fma(na2, yy, b2 * x);
+            yz[j] = yy;
+        }
+        const V2 ez_own = ez;
+        ez = mv_add_fma(pstep[0], dpp_v2<0x111, 0xf>(ez), ez);
+        ez = mv_add_fma(pstep[1], dpp_v2<0x112, 0xf>(ez), ez);
+        ez = mv_add_fma(pstep[2], dpp_v2<0x114, 0xf>(ez), ez);
+        ez = mv_add_fma(pstep[3], dpp_v2<0x118, 0xf>(ez), ez);
+        ez = mv_add_fma(m16, dpp_v2<0x142, 0xa>(ez), ez);
+        ez = mv_add_fma(m32, dpp_v2<0x143, 0xc>(ez), ez);
+        V2 *tot = sh.tot[parity & 1];
+        if (lane == 63) tot[wave] = ez;
+        __syncthreads();
+        V2 cw = carry_z, fold = carry_z;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            fold = mv_add_fma(pwave, fold, tot[w]);
+            if (w + 1 == wave) cw = fold;                         // this wave's carry-in
+        }
+        carry_z = fold;
+        const V2 ex = dpp_v2<0x138, 0xf>(ez);                     // the lane before, 0 for lane 0
+        const V2 zin = mv_add_fma(mlane, cw, ex);
+        float yf[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+            yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
+        store_frames<T>(ob, f0, n, 1, 0, yf);
+        if (f0 <= n - 1 && n - 1 < f0 + T) {                      // the thread that renders the block's last frame:
+            const int jn = (int)(n - 1 - f0);                     // the states after it, by the literal recurrences
+            double yl = y_in;
+            V2 z = zin;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const double zz = leak * yl;
+                const double yn = zz + xb[j];
+                const double x = (double)(float)(yn * amp2);
+                const double yy = z.x + b0 * x;
+                const double z0 = (z.y + b1 * x) + na1 * yy;
+                const double z1 = b2 * x + na2 * yy;
+                if (j <= jn) {
+                    yl = yn;
+                    z = V2{z0, z1};
+                }
+            }
+            saw_state[inst * 2 + 1] = yl;
+            bq_state[inst * 2 + 0] = z.x;
+            bq_state[inst * 2 + 1] = z.y;
+        }
+        (void)ez_own;
+    }
+    if (tid == 0) saw_state[inst * 2 + 0] = pgx::pgx_mod1(phase0 + (double)n * inc);
+}
+
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
 struct SawPlan {
     int nseg, tiles_per_seg;
@@ -3509,6 +3635,20 @@ int pgx_blitsaw_biquad_bank(float *out, int64_t out_stride, int batch, int64_t n
     hipLaunchKernelGGL(k_blitsaw_biquad, dim3(batch), dim3(kWaves * 64), 0, pgx::stream(), out, out_stride, n,
                        sample_rate, params, saw_state, coef, biquad_state);
     PGX_LAUNCH_CHECK("k_blitsaw_biquad");
+    return PGX_OK;
+}
+
+int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n, const double *saw_tables,
+                            double *saw_state, const double *coef, const double *biquad_tables,
+                            double *biquad_state) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && saw_tables && saw_state && coef && biquad_tables && biquad_state,
+                  "pgx_blitsaw_biquad_wide: bad argument");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_blitsaw_biquad_wide: out_stride too small");
+    hipLaunchKernelGGL(k_blitsaw_biquad_wide<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride, n,
+                       saw_tables, saw_state, coef, biquad_tables, biquad_state);
+    PGX_LAUNCH_CHECK("k_blitsaw_biquad_wide");
     return PGX_OK;
 }
 

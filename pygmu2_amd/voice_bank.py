@@ -90,6 +90,20 @@ class _SineNode(_Node):
         return out
 
 
+def _wide_oscillators_ok(rec, sr: float) -> bool:
+    """pgx_supersaw_wide / pgx_blitsaw_biquad_wide render these oscillators (records of BLITSAW_PARAMS): the automatic
+    (odd) M, a leak in (0, 0.9999] and f >= 1 Hz for the closed-form carries of the time segments, and a numerator
+    recurrence n[j+1] = 2 cos(M pi inc) n[j] - n[j-1] that does not amplify its roundings: |sin(M pi inc)| >= 0.05
+    (M pi inc is within 2 pi inc of pi/2 below Nyquist; above it M = 1 and the angle is pi inc itself)."""
+    if not (np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0) and np.all(rec["leak"] <= 0.9999)
+            and np.all(rec["freq"] >= 1.0)):
+        return False
+    f = np.asarray(rec["freq"], dtype=np.float64)
+    mi = np.floor(sr / (2.0 * np.maximum(f, 1.0))).astype(np.int64)
+    mi = np.maximum(mi - (1 - mi % 2), 1)                       # blit_saw_pe.py:166-173: the odd M at or below sr / 2f
+    return bool(np.all(np.abs(np.sin(mi * np.pi * (f / sr))) >= 0.05))
+
+
 class _BlitSawNode(_Node):
     def __init__(self, pes):
         super().__init__(pes, {})
@@ -106,7 +120,7 @@ class _BlitSawNode(_Node):
         # (_SuperSawNode.segmented); needs the automatic (odd) M and a leak below 1 for the closed-form carries
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
-        self.wide_ok = self.closed_form_ok and bool(np.all(rec["freq"] <= 0.5 * self.sr))   # (_SuperSawNode.wide)
+        self.wide_ok = _wide_oscillators_ok(rec, self.sr)           # (_SuperSawNode.wide)
         self.state_alt = None
         self.tables = {}
         self.unit_amp = None
@@ -189,9 +203,9 @@ class _SuperSawNode(_Node):
         rec = np.concatenate([pe._voice_param_records() for pe in pes])
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
-        # pgx_supersaw_wide (16 frames per thread): the rotation form of the Dirichlet kernel only -- scalar frequency
-        # up to sr/2 and the automatic M -- and the closed-form carries of the time segments
-        self.wide_ok = self.closed_form_ok and bool(np.all(rec["freq"] <= 0.5 * self.sr))
+        # pgx_supersaw_wide (16 frames per thread): the rotation / recurrence form of the Dirichlet kernel only -- scalar
+        # frequency, the automatic M -- and the closed-form carries of the time segments (_wide_oscillators_ok)
+        self.wide_ok = _wide_oscillators_ok(rec, self.sr)
         self.state_alt = None        # the segmented bank reads one state buffer and writes the other
         self.ahead_bank = None       # (start, n, bank output, last_end before): VoiceBank._supersaw_pipelined
         self.tables = {}             # ... and loads what depends on the parameters only (pgx_supersaw_*_tables)
@@ -366,8 +380,21 @@ class _BiquadNode(_Node):
                 self.state = DeviceBuffer((self.k, 1, 2), np.float64, zero=True)
             src.prepare(start)
             out = DeviceBuffer((self.k, n, 1), np.float32)
-            check(L.pgx_blitsaw_biquad_bank(out.ptr, n, self.k, n, self.sr, src.params.ptr, src.state.ptr,
-                                            self.coef.ptr, self.state.ptr), "pgx_blitsaw_biquad_bank")
+            if src.wide():
+                # sixteen frames per thread (pgx_blitsaw_biquad_wide): the oscillator's and the filter's per-voice tables
+                saw_tables = src.tables.get("wide")
+                if saw_tables is None:
+                    saw_tables = src.tables["wide"] = DeviceBuffer((L.pgx_supersaw_wide_table_bytes(self.k, 1),), np.uint8)
+                    check(L.pgx_supersaw_wide_tables(saw_tables.ptr, self.k, 1, self.sr, src.params.ptr),
+                          "pgx_supersaw_wide_tables")
+                if self.tables is None:
+                    self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
+                    check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
+                check(L.pgx_blitsaw_biquad_wide(out.ptr, n, self.k, n, saw_tables.ptr, src.state.ptr, self.coef.ptr,
+                                                self.tables.ptr, self.state.ptr), "pgx_blitsaw_biquad_wide")
+            else:
+                check(L.pgx_blitsaw_biquad_bank(out.ptr, n, self.k, n, self.sr, src.params.ptr, src.state.ptr,
+                                                self.coef.ptr, self.state.ptr), "pgx_blitsaw_biquad_bank")
             src.last_end = start + n
             return out
         x = src.render(start, n)

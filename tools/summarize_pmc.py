@@ -26,7 +26,16 @@ def main(path):
     print("| kernel | grid (threads) | counter | launches | mean | min | max |")
     print("|---|---|---|---|---|---|---|")
     for (k, g, c), v in sorted(acc.items()):
-        print(f"| {k} | {g} | {c} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} |")
+        # launches of different sizes can share a grid (a fixed number of workgroups): one row per cluster of values
+        # (a value more than 20 % above its cluster's smallest starts a new one)
+        clusters = []
+        for x in sorted(v):
+            if clusters and x <= 1.2 * clusters[-1][0] + 1.0:
+                clusters[-1].append(x)
+            else:
+                clusters.append([x])
+        for cl in clusters:
+            print(f"| {k} | {g} | {c} | {len(cl)} | {sum(cl) / len(cl):.1f} | {min(cl):.1f} | {max(cl):.1f} |")
 
 
 if __name__ == "__main__":

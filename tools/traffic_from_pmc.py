@@ -26,6 +26,18 @@ def table(name):
     return rows
 
 
+def rows_of(name, kernel):
+    """[(grid, mean KiB)] of every row of a kernel (several rows per grid when launches of different sizes share it),
+    by ascending mean."""
+    found = []
+    path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_{name}.md")
+    for line in open(path):
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        if len(cells) == 7 and cells[1].isdigit() and cells[0].startswith(kernel):
+            found.append((int(cells[1]), float(cells[4])))
+    return sorted(found, key=lambda r: r[1])
+
+
 def kib(rows, kernel, grid):
     for (k, g), v in rows.items():
         if k.startswith(kernel) and g == grid:
@@ -42,17 +54,19 @@ md = [f"# PMC: HBM traffic of the kernels priced against the HBM roofline, round
       "wide (16 B per lane) coalesced streaming read -> x2 where stated; WRITE_SIZE is exact.", ""]
 
 # ---- C2 fused
-f, w = table("c2fused_FETCH_SIZE"), table("c2fused_WRITE_SIZE")
-grids = {1_000_000: 126976, 16_000_000: 253952, 33_000_000: 258048, 1 << 26: 262144}
-md += ["## C2, the fused chain: `k_biquad_settled<mono, staged, sine>` (`pgx_biquad_sine`): nothing read, 4 B/frame written", "",
-       "| frames per launch | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB (fetch as counted + write) | algorithmic MB (4 B/frame) | ratio |",
-       "|---|---|---|---|---|---|"]
+sizes = [1_000_000, 16_000_000, 33_000_000, 1 << 26]
+wr_rows = rows_of("c2fused_WRITE_SIZE", "k_biquad_settled<true, true, true")
+fe_rows = rows_of("c2fused_FETCH_SIZE", "k_biquad_settled<true, true, true")
+assert len(wr_rows) == len(sizes), wr_rows          # one cluster of launches per size, ascending
+md += ["## C2, the fused chain: `k_biquad_settled<mono, staged, sine, 256>` (`pgx_biquad_sine`): nothing read, 4 B/frame written", "",
+       "| frames per launch | grid (threads) | FETCH_SIZE KiB (largest row of the kernel) | WRITE_SIZE KiB | traffic MB (fetch as counted + write) | algorithmic MB (4 B/frame) | ratio |",
+       "|---|---|---|---|---|---|---|"]
 out["pgx_biquad_sine"] = {}
-for frames, grid in grids.items():
-    fe, wr = kib(f, "k_biquad_settled<true, true, true>", grid), kib(w, "k_biquad_settled<true, true, true>", grid)
+fe = max(v for _, v in fe_rows)
+for frames, (grid, wr) in zip(sizes, wr_rows):
     total = (fe + wr) * 1024
     out["pgx_biquad_sine"][str(frames)] = int(round(total, -4))
-    md.append(f"| {frames:,} | {fe:,.1f} | {wr:,.1f} | **{total / 1e6:.2f}** | {4 * frames / 1e6:.2f} | {total / (4 * frames):.3f} |")
+    md.append(f"| {frames:,} | {grid} | {fe:,.1f} | {wr:,.1f} | **{total / 1e6:.2f}** | {4 * frames / 1e6:.2f} | {total / (4 * frames):.3f} |")
 md += ["", "(The little that is fetched: coefficient tables and the carried state; what is written beyond the output: the "
        "state.  The kernel is compiled without scratch: no spill traffic.)", ""]
 
