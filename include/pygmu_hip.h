@@ -62,6 +62,14 @@ int pgx_stream_fork(void);
 int pgx_stream_select(int side);
 int pgx_stream_join(void);
 int pgx_stream_is_forked(void);           /* 1 between fork and join */
+/* A fork whose side work the main stream does not need yet (the next block's envelopes, rendered one block ahead):
+ *   pgx_stream_detach()         ends the fork without waiting: the side stream keeps running what it was given, calls go
+ *                               to the main stream again; blocks freed during the fork stay parked
+ *   pgx_stream_wait_detached()  the main stream waits for that work (no-op when nothing is detached)
+ * A new fork waits for detached work first (there is one side stream); pgx_stream_sync covers it. */
+int pgx_stream_detach(void);
+int pgx_stream_wait_detached(void);
+int pgx_stream_is_detached(void);
 
 int pgx_malloc(void **dptr, size_t bytes);      /* pooled (size-class free lists)           */
 int pgx_free(void *dptr);                       /* returns the block to the pool            */

@@ -27,9 +27,10 @@ struct Runtime {
     hipStream_t stream = nullptr;          // main stream
     hipStream_t side = nullptr;            // second stream, used between fork and join
     hipStream_t current = nullptr;         // where the next call is enqueued
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_detached = nullptr;
     bool forked = false;
-    std::vector<void *> parked;            // blocks freed while forked (re-pooled at join)
+    bool detached = false;                 // the side stream still runs what a fork gave it; nobody waits yet
+    std::vector<void *> parked;            // blocks freed while forked (re-pooled at join / when the detached work is waited for)
     std::mutex mu;
     std::map<size_t, std::vector<void *>> free_lists;   // size class -> blocks
     std::unordered_map<void *, size_t> live;             // ptr -> size class
@@ -124,6 +125,8 @@ int pgx_init(int device) {
     }
     PGX_HIP(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
     PGX_HIP(hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming));
+    PGX_HIP(hipEventCreateWithFlags(&r.ev_detached, hipEventDisableTiming));
+    r.detached = false;
     PGX_HIP(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
     PGX_HIP(hipEventCreateWithFlags(&r.ev_copy_in, hipEventDisableTiming));
     for (auto &e : r.copy_done) PGX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -170,6 +173,8 @@ int pgx_shutdown(void) {
     (void)hipStreamDestroy(r.side);
     (void)hipEventDestroy(r.ev_fork);
     (void)hipEventDestroy(r.ev_join);
+    (void)hipEventDestroy(r.ev_detached);
+    r.detached = false;
     r.stream = r.side = r.current = nullptr;
     r.forked = false;
     r.ready = false;
@@ -191,14 +196,53 @@ void *pgx_stream_handle(void) { return (void *)rt().stream; }
 int pgx_stream_sync(void) {
     PGX_REQUIRE_INIT();
     PGX_HIP(hipStreamSynchronize(rt().stream));
-    if (rt().forked) PGX_HIP(hipStreamSynchronize(rt().side));
+    if (rt().forked || rt().detached) PGX_HIP(hipStreamSynchronize(rt().side));
     return PGX_OK;
 }
+
+static void release_parked(Runtime &r) {
+    std::lock_guard<std::mutex> lock(r.mu);
+    for (void *p : r.parked) {                      // single-stream order holds again from here on
+        auto it = r.live.find(p);
+        if (it == r.live.end()) continue;
+        const size_t cls = it->second;
+        r.live.erase(it);
+        r.free_lists[cls].push_back(p);
+        r.bytes_cached += cls;
+    }
+    r.parked.clear();
+}
+
+int pgx_stream_wait_detached(void) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    if (!r.detached) return PGX_OK;
+    PGX_HIP(hipStreamWaitEvent(r.stream, r.ev_detached, 0));
+    r.detached = false;
+    release_parked(r);
+    return PGX_OK;
+}
+
+int pgx_stream_detach(void) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(r.forked, "pgx_stream_detach: not forked");
+    PGX_HIP(hipEventRecord(r.ev_detached, r.side));
+    r.forked = false;
+    r.detached = true;                              // (what was freed while forked stays parked until the wait)
+    r.current = r.stream;
+    return PGX_OK;
+}
+
+int pgx_stream_is_detached(void) { return rt().ready && rt().detached ? 1 : 0; }
 
 int pgx_stream_fork(void) {
     PGX_REQUIRE_INIT();
     Runtime &r = rt();
     PGX_CHECK_ARG(!r.forked, "pgx_stream_fork: already forked");
+    if (r.detached) {                               // one side stream: what it still runs is waited for first
+        if (int rc = pgx_stream_wait_detached()) return rc;
+    }
     PGX_HIP(hipEventRecord(r.ev_fork, r.stream));
     PGX_HIP(hipStreamWaitEvent(r.side, r.ev_fork, 0));
     r.forked = true;
@@ -224,16 +268,7 @@ int pgx_stream_join(void) {
     PGX_HIP(hipStreamWaitEvent(r.stream, r.ev_join, 0));
     r.forked = false;
     r.current = r.stream;
-    std::lock_guard<std::mutex> lock(r.mu);
-    for (void *p : r.parked) {                      // single-stream order holds again from here on
-        auto it = r.live.find(p);
-        if (it == r.live.end()) continue;
-        const size_t cls = it->second;
-        r.live.erase(it);
-        r.free_lists[cls].push_back(p);
-        r.bytes_cached += cls;
-    }
-    r.parked.clear();
+    release_parked(r);
     return PGX_OK;
 }
 

@@ -48,6 +48,9 @@ _SIGNATURES = [
     ("pgx_stream_select", _I, [_I]),
     ("pgx_stream_join", _I, []),
     ("pgx_stream_is_forked", _I, []),
+    ("pgx_stream_detach", _I, []),
+    ("pgx_stream_wait_detached", _I, []),
+    ("pgx_stream_is_detached", _I, []),
     ("pgx_malloc", _I, [C.POINTER(_P), _Z]),
     ("pgx_free", _I, [_P]),
     ("pgx_pool_trim", _I, []),

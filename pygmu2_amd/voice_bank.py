@@ -41,6 +41,7 @@ PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
+ENVELOPE_AHEAD = True        # a bank's AdsrGatedPE(PeriodicGate) envelopes one block ahead on the side stream (render_mix)
 WIDE_SUPERSAW = True         # the bank kernel with 16 frames per thread (pgx_supersaw_wide) where its conditions hold
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
 FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
@@ -569,16 +570,65 @@ class _AdsrGatedNode(_Node):
         self.params = _dev.upload_structs(rec)
         self.state = DeviceBuffer((self.k, 3), np.float64, zero=True)
         self.ws = None
+        self.ahead = None            # (start, n, envelopes, state before them): render_ahead
+        self.last = None             # (start, n) of the last block handed out
 
     def _scratch(self, n):
         need = lib().pgx_adsr_workspace_bytes(self.k, n)
         if self.ws is None or self.ws.nbytes < need:
+            if self.ahead is not None:                          # (the side stream may still be using the old one)
+                check(lib().pgx_stream_wait_detached(), "pgx_stream_wait_detached")
             self.ws = DeviceBuffer((need,), np.uint8)
         return self.ws
 
     def reset(self):
+        self.forget_ahead(restore=False)
+        self.last = None
         super().reset()
         self.state.zero_()
+
+    # ---- one block ahead (VoiceBank.render_mix): the envelopes depend on nothing but time and three carried numbers
+    # each, and their walk is a latency chain that leaves the machine to everybody else -- so block k+1's are walked
+    # on the side stream while block k is mixed and block k+1's oscillators run; nobody waits for them until block
+    # k+1's mix.  A pull that is not the next block puts the states back.
+    def forget_ahead(self, restore: bool) -> None:
+        ahead, self.ahead = self.ahead, None
+        if ahead is None:
+            return
+        check(lib().pgx_stream_wait_detached(), "pgx_stream_wait_detached")
+        if restore:
+            check(lib().pgx_memcpy_d2d(self.state.ptr, ahead[3].ptr, ahead[3].nbytes), "pgx_memcpy_d2d")
+
+    def take_ahead(self, start, n):
+        """The envelopes of (start, n) if they were rendered ahead (the main stream then waits for them, which by now is
+        no wait); else None, with the states back where the last block left them."""
+        ahead = self.ahead
+        if ahead is None:
+            return None
+        if ahead[0] == start and ahead[1] == n:
+            self.ahead = None
+            check(lib().pgx_stream_wait_detached(), "pgx_stream_wait_detached")
+            self.last = (start, n)
+            return ahead[2]
+        self.forget_ahead(restore=True)
+        return None
+
+    def render_ahead(self, start, n) -> None:
+        """Fused PeriodicGate only.  Everything (state copy, edge search, walk) goes to the side stream, which starts
+        behind what the main stream holds so far and is left running (pgx_stream_detach)."""
+        L = lib()
+        gate_node = self.children["gate"]
+        out = DeviceBuffer((self.k, n, 1), np.float32)
+        saved = DeviceBuffer(self.state.shape, self.state.dtype)
+        scratch = self._scratch(n)
+        check(L.pgx_stream_fork(), "pgx_stream_fork")
+        try:
+            check(L.pgx_memcpy_d2d(saved.ptr, self.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
+            check(L.pgx_adsr_gated_periodic(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
+                                            self.state.ptr, scratch.ptr, 0), "pgx_adsr_gated_periodic")
+        finally:
+            check(L.pgx_stream_detach(), "pgx_stream_detach")
+        self.ahead = (start, n, out, saved)
 
     def channels(self):
         return 1
@@ -589,6 +639,9 @@ class _AdsrGatedNode(_Node):
     def render(self, start, n, detach=False):
         """detach=True (fused gate only): the envelope walk is left running on the side stream;
         the caller joins (pgx_stream_join) before using the result."""
+        if self.ahead is not None:
+            self.forget_ahead(restore=True)
+        self.last = (start, n)
         out = DeviceBuffer((self.k, n, 1), np.float32)
         gate_node = self.children["gate"]
         if isinstance(gate_node, _GateNode):
@@ -763,13 +816,25 @@ class VoiceBank:
             L = lib()
             gain = root.children["gain"]
             if isinstance(gain, _AdsrGatedNode) and gain.fused_gate():
-                # edge search first (parallel, short), then the walk detached on the side stream
-                try:
-                    g = gain.render(start, duration, detach=True)
+                ahead_ok = ENVELOPE_AHEAD and duration >= 1024 and not L.pgx_stream_is_forked()
+                streaming = gain.last == (start - duration, duration)      # equal blocks, one after the other
+                if ahead_ok and gain.ahead is not None:
+                    # this block's envelopes were walked while the last block was mixed: oscillators first, then the
+                    # (by now idle) wait for the side stream
                     x = root.children["source"].render(start, duration)
-                finally:
-                    if L.pgx_stream_is_forked():        # the fork happens inside the detached render
-                        check(L.pgx_stream_join(), "pgx_stream_join")
+                    g = gain.take_ahead(start, duration)
+                    if g is None:                       # a seek: walked now, behind the oscillators
+                        g = gain.render(start, duration)
+                else:
+                    # edge search first (parallel, short), then the walk detached on the side stream
+                    try:
+                        g = gain.render(start, duration, detach=True)
+                        x = root.children["source"].render(start, duration)
+                    finally:
+                        if L.pgx_stream_is_forked():        # the fork happens inside the detached render
+                            check(L.pgx_stream_join(), "pgx_stream_join")
+                if ahead_ok and streaming:              # (from a stream's second block on)
+                    gain.render_ahead(start + duration, duration)
             else:
                 check(L.pgx_stream_fork(), "pgx_stream_fork")
                 try:

@@ -246,3 +246,33 @@ def test_blitsaw_biquad_bank_in_one_launch_matches_the_two_launch_bank(monkeypat
         assert float(np.max(np.abs(a.astype(np.float64) - b))) <= (1e-6 if wide else 2e-7) * peak
         if not wide:
             assert np.mean(a != b) < 1e-3
+
+
+def test_envelopes_one_block_ahead_change_nothing(monkeypatch):
+    """A C5 bank streamed in equal blocks walks block k+1's envelopes on the side stream while block k is mixed
+    (voice_bank.ENVELOPE_AHEAD); a seek or a different block length puts the envelope states back.  Same kernels, same
+    order of operations per voice: bit for bit the bank without it."""
+    from pygmu2_amd import voice_bank
+    pg.set_sample_rate(48000)
+    blocks = ([(i * 6000, 6000) for i in range(5)] + [(30_000, 4096), (34_096, 4096), (38_192, 4096)]    # a new block length
+              + [(100_000, 6000), (106_000, 6000), (112_000, 6000)]                                         # a seek
+              + [(0, 6000), (6000, 6000)])                                                                   # and back to the start
+
+    def run(ahead):
+        monkeypatch.setattr(voice_bank, "ENVELOPE_AHEAD", ahead)
+        mix = pg.MixPE(*[c5_voice(pg, i) for i in range(0, 512, 3)])
+        r = pg.NullRenderer(sample_rate=48000)
+        r.set_source(mix)
+        r.start()
+        outs, armed = [], 0
+        for s, n in blocks:
+            outs.append(mix.render(s, n).data.copy())
+            armed += mix._voice_bank().root.children["gain"].ahead is not None
+        r.stop()
+        return outs, armed
+
+    got, armed = run(True)
+    want, none = run(False)
+    assert armed >= 7 and none == 0
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b), float(np.max(np.abs(a - b)))

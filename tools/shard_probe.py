@@ -11,7 +11,7 @@ from pygmu2_amd.sharding import c5_voice, shard_indices, supersaw_voice
 pg.set_sample_rate(48000)
 block = 48000
 make = supersaw_voice if sys.argv[1:] == ["supersaw"] else c5_voice
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("PGX_WORLDS", "1,2,4,8").split(",")]:
     voices = [make(pg, i) for i in shard_indices(512, 0, world)]
     root = pg.MixPE(*voices)
     r = pg.NullRenderer(sample_rate=48000)
