@@ -389,7 +389,7 @@ template <bool TRIG, int WPE>
 __global__ void __launch_bounds__(256)
 k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
             const pgx_adsr_params *params, const unsigned long long *masks, const unsigned long long *group_bits,
-            const float *last_gate, double *state) {
+            const float *last_gate, const double *state, double *state_out) {
     const int lane = threadIdx.x & 63;
     // A dependent chain: when it shares a SIMD with throughput kernels of a forked block
     // (pgx_adsr_gated_periodic's detach_walk) it must win instruction arbitration, or it is the
@@ -402,7 +402,8 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
     if (inst >= batch) return;
     const pgx_adsr_params p = params[inst];
     float *o = out + (int64_t)inst * out_stride;
-    double *st = state + (int64_t)inst * 3;
+    const double *st = state + (int64_t)inst * 3;
+    double *sto = state_out + (int64_t)inst * 3;                 // (the same buffer unless the block is rendered ahead)
     const unsigned long long *mk = masks + (int64_t)inst * nchunks * 2;
     const unsigned long long *gb = group_bits + (int64_t)inst * gwords;
 
@@ -458,9 +459,9 @@ k_adsr_walk(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
         pos += 1;
     }
     if (lane == 0 && sub == 0) {
-        st[0] = (double)c.s;
-        st[1] = c.env;
-        st[2] = TRIG ? (double)c.ends_at : (double)last_gate[inst];
+        sto[0] = (double)c.s;
+        sto[1] = c.env;
+        sto[2] = TRIG ? (double)c.ends_at : (double)last_gate[inst];
     }
 }
 
@@ -500,7 +501,8 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
                 const pgx_adsr_params *params, const unsigned long long *masks,
-                const unsigned long long *group_bits, const float *last_gate, double *state) {
+                const unsigned long long *group_bits, const float *last_gate, const double *state,
+                double *state_out) {
     __shared__ int e_pos[WAVES][kParMaxGroups + 2];
     __shared__ unsigned char e_att[WAVES][kParMaxGroups + 2];
     const int lane = threadIdx.x & 63;
@@ -509,7 +511,8 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
     const int inst = blockIdx.x;
     const pgx_adsr_params p = params[inst];
     float *o = out + (int64_t)inst * out_stride;
-    double *st = state + (int64_t)inst * 3;
+    const double *st = state + (int64_t)inst * 3;
+    double *sto = state_out + (int64_t)inst * 3;
     const unsigned long long *mk = masks + (int64_t)inst * nchunks * 2;
     const unsigned long long *gb = group_bits + (int64_t)inst * gwords;
     const int s0 = (int)st[0];
@@ -693,9 +696,9 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
             pos += 1;
         }
         if (lane == 0) {
-            st[0] = (double)c.s;
-            st[1] = c.env;
-            st[2] = (double)last_gate[inst];
+            sto[0] = (double)c.s;
+            sto[1] = c.env;
+            sto[2] = (double)last_gate[inst];
         }
         return;
     }
@@ -869,9 +872,9 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
     walk(c, seg_start, seg_end, L_int(sp_edge, j), true, -1);
     PGX_ADSR_DEBUG_MAX(7, PGX_ADSR_CLOCK() - t_emit);
     if (seg_end == n32 && lane == 0) {                            // the wave that walked to the block's end
-        st[0] = (double)c.s;
-        st[1] = c.env;
-        st[2] = (double)last_gate[inst];
+        sto[0] = (double)c.s;
+        sto[1] = c.env;
+        sto[2] = (double)last_gate[inst];
     }
 }
 
@@ -897,7 +900,8 @@ AdsrWs adsr_ws(void *workspace, int batch, int64_t n) {
 template <int MODE>
 int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_stride, int batch, int64_t start,
                 int64_t n, const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
-                void *workspace, bool detach_walk = false) {
+                void *workspace, bool detach_walk = false, double *state_out = nullptr) {
+    if (state_out == nullptr) state_out = state;                // in place
     AdsrWs w = adsr_ws(workspace, batch, n);
     if (int rc = pgx_memset(w.group_bits, 0, w.bits_bytes)) return rc;
     if (MODE == 2) {
@@ -929,16 +933,17 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
         hipLaunchKernelGGL(k_adsr_walk_par<kParWaves>, dim3(batch), dim3(kParWaves * 64), 0, pgx::stream(), out,
                            out_stride, batch, start, n, w.nchunks, w.gwords, params,
                            (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
-                           (const float *)w.last_gate, state);
+                           (const float *)w.last_gate, (const double *)state, state_out);
     else if (batch <= kWideWalkBatch)
         hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 4>), dim3(batch), dim3(256), 0, pgx::stream(), out, out_stride,
                            batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
-                           (const unsigned long long *)w.group_bits, (const float *)w.last_gate, state);
+                           (const unsigned long long *)w.group_bits, (const float *)w.last_gate, (const double *)state,
+                           state_out);
     else
         hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 1>), dim3((batch + 3) / 4), dim3(256), 0, pgx::stream(), out,
                            out_stride, batch, start, n, w.nchunks, w.gwords, params,
                            (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
-                           (const float *)w.last_gate, state);
+                           (const float *)w.last_gate, (const double *)state, state_out);
     PGX_LAUNCH_CHECK("k_adsr_walk");
     if (detach_walk) return pgx_stream_select(0);
     return PGX_OK;
@@ -975,6 +980,19 @@ int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t s
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_adsr_gated_periodic: stride too small");
     return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, state, workspace,
                           detach_walk != 0);
+}
+
+int pgx_adsr_gated_periodic_to(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
+                               const pgx_gate_params *gates, const pgx_adsr_params *params, const double *state_in,
+                               double *state_out, void *workspace) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && gates && params && state_in && state_out && workspace,
+                  "pgx_adsr_gated_periodic_to: null pointer");
+    PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_gated_periodic_to: block too long");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_adsr_gated_periodic_to: stride too small");
+    return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, const_cast<double *>(state_in),
+                          workspace, false, state_out);
 }
 
 int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride, int batch,

@@ -570,7 +570,8 @@ class _AdsrGatedNode(_Node):
         self.params = _dev.upload_structs(rec)
         self.state = DeviceBuffer((self.k, 3), np.float64, zero=True)
         self.ws = None
-        self.ahead = None            # (start, n, envelopes, state before them): render_ahead
+        self.ahead = None            # (start, n, envelopes): render_ahead
+        self.state_next = None       # ... which reads `state` and leaves the states after the block here
         self.last = None             # (start, n) of the last block handed out
 
     def _scratch(self, n):
@@ -582,7 +583,7 @@ class _AdsrGatedNode(_Node):
         return self.ws
 
     def reset(self):
-        self.forget_ahead(restore=False)
+        self.forget_ahead()
         self.last = None
         super().reset()
         self.state.zero_()
@@ -591,44 +592,42 @@ class _AdsrGatedNode(_Node):
     # each, and their walk is a latency chain that leaves the machine to everybody else -- so block k+1's are walked
     # on the side stream while block k is mixed and block k+1's oscillators run; nobody waits for them until block
     # k+1's mix.  A pull that is not the next block puts the states back.
-    def forget_ahead(self, restore: bool) -> None:
+    def forget_ahead(self, restore: bool = True) -> None:
+        """(restore: nothing to do -- a block rendered ahead reads `state` and writes `state_next`)"""
         ahead, self.ahead = self.ahead, None
-        if ahead is None:
-            return
-        check(lib().pgx_stream_wait_detached(), "pgx_stream_wait_detached")
-        if restore:
-            check(lib().pgx_memcpy_d2d(self.state.ptr, ahead[3].ptr, ahead[3].nbytes), "pgx_memcpy_d2d")
+        if ahead is not None:
+            check(lib().pgx_stream_wait_detached(), "pgx_stream_wait_detached")
 
     def take_ahead(self, start, n):
         """The envelopes of (start, n) if they were rendered ahead (the main stream then waits for them, which by now is
-        no wait); else None, with the states back where the last block left them."""
+        no wait) -- their end states become the carried ones; else None, nothing having moved."""
         ahead = self.ahead
         if ahead is None:
             return None
+        self.forget_ahead()
         if ahead[0] == start and ahead[1] == n:
-            self.ahead = None
-            check(lib().pgx_stream_wait_detached(), "pgx_stream_wait_detached")
+            self.state, self.state_next = self.state_next, self.state
             self.last = (start, n)
             return ahead[2]
-        self.forget_ahead(restore=True)
         return None
 
     def render_ahead(self, start, n) -> None:
-        """Fused PeriodicGate only.  Everything (state copy, edge search, walk) goes to the side stream, which starts
-        behind what the main stream holds so far and is left running (pgx_stream_detach)."""
+        """Fused PeriodicGate only.  Edge search and walk go to the side stream, which starts behind what the main
+        stream holds so far and is left running (pgx_stream_detach)."""
         L = lib()
         gate_node = self.children["gate"]
         out = DeviceBuffer((self.k, n, 1), np.float32)
-        saved = DeviceBuffer(self.state.shape, self.state.dtype)
+        if self.state_next is None:
+            self.state_next = DeviceBuffer(self.state.shape, self.state.dtype)
         scratch = self._scratch(n)
         check(L.pgx_stream_fork(), "pgx_stream_fork")
         try:
-            check(L.pgx_memcpy_d2d(saved.ptr, self.state.ptr, saved.nbytes), "pgx_memcpy_d2d")
-            check(L.pgx_adsr_gated_periodic(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
-                                            self.state.ptr, scratch.ptr, 0), "pgx_adsr_gated_periodic")
+            check(L.pgx_adsr_gated_periodic_to(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
+                                               self.state.ptr, self.state_next.ptr, scratch.ptr),
+                  "pgx_adsr_gated_periodic_to")
         finally:
             check(L.pgx_stream_detach(), "pgx_stream_detach")
-        self.ahead = (start, n, out, saved)
+        self.ahead = (start, n, out)
 
     def channels(self):
         return 1
@@ -640,7 +639,7 @@ class _AdsrGatedNode(_Node):
         """detach=True (fused gate only): the envelope walk is left running on the side stream;
         the caller joins (pgx_stream_join) before using the result."""
         if self.ahead is not None:
-            self.forget_ahead(restore=True)
+            self.forget_ahead()
         self.last = (start, n)
         out = DeviceBuffer((self.k, n, 1), np.float32)
         gate_node = self.children["gate"]
@@ -815,6 +814,7 @@ class VoiceBank:
             # filters: VALU-bound) share nothing, so they are enqueued on two streams and overlap.
             L = lib()
             gain = root.children["gain"]
+            walk_ahead = False
             if isinstance(gain, _AdsrGatedNode) and gain.fused_gate():
                 ahead_ok = ENVELOPE_AHEAD and duration >= 1024 and not L.pgx_stream_is_forked()
                 streaming = gain.last == (start - duration, duration)      # equal blocks, one after the other
@@ -833,8 +833,7 @@ class VoiceBank:
                     finally:
                         if L.pgx_stream_is_forked():        # the fork happens inside the detached render
                             check(L.pgx_stream_join(), "pgx_stream_join")
-                if ahead_ok and streaming:              # (from a stream's second block on)
-                    gain.render_ahead(start + duration, duration)
+                walk_ahead = ahead_ok and streaming
             else:
                 check(L.pgx_stream_fork(), "pgx_stream_fork")
                 try:
@@ -843,6 +842,13 @@ class VoiceBank:
                     x = root.children["source"].render(start, duration)
                 finally:
                     check(L.pgx_stream_join(), "pgx_stream_join")
+            if walk_ahead:
+                # from a stream's second block on.  Between this block's oscillators and its mix: the side stream starts
+                # behind what the main stream holds at the fork.  Behind the mix the walk -- edge search, walk, a
+                # cross-stream wake-up: longer than the next block's oscillators -- became the critical path (a rank's 64
+                # voices: 66 -> 89 us per block); in front of the oscillators it shares the SIMDs with them from their
+                # first tile (66 -> 74 us; 512 voices 133 -> 143 us)
+                gain.render_ahead(start + duration, duration)
             ch, gch = x.shape[2], g.shape[2]
             out = DeviceBuffer((duration, ch), np.float32)
             check(lib().pgx_gain_mix_batch(out.ptr, x.ptr, duration * ch, g.ptr, duration * gch, self.k,
