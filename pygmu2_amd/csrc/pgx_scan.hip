@@ -3774,7 +3774,7 @@ int pgx_supersaw_wide_segments(int batch, int nvoices, int64_t n) {
     static const int forced = getenv("PGX_SSW_SEGS") ? atoi(getenv("PGX_SSW_SEGS")) : 0;      // experiments
     int64_t best = 1;
     double best_cost = 0.0;
-    for (int64_t k = 1; k <= tiles && k <= 32; ++k) {
+    for (int64_t k = 1; k <= tiles && k <= 4096; ++k) {        // (grid.y)
         const int64_t seg_tiles = pgx::ceil_div(tiles, k);
         const int64_t nseg = pgx::ceil_div(tiles, seg_tiles);
         if (nseg != k) continue;                                // (the same plan as a smaller k)

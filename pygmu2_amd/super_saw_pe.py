@@ -15,6 +15,7 @@ import numpy as np
 
 from . import device as _dev
 from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, new_output, ptr
+from . import blit_saw_pe as _blit
 from .blit_saw_pe import BlitSawPE
 from .cache_pe import CachePE
 from .extent import Extent
@@ -141,6 +142,8 @@ class SuperSawPE(ProcessingElement):
                 rec[i][k] = v
         return rec
 
+    _wide_records = _voice_param_records
+
     def _voice_initial_state(self) -> np.ndarray:
         return np.stack([osc._initial_state() for osc in self._oscillators])
 
@@ -155,6 +158,13 @@ class SuperSawPE(ProcessingElement):
             self._last_render_end = None
         if self._last_render_end is None or start != self._last_render_end:
             self._state.upload(self._voice_initial_state())
+
+        if (_blit.WIDE_LONG_RENDERS and duration >= _blit.WIDE_MIN_FRAMES and not self.inputs() and nv <= 16):
+            # a long block (a look-ahead window) of a scalar-parameter SuperSaw: voices summed on chip, time segments
+            out = _blit.render_wide(self, nv, start, duration, float(self._amplitude), self._channels)
+            if out is not None:
+                self._last_render_end = start + duration
+                return Snippet(start, out)
 
         # per-voice frequency streams for a PE frequency: GainPE(freq, ratio) == f32 * f32(ratio)
         f_buf, f_stride = None, 0

@@ -25,7 +25,7 @@ from . import device as _dev
 from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, ptr
 from .adsr_pe import AdsrGatedPE
 from .biquad_pe import BiquadPE, rbj_coefficients, settle_frames
-from .blit_saw_pe import BlitSawPE
+from .blit_saw_pe import BlitSawPE, wide_oscillators_ok
 from .comb_pe import CombPE
 from .extent import Extent
 from .gain_pe import GainPE
@@ -91,20 +91,6 @@ class _SineNode(_Node):
         return out
 
 
-def _wide_oscillators_ok(rec, sr: float) -> bool:
-    """pgx_supersaw_wide / pgx_blitsaw_biquad_wide render these oscillators (records of BLITSAW_PARAMS): the automatic
-    (odd) M, a leak in (0, 0.9999] and f >= 1 Hz for the closed-form carries of the time segments, and a numerator
-    recurrence n[j+1] = 2 cos(M pi inc) n[j] - n[j-1] that does not amplify its roundings: |sin(M pi inc)| >= 0.05
-    (M pi inc is within 2 pi inc of pi/2 below Nyquist; above it M = 1 and the angle is pi inc itself)."""
-    if not (np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0) and np.all(rec["leak"] <= 0.9999)
-            and np.all(rec["freq"] >= 1.0)):
-        return False
-    f = np.asarray(rec["freq"], dtype=np.float64)
-    mi = np.floor(sr / (2.0 * np.maximum(f, 1.0))).astype(np.int64)
-    mi = np.maximum(mi - (1 - mi % 2), 1)                       # blit_saw_pe.py:166-173: the odd M at or below sr / 2f
-    return bool(np.all(np.abs(np.sin(mi * np.pi * (f / sr))) >= 0.05))
-
-
 class _BlitSawNode(_Node):
     def __init__(self, pes):
         super().__init__(pes, {})
@@ -121,7 +107,7 @@ class _BlitSawNode(_Node):
         # (_SuperSawNode.segmented); needs the automatic (odd) M and a leak below 1 for the closed-form carries
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
-        self.wide_ok = _wide_oscillators_ok(rec, self.sr)           # (_SuperSawNode.wide)
+        self.wide_ok = wide_oscillators_ok(rec, self.sr)           # (_SuperSawNode.wide)
         self.state_alt = None
         self.tables = {}
         self.unit_amp = None
@@ -205,8 +191,8 @@ class _SuperSawNode(_Node):
         self.closed_form_ok = bool(np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0)
                                    and np.all(rec["leak"] <= 0.9999) and np.all(rec["freq"] >= 1.0))
         # pgx_supersaw_wide (16 frames per thread): the rotation / recurrence form of the Dirichlet kernel only -- scalar
-        # frequency, the automatic M -- and the closed-form carries of the time segments (_wide_oscillators_ok)
-        self.wide_ok = _wide_oscillators_ok(rec, self.sr)
+        # frequency, the automatic M -- and the closed-form carries of the time segments (blit_saw_pe.wide_oscillators_ok)
+        self.wide_ok = wide_oscillators_ok(rec, self.sr)
         self.state_alt = None        # the segmented bank reads one state buffer and writes the other
         self.ahead_bank = None       # (start, n, bank output, last_end before): VoiceBank._supersaw_pipelined
         self.tables = {}             # ... and loads what depends on the parameters only (pgx_supersaw_*_tables)

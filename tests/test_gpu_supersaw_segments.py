@@ -107,3 +107,49 @@ def test_segment_plan_and_fallbacks():
             osc._leak = 1.0
     bank = mix._voice_bank()
     assert bank and not bank.root.segmented(48_000)
+
+
+@pytest.mark.parametrize("kind", ["blitsaw", "supersaw"])
+def test_a_lone_oscillator_over_a_long_block(kind):
+    """One BlitSawPE / SuperSawPE with scalar parameters rendered 300 000 frames at once (what a look-ahead window hands
+    it): pgx_supersaw_wide with one instance in ~70 time segments -- against the same PE rendered in 4000-frame blocks
+    (k_blitsaw: the reference's arithmetic) and against the oracle; the short block after it continues the stream."""
+    import pygmu2_amd as pg
+    from pygmu2_amd import blit_saw_pe
+    from oracle import graph_eval
+    from oracle.golden_cases import S
+    pg.set_sample_rate(48000)
+    if kind == "blitsaw":
+        make = lambda: pg.BlitSawPE(frequency=173.3, amplitude=0.8)
+        spec = S("BlitSawPE", frequency=173.3, amplitude=0.8)
+    else:
+        make = lambda: pg.SuperSawPE(frequency=98.0, voices=7, detune_cents=20.0, seed=3, channels=2)
+        spec = S("SuperSawPE", frequency=98.0, voices=7, detune_cents=20.0, seed=3, channels=2)
+    blocks = [(0, 300_000), (300_000, 4000), (304_000, 50_000)]
+
+    def run(wide, cut):
+        keep = blit_saw_pe.WIDE_LONG_RENDERS
+        blit_saw_pe.WIDE_LONG_RENDERS = wide
+        try:
+            pe = make()
+            r = pg.NullRenderer(sample_rate=48000)
+            r.set_source(pe)
+            r.start()
+            outs = []
+            for s, n in blocks:
+                parts = [pe.render(p, min(cut, s + n - p)).data.copy() for p in range(s, s + n, cut)]
+                outs.append(np.concatenate(parts))
+            r.stop()
+            return outs
+        finally:
+            blit_saw_pe.WIDE_LONG_RENDERS = keep
+
+    got = run(True, 10 ** 9)
+    want = run(False, 4000)
+    g = graph_eval.Node(spec, 48000)
+    for a, b, (s, n) in zip(got, want, blocks):
+        peak = float(np.max(np.abs(b)))
+        assert a.shape == b.shape
+        assert float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak
+    ref = np.concatenate([g.render(p, 4000) for p in range(0, 300_000, 4000)])
+    assert float(np.max(np.abs(got[0].astype(np.float64) - ref))) <= 1e-5 * float(np.max(np.abs(ref)))
