@@ -135,10 +135,13 @@ def test_bank_of_combs_matches_voices_one_by_one():
         return [pg.CombPE(pg.BlitSawPE(frequency=55.0 * 2 ** (i / 7.0)), frequency=40.0 * 2 ** (i / 5.0),
                           feedback=0.3 + 0.02 * i) for i in range(24)]
 
+    from pygmu2_amd import blit_saw_pe
+
     def run(banked):
-        keep = voice_bank.MIN_VOICES, voice_bank.SEGMENTED_SUPERSAW
+        keep = voice_bank.MIN_VOICES, voice_bank.SEGMENTED_SUPERSAW, blit_saw_pe.WIDE_LONG_RENDERS
         voice_bank.MIN_VOICES = 4 if banked else 10 ** 9
         voice_bank.SEGMENTED_SUPERSAW = False      # the oscillators in front of the combs: not what is compared here
+        blit_saw_pe.WIDE_LONG_RENDERS = False      # (... bank or lone: k_blitsaw's samples either way)
         try:
             mix = pg.MixPE(*voices())
             r = pg.NullRenderer(sample_rate=48000)
@@ -149,7 +152,7 @@ def test_bank_of_combs_matches_voices_one_by_one():
             r.stop()
             return outs
         finally:
-            voice_bank.MIN_VOICES, voice_bank.SEGMENTED_SUPERSAW = keep
+            voice_bank.MIN_VOICES, voice_bank.SEGMENTED_SUPERSAW, blit_saw_pe.WIDE_LONG_RENDERS = keep
 
     for a, b in zip(run(True), run(False)):
         assert np.array_equal(a, b)

@@ -193,6 +193,8 @@ def test_supersaw_bank_summed_on_chip_is_the_two_launch_path_bit_for_bit(voices,
     from pygmu2_amd import voice_bank
     pg.set_sample_rate(48000)
     monkeypatch.setattr(voice_bank, "WIDE_SUPERSAW", False)           # the 8-frames-per-thread bank: k_blitsaw's bits
+    from pygmu2_amd import blit_saw_pe
+    monkeypatch.setattr(blit_saw_pe, "WIDE_LONG_RENDERS", False)      # (and for the lone PEs inside look-ahead windows)
     n_inst = 258 if voices == 7 else 256                              # (pgx_supersaw_wide: test_gpu_supersaw_segments.py)
 
     def make():

@@ -76,8 +76,9 @@ md += ["## The filter alone: `k_biquad_settled<mono, staged>` (`pgx_biquad_const
        "| frames per launch | FETCH_SIZE KiB (raw) | read MB (x2: wide streaming reads) | WRITE_SIZE KiB | traffic MB | algorithmic MB | ratio |",
        "|---|---|---|---|---|---|---|"]
 out["pgx_biquad_const_settled"] = {}
+grids = {1_000_000: 126976, 16_000_000: 253952, 33_000_000: 258048, 1 << 26: 262144}      # 512 workgroups of 512 threads
 for frames, grid in grids.items():
-    fe, wr = kib(f, "k_biquad_settled<true, true, false>", grid), kib(w, "k_biquad_settled<true, true, false>", grid)
+    fe, wr = kib(f, "k_biquad_settled<true, true, false", grid), kib(w, "k_biquad_settled<true, true, false", grid)
     total = (2 * fe + wr) * 1024
     out["pgx_biquad_const_settled"][str(frames)] = int(round(total, -4))
     md.append(f"| {frames:,} | {fe:,.1f} | {2 * fe * 1024 / 1e6:.2f} | {wr:,.1f} | **{total / 1e6:.2f}** | {8 * frames / 1e6:.2f} | {total / (8 * frames):.3f} |")
@@ -129,7 +130,7 @@ for (k, g), v in sorted(f.items()):
 # (k_mix_batch runs at two sizes in the probe -- 512 inputs for the SuperSaw mix, 64 for C4 -- its largest launch is the 512-input one)
 mix512 = max(v for (n_, k, g), v in MAXES.items() if n_ == "mixes_FETCH_SIZE" and k.startswith("k_mix_batch"))
 ss = (kib(w, "k_supersaw_wide<4>", 131072) + 2 * mix512) * 1024
-c5 = (kib(w, "k_blitsaw_biquad", 131072) + kib(w, "k_adsr_walk<false, 1>", 32768) + 2 * kib(f, "k_gain_mix_batch", 48128)) * 1024
+c5 = (kib(w, "k_blitsaw_biquad_wide", 131072) + kib(w, "k_adsr_walk_par<8>", 262144) + 2 * kib(f, "k_gain_mix_batch", 48128)) * 1024
 md += ["", f"SuperSaw mix (512 x 7 oscillators): the `[512][48000]` float32 layer under the MixPE is written once and read once "
        f"(x2 on the wide reads of `k_mix_batch`; the 512-input launch is the table's maximum, its mean blends in C4's 64-input mix): about **{ss / 1e6:.0f} MB** per block against "
        f"0.192 MB of final mix.  C5: oscillator+filter output and envelopes, each `[512][48000]`, written and read by "
