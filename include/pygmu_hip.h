@@ -390,7 +390,9 @@ int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n
                             const double *saw_tables /* [batch] pgx_supersaw_wide_tables(nvoices = 1) */,
                             double *saw_state /* [batch][2] */, const double *coef /* [batch][5] */,
                             const double *biquad_tables /* [batch] pgx_biquad_tables */,
-                            double *biquad_state /* [batch][2] */);
+                            double *biquad_state /* [batch][2] */,
+                            const float *gain /* NULL, or [batch][gain_stride]: out = float32(voice * gain), GainPE's product */,
+                            int64_t gain_stride);
 
 /* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
  * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the

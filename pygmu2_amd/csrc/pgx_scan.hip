@@ -2186,7 +2186,8 @@ struct SawBqWideShared {
 template <int NW>
 __global__ void __launch_bounds__(NW * 64)
 k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *saw_tables, double *saw_state,
-                      const double *coef, const double *bq_tables, double *bq_state) {
+                      const double *coef, const double *bq_tables, double *bq_state, const float *gain,
+                      int64_t gain_stride) {
     constexpr int T = kSswT, kTile = NW * 64 * T;
     static_assert(kSswT == kBqT, "the filter tables are made for 16 frames per thread");
     __shared__ SawBqWideShared<NW> sh;
@@ -2217,8 +2218,23 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
     const double *rows = tb + kBqRowsAt;
     V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
     int parity = 0;
+    const float *gb = gain ? gain + (int64_t)inst * gain_stride : nullptr;
     for (int64_t base = 0; base < n; base += kTile, ++parity) {
         const int64_t f0 = base + (int64_t)tid * T;
+        // the voice's gain (GainPE(x, gain=<PE>): float32 x float32) for these frames, asked for first
+        float gv[T];
+        if (gb != nullptr) {
+            if (f0 + T <= n && aligned16(gb + f0)) {
+#pragma unroll
+                for (int j = 0; j < T; j += 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(gb + f0 + j);
+                    gv[j] = q.x; gv[j + 1] = q.y; gv[j + 2] = q.z; gv[j + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) gv[j] = f0 + j < n ? gb[f0 + j] : 0.0f;
+            }
+        }
         // ---- the oscillator (frames past the block's end are rendered like the others and never stored)
         const double ph = pgx::pgx_mod1(phase0 + (double)(f0 + 1) * inc);
         const double theta = kPi * ph;
@@ -2269,6 +2285,10 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
 #pragma unroll
         for (int j = 0; j < T; ++j)
             yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
+        if (gb != nullptr) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) yf[j] = yf[j] * gv[j];    // gain_pe.py:104-119: the float32 product
+        }
         store_frames<T>(ob, f0, n, 1, 0, yf);
         if (f0 <= n - 1 && n - 1 < f0 + T) {                      // the thread that renders the block's last frame:
             const int jn = (int)(n - 1 - f0);                     // the states after it, by the literal recurrences
@@ -3640,14 +3660,15 @@ int pgx_blitsaw_biquad_bank(float *out, int64_t out_stride, int batch, int64_t n
 
 int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n, const double *saw_tables,
                             double *saw_state, const double *coef, const double *biquad_tables,
-                            double *biquad_state) {
+                            double *biquad_state, const float *gain, int64_t gain_stride) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || batch <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && saw_tables && saw_state && coef && biquad_tables && biquad_state,
                   "pgx_blitsaw_biquad_wide: bad argument");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_blitsaw_biquad_wide: out_stride too small");
+    PGX_CHECK_ARG(gain == nullptr || batch == 1 || gain_stride >= n, "pgx_blitsaw_biquad_wide: gain_stride too small");
     hipLaunchKernelGGL(k_blitsaw_biquad_wide<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride, n,
-                       saw_tables, saw_state, coef, biquad_tables, biquad_state);
+                       saw_tables, saw_state, coef, biquad_tables, biquad_state, gain, gain_stride);
     PGX_LAUNCH_CHECK("k_blitsaw_biquad_wide");
     return PGX_OK;
 }

@@ -41,6 +41,7 @@ PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
+FUSE_GAIN_IN_CHAIN = False   # ... and multiplied into the voices by the oscillator -> filter kernel: measured, no gain (render_mix)
 ENVELOPE_AHEAD = True        # a bank's AdsrGatedPE(PeriodicGate) envelopes one block ahead on the side stream (render_mix)
 WIDE_SUPERSAW = True         # the bank kernel with 16 frames per thread (pgx_supersaw_wide) where its conditions hold
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
@@ -358,7 +359,12 @@ class _BiquadNode(_Node):
     def channels(self):
         return self.children["source"].channels()
 
-    def render(self, start, n):
+    def takes_gain(self) -> bool:
+        """render(..., gain=<[K][n] float32>) multiplies the voices by it inside the chain's kernel."""
+        src = self.children["source"]
+        return isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= FUSED_VOICE_MIN and src.wide()
+
+    def render(self, start, n, gain=None):
         L = lib()
         src = self.children["source"]
         if isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= FUSED_VOICE_MIN:
@@ -378,7 +384,8 @@ class _BiquadNode(_Node):
                     self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
                     check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
                 check(L.pgx_blitsaw_biquad_wide(out.ptr, n, self.k, n, saw_tables.ptr, src.state.ptr, self.coef.ptr,
-                                                self.tables.ptr, self.state.ptr), "pgx_blitsaw_biquad_wide")
+                                                self.tables.ptr, self.state.ptr, ptr(gain), n),
+                      "pgx_blitsaw_biquad_wide")
             else:
                 check(L.pgx_blitsaw_biquad_bank(out.ptr, n, self.k, n, self.sr, src.params.ptr, src.state.ptr,
                                                 self.coef.ptr, self.state.ptr), "pgx_blitsaw_biquad_bank")
@@ -804,13 +811,36 @@ class VoiceBank:
             if isinstance(gain, _AdsrGatedNode) and gain.fused_gate():
                 ahead_ok = ENVELOPE_AHEAD and duration >= 1024 and not L.pgx_stream_is_forked()
                 streaming = gain.last == (start - duration, duration)      # equal blocks, one after the other
+                source = root.children["source"]
+                gained = False
                 if ahead_ok and gain.ahead is not None:
-                    # this block's envelopes were walked while the last block was mixed: oscillators first, then the
-                    # (by now idle) wait for the side stream
-                    x = root.children["source"].render(start, duration)
-                    g = gain.take_ahead(start, duration)
-                    if g is None:                       # a seek: walked now, behind the oscillators
-                        g = gain.render(start, duration)
+                    # this block's envelopes were walked while the last block was mixed (the wait for the side stream is
+                    # no wait by now).  A chain that takes the gain can multiply by them in its own kernel -- the mix then
+                    # reads one [voices][frames] layer, not two (35 -> 17 us) -- but the oscillators then depend on the
+                    # envelopes, the next walk has to start in front of them and shares their SIMDs from the first tile:
+                    # 512 voices 139 us per block against 137, 256 voices 91 against 90.  Off.
+                    if FUSE_GAIN_IN_CHAIN and isinstance(source, _BiquadNode) and source.takes_gain():
+                        g = gain.take_ahead(start, duration)
+                        if g is not None:
+                            # (the next block's walk first: the oscillators now depend on this block's envelopes, so a
+                            # walk that starts behind them would be finished only a whole walk after them)
+                            if streaming:
+                                gain.render_ahead(start + duration, duration)
+                                streaming = False
+                            x = source.render(start, duration, gain=g)
+                            gained = True
+                        else:                           # a seek: walked now, beside the oscillators
+                            try:
+                                g = gain.render(start, duration, detach=True)
+                                x = source.render(start, duration)
+                            finally:
+                                if L.pgx_stream_is_forked():
+                                    check(L.pgx_stream_join(), "pgx_stream_join")
+                    else:
+                        x = source.render(start, duration)
+                        g = gain.take_ahead(start, duration)
+                        if g is None:                   # a seek: walked now, behind the oscillators
+                            g = gain.render(start, duration)
                 else:
                     # edge search first (parallel, short), then the walk detached on the side stream
                     try:
@@ -820,6 +850,13 @@ class VoiceBank:
                         if L.pgx_stream_is_forked():        # the fork happens inside the detached render
                             check(L.pgx_stream_join(), "pgx_stream_join")
                 walk_ahead = ahead_ok and streaming
+                if gained:
+                    if walk_ahead:
+                        gain.render_ahead(start + duration, duration)
+                    ch = x.shape[2]
+                    out = DeviceBuffer((duration, ch), np.float32)
+                    check(L.pgx_mix_batch(out.ptr, x.ptr, duration * ch, self.k, duration * ch), "pgx_mix_batch")
+                    return Snippet(start, out)
             else:
                 check(L.pgx_stream_fork(), "pgx_stream_fork")
                 try:

@@ -250,7 +250,8 @@ def test_blitsaw_biquad_bank_in_one_launch_matches_the_two_launch_bank(monkeypat
             assert np.mean(a != b) < 1e-3
 
 
-def test_envelopes_one_block_ahead_change_nothing(monkeypatch):
+@pytest.mark.parametrize("gain_in_chain", [False, True])
+def test_envelopes_one_block_ahead_change_nothing(monkeypatch, gain_in_chain):
     """A C5 bank streamed in equal blocks walks block k+1's envelopes on the side stream while block k is mixed
     (voice_bank.ENVELOPE_AHEAD); a seek or a different block length puts the envelope states back.  Same kernels, same
     order of operations per voice: bit for bit the bank without it."""
@@ -259,6 +260,8 @@ def test_envelopes_one_block_ahead_change_nothing(monkeypatch):
     blocks = ([(i * 6000, 6000) for i in range(5)] + [(30_000, 4096), (34_096, 4096), (38_192, 4096)]    # a new block length
               + [(100_000, 6000), (106_000, 6000), (112_000, 6000)]                                         # a seek
               + [(0, 6000), (6000, 6000)])                                                                   # and back to the start
+
+    monkeypatch.setattr(voice_bank, "FUSE_GAIN_IN_CHAIN", gain_in_chain)    # (x gain inside pgx_blitsaw_biquad_wide: same float32 products)
 
     def run(ahead):
         monkeypatch.setattr(voice_bank, "ENVELOPE_AHEAD", ahead)

@@ -431,3 +431,47 @@ def test_comb_and_small_oscillator_banks_are_batchable():
     assert voice_bank._signature(pg.CombPE(pg.BlitSawPE(110.0), frequency=pg.SinePE(2.0), feedback=0.5)) is None
     assert voice_bank._signature(pg.CombPE(pg.BlitSawPE(110.0), frequency=220.0, feedback=pg.SinePE(2.0))) is None
     pg.set_sample_rate(44100)
+
+
+def _raw_library():
+    """The C-ABI library without a device: planning entry points only (nothing that launches)."""
+    import ctypes
+    from pygmu2_amd import build
+    lib = ctypes.CDLL(build.LIB_PATH)
+    lib.pgx_supersaw_wide_segments.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64]
+    lib.pgx_supersaw_wide_table_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.pgx_supersaw_wide_table_bytes.restype = ctypes.c_size_t
+    lib.pgx_convolve_fft_size.argtypes = [ctypes.c_int64]
+    lib.pgx_convolve_fft_size.restype = ctypes.c_int64
+    lib.pgx_convolve_fft_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]
+    lib.pgx_convolve_fft_workspace_bytes.restype = ctypes.c_size_t
+    return lib
+
+
+def test_segment_planner_of_the_wide_bank():
+    """pgx_supersaw_wide_segments: the plan with the smallest estimated makespan (host arithmetic only)."""
+    lib = _raw_library()
+    seg = lib.pgx_supersaw_wide_segments
+    assert seg(64, 7, 48_000) == 4            # 12 tiles: 4 segments x 3 tiles = one workgroup per CU
+    assert seg(128, 7, 48_000) == 4           # two workgroups per CU beat one with six tiles
+    assert seg(512, 7, 48_000) == 1           # enough instances: no segment entry cost
+    assert seg(64, 7, 4096) == 1              # a single tile
+    assert seg(1, 7, 2_822_400) == 230        # a lone SuperSaw over a 64-block window: 689 tiles in threes -- the chip is full
+    assert seg(0, 7, 48_000) == 1 and seg(64, 0, 48_000) == 1 and seg(64, 7, 0) == 1
+    for batch in (1, 3, 17, 64, 200, 512, 5000):
+        for nv in (1, 7, 16):
+            for n in (1, 4095, 4097, 48_000, 1 << 20):
+                k = seg(batch, nv, n)
+                tiles = -(-n // 4096)
+                assert 1 <= k <= tiles
+                assert (k - 1) * -(-tiles // k) < tiles          # no empty segment
+    assert lib.pgx_supersaw_wide_table_bytes(3, 7) == 3 * 7 * 212 * 8
+
+
+def test_fft_convolution_sizes():
+    lib = _raw_library()
+    assert lib.pgx_convolve_fft_size(65536) == 131072 and lib.pgx_convolve_fft_size(2048) == 4096
+    assert lib.pgx_convolve_fft_size(131072) == 262144 and lib.pgx_convolve_fft_size(131073) == 0
+    # 96 000 stereo frames, 65 536 taps: two overlap-save blocks per channel -> two packed transforms of 2^17 complex doubles
+    need = lib.pgx_convolve_fft_workspace_bytes(96_000, 65536, 2, 131072)
+    assert need >= 2 * 131072 * 16 + 65535 * 2 * 4
