@@ -1,6 +1,7 @@
 """CPU: the RIFF/WAVE container code (pygmu2_amd/wav_io.py) against the standard library's `wave`
 reader, and the oracle's restatement of libsndfile's PCM_16 conversion on known values."""
 
+import os
 import struct
 import wave
 
@@ -76,3 +77,29 @@ def test_reader_skips_unknown_chunks_and_rejects_other_formats(tmp_path):
         wav_io.read_info(bad)
     with pytest.raises(ValueError, match="unsupported WAV subtype"):
         wav_io.WavFileWriter(str(tmp_path / "c.wav"), 8000, 1, "PCM_24")
+
+
+KEMAR_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kemar")
+
+
+@pytest.mark.parametrize("name", sorted(os.listdir(KEMAR_DIR)))
+def test_reader_on_the_reference_trees_own_recordings(name):
+    """The KEMAR impulse responses of the reference tree (src/pygmu2/assets/kemar: 22 of its 371 files, every 19th by
+    name, kept as data fixtures): the reader against the standard library's decoding of the same file and libsndfile's
+    PCM16 -> float32 rule (s / 32768), whole and in an inner window, and the file name against the grid rule that picks
+    it (spatial_pe.py:293-520)."""
+    import wave
+    from pygmu2_amd import wav_io
+    from pygmu2_amd.spatial_pe import kemar_entries
+    path = os.path.join(KEMAR_DIR, name)
+    with wave.open(path, "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, w.getnchannels())
+        rate = w.getframerate()
+    info = wav_io.read_info(path)
+    assert (info.frames, info.channels, info.sample_rate) == (pcm.shape[0], pcm.shape[1], rate)
+    want = pcm.astype(np.float32) * np.float32(1.0 / 32768.0)
+    got = wav_io.read_frames(path, info, 0, info.frames)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    a, b = info.frames // 3, info.frames - 7
+    assert np.array_equal(wav_io.read_frames(path, info, a, b), want[a:b])
+    assert any(entry[2] == name for entry in kemar_entries())
