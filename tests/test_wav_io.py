@@ -85,9 +85,9 @@ KEMAR_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 @pytest.mark.parametrize("name", sorted(os.listdir(KEMAR_DIR)))
 def test_reader_on_the_reference_trees_own_recordings(name):
     """The KEMAR impulse responses of the reference tree (src/pygmu2/assets/kemar: 22 of its 371 files, every 19th by
-    name, kept as data fixtures): the reader against the standard library's decoding of the same file and libsndfile's
-    PCM16 -> float32 rule (s / 32768), whole and in an inner window, and the file name against the grid rule that picks
-    it (spatial_pe.py:293-520)."""
+    name, kept as data fixtures): the reader against the standard library's decoding of the same file, whole and in an
+    inner window (the s / 32768 conversion is the device's: tests/test_gpu_wav.py), and the file name against the grid
+    rule that picks it (spatial_pe.py:293-520)."""
     import wave
     from pygmu2_amd import wav_io
     from pygmu2_amd.spatial_pe import kemar_entries
@@ -97,9 +97,8 @@ def test_reader_on_the_reference_trees_own_recordings(name):
         rate = w.getframerate()
     info = wav_io.read_info(path)
     assert (info.frames, info.channels, info.sample_rate) == (pcm.shape[0], pcm.shape[1], rate)
-    want = pcm.astype(np.float32) * np.float32(1.0 / 32768.0)
-    got = wav_io.read_frames(path, info, 0, info.frames)
-    assert got.dtype == np.float32 and np.array_equal(got, want)
+    got = wav_io.read_frames(path, info, 0, info.frames)          # the stored samples; s / 32768 happens on the device
+    assert info.subtype == "PCM_16" and got.dtype == np.int16 and np.array_equal(got, pcm)
     a, b = info.frames // 3, info.frames - 7
-    assert np.array_equal(wav_io.read_frames(path, info, a, b), want[a:b])
+    assert np.array_equal(wav_io.read_frames(path, info, a, b), pcm[a:b])
     assert any(entry[2] == name for entry in kemar_entries())
