@@ -949,6 +949,28 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
     return PGX_OK;
 }
 
+// Blocks longer than the 65 536 frames k_adsr_walk_par covers (look-ahead windows of a lone envelope: up to 64 x 44 100
+// frames) are walked chunk after chunk by it -- the result does not depend on the partition -- instead of in one piece by
+// k_adsr_walk's single chain: a 2.8 M-frame window 1.6 ms -> 43 chunks.  PGX_ADSR_CHUNK=0: one piece.
+template <int MODE>
+int adsr_run(float *out, int64_t out_stride, const float *ctl, int64_t ctl_stride, int batch, int64_t start, int64_t n,
+             const pgx_gate_params *gates, const pgx_adsr_params *params, double *state, void *workspace,
+             bool detach_walk = false, double *state_out = nullptr) {
+    constexpr int64_t kParFrames = (int64_t)kParMaxGroups * kGroupChunks * 64;
+    static const bool chunk_on = !(getenv("PGX_ADSR_CHUNK") && atoi(getenv("PGX_ADSR_CHUNK")) == 0);
+    if (MODE == 1 || !chunk_on || detach_walk || batch > kParWalkBatch || n <= kParFrames)
+        return adsr_launch<MODE>(out, out_stride, ctl, ctl_stride, batch, start, n, gates, params, state, workspace,
+                                 detach_walk, state_out);
+    double *carried = state_out ? state_out : state;
+    for (int64_t pos = 0; pos < n; pos += kParFrames) {
+        const int64_t len = n - pos < kParFrames ? n - pos : kParFrames;
+        if (int rc = adsr_launch<MODE>(out + pos, out_stride, ctl ? ctl + pos : nullptr, ctl_stride, batch, start + pos, len,
+                                       gates, params, pos == 0 ? state : carried, workspace, false, carried))
+            return rc;
+    }
+    return PGX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -967,7 +989,7 @@ int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t ga
     PGX_CHECK_ARG(out && gate && params && state && workspace, "pgx_adsr_gated: null pointer");
     PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_gated: block too long");
     PGX_CHECK_ARG(batch == 1 || (out_stride >= n && gate_stride >= n), "pgx_adsr_gated: stride too small");
-    return adsr_launch<0>(out, out_stride, gate, gate_stride, batch, 0, n, nullptr, params, state, workspace);
+    return adsr_run<0>(out, out_stride, gate, gate_stride, batch, 0, n, nullptr, params, state, workspace);
 }
 
 int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
@@ -978,8 +1000,8 @@ int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t s
     PGX_CHECK_ARG(out && gates && params && state && workspace, "pgx_adsr_gated_periodic: null pointer");
     PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_gated_periodic: block too long");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_adsr_gated_periodic: stride too small");
-    return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, state, workspace,
-                          detach_walk != 0);
+    return adsr_run<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, state, workspace,
+                       detach_walk != 0);
 }
 
 int pgx_adsr_gated_periodic_to(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
@@ -991,8 +1013,8 @@ int pgx_adsr_gated_periodic_to(float *out, int64_t out_stride, int batch, int64_
                   "pgx_adsr_gated_periodic_to: null pointer");
     PGX_CHECK_ARG(n < (int64_t)1 << 30, "pgx_adsr_gated_periodic_to: block too long");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_adsr_gated_periodic_to: stride too small");
-    return adsr_launch<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, const_cast<double *>(state_in),
-                          workspace, false, state_out);
+    return adsr_run<2>(out, out_stride, nullptr, 0, batch, start, n, gates, params, const_cast<double *>(state_in),
+                       workspace, false, state_out);
 }
 
 int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride, int batch,
