@@ -68,6 +68,10 @@ int pgx_stream_is_forked(void);           /* 1 between fork and join */
  *   pgx_stream_wait_detached()  the main stream waits for that work (no-op when nothing is detached)
  * A new fork waits for detached work first (there is one side stream); pgx_stream_sync covers it. */
 int pgx_stream_detach(void);
+/* pgx_stream_fork_after(event): a fork whose side stream starts behind `event` -- recorded earlier on the main stream
+ * with pgx_event_record -- instead of behind the main stream's current tail (NULL: behind nothing).  For side work that
+ * depends on nothing the main stream is doing and writes only buffers whose last main-stream reader the event covers. */
+int pgx_stream_fork_after(void *event);
 int pgx_stream_wait_detached(void);
 int pgx_stream_is_detached(void);
 

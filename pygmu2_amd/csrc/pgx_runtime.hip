@@ -250,6 +250,24 @@ int pgx_stream_fork(void) {
     return PGX_OK;
 }
 
+// A fork whose side stream does not start behind everything the main stream holds, but behind an event recorded on
+// the main stream earlier (or behind nothing: event == NULL): for side work that depends on nothing the main stream is
+// doing -- the next block's envelopes -- and writes only buffers whose last main-stream reader that event covers.  A
+// side queue that has to be woken by the main stream's CURRENT tail starts ~17 us after it; one that waits for something
+// long finished starts at once.
+int pgx_stream_fork_after(void *event) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(!r.forked, "pgx_stream_fork_after: already forked");
+    if (r.detached) {
+        if (int rc = pgx_stream_wait_detached()) return rc;
+    }
+    if (event != nullptr) PGX_HIP(hipStreamWaitEvent(r.side, (hipEvent_t)event, 0));
+    r.forked = true;
+    r.current = r.side;
+    return PGX_OK;
+}
+
 int pgx_stream_is_forked(void) { return rt().ready && rt().forked ? 1 : 0; }
 
 int pgx_stream_select(int side) {

@@ -2183,7 +2183,7 @@ struct SawBqWideShared {
     double aff[2 * NW];
     V2 tot[2][NW];
 };
-template <int NW>
+template <int NW, bool GAIN>
 __global__ void __launch_bounds__(NW * 64)
 k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *saw_tables, double *saw_state,
                       const double *coef, const double *bq_tables, double *bq_state, const float *gain,
@@ -2218,12 +2218,13 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
     const double *rows = tb + kBqRowsAt;
     V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
     int parity = 0;
-    const float *gb = gain ? gain + (int64_t)inst * gain_stride : nullptr;
+    const float *gb = GAIN ? gain + (int64_t)inst * gain_stride : nullptr;     // (GAIN: its own instantiation -- as a run-time
+                                                                                // option it cost the plain kernel 19 VGPRs and 8 %)
     for (int64_t base = 0; base < n; base += kTile, ++parity) {
         const int64_t f0 = base + (int64_t)tid * T;
         // the voice's gain (GainPE(x, gain=<PE>): float32 x float32) for these frames, asked for first
-        float gv[T];
-        if (gb != nullptr) {
+        float gv[GAIN ? T : 1];
+        if (GAIN) {
             if (f0 + T <= n && aligned16(gb + f0)) {
 #pragma unroll
                 for (int j = 0; j < T; j += 4) {
@@ -2285,9 +2286,9 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
 #pragma unroll
         for (int j = 0; j < T; ++j)
             yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
-        if (gb != nullptr) {
+        if (GAIN) {
 #pragma unroll
-            for (int j = 0; j < T; ++j) yf[j] = yf[j] * gv[j];    // gain_pe.py:104-119: the float32 product
+            for (int j = 0; j < T; ++j) yf[j] = yf[j] * gv[GAIN ? j : 0];   // gain_pe.py:104-119: the float32 product
         }
         store_frames<T>(ob, f0, n, 1, 0, yf);
         if (f0 <= n - 1 && n - 1 < f0 + T) {                      // the thread that renders the block's last frame:
@@ -3667,8 +3668,12 @@ int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n
                   "pgx_blitsaw_biquad_wide: bad argument");
     PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_blitsaw_biquad_wide: out_stride too small");
     PGX_CHECK_ARG(gain == nullptr || batch == 1 || gain_stride >= n, "pgx_blitsaw_biquad_wide: gain_stride too small");
-    hipLaunchKernelGGL(k_blitsaw_biquad_wide<4>, dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride, n,
-                       saw_tables, saw_state, coef, biquad_tables, biquad_state, gain, gain_stride);
+    if (gain != nullptr)
+        hipLaunchKernelGGL((k_blitsaw_biquad_wide<4, true>), dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
+                           n, saw_tables, saw_state, coef, biquad_tables, biquad_state, gain, gain_stride);
+    else
+        hipLaunchKernelGGL((k_blitsaw_biquad_wide<4, false>), dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
+                           n, saw_tables, saw_state, coef, biquad_tables, biquad_state, gain, gain_stride);
     PGX_LAUNCH_CHECK("k_blitsaw_biquad_wide");
     return PGX_OK;
 }

@@ -49,6 +49,7 @@ _SIGNATURES = [
     ("pgx_stream_join", _I, []),
     ("pgx_stream_is_forked", _I, []),
     ("pgx_stream_detach", _I, []),
+    ("pgx_stream_fork_after", _I, [_P]),
     ("pgx_stream_wait_detached", _I, []),
     ("pgx_stream_is_detached", _I, []),
     ("pgx_malloc", _I, [C.POINTER(_P), _Z]),

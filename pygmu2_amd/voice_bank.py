@@ -42,6 +42,7 @@ PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillat
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
 FUSE_GAIN_IN_CHAIN = False   # ... and multiplied into the voices by the oscillator -> filter kernel: measured, no gain (render_mix)
+EARLY_WALK_MAX_VOICES = 256  # ... started at once (not behind the block's oscillators) for banks up to this size
 ENVELOPE_AHEAD = True        # a bank's AdsrGatedPE(PeriodicGate) envelopes one block ahead on the side stream (render_mix)
 WIDE_SUPERSAW = True         # the bank kernel with 16 frames per thread (pgx_supersaw_wide) where its conditions hold
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
@@ -565,6 +566,8 @@ class _AdsrGatedNode(_Node):
         self.ws = None
         self.ahead = None            # (start, n, envelopes): render_ahead
         self.state_next = None       # ... which reads `state` and leaves the states after the block here
+        self.ring = []               # ... into one of three envelope buffers of its own, used in turn: [buffer, event]
+        self.ring_at = 0             #     (event: recorded behind the mix that read the buffer last; None: never used)
         self.last = None             # (start, n) of the last block handed out
 
     def _scratch(self, n):
@@ -609,11 +612,29 @@ class _AdsrGatedNode(_Node):
         stream holds so far and is left running (pgx_stream_detach)."""
         L = lib()
         gate_node = self.children["gate"]
-        out = DeviceBuffer((self.k, n, 1), np.float32)
         if self.state_next is None:
             self.state_next = DeviceBuffer(self.state.shape, self.state.dtype)
         scratch = self._scratch(n)
-        check(L.pgx_stream_fork(), "pgx_stream_fork")
+        # The walk depends on nothing the main stream is doing: it only must not overwrite an envelope buffer a mix is
+        # still reading.  With three buffers of the node's own used in turn, the last reader of the one to be written is
+        # the mix of three blocks ago, long finished: the side stream waits for THAT (an event recorded behind it,
+        # mark_consumed) instead of for the main stream's tail -- no queue to be woken (~17 us), and the walk starts as
+        # soon as the one before it has ended.  A buffer's first use starts behind the main stream's tail (it comes
+        # from the pool: its previous owner's kernels are somewhere on the main stream).
+        # (A full bank's walk -- 512 envelopes x 8 waves -- is better started behind the block's oscillators, whose SIMDs it
+        # would share from their first tile otherwise, and written to the pool's most recently freed buffer: three
+        # 98 MB buffers in turn are more than the memory-side cache holds.  137 us per block against 144.)
+        if self.k > EARLY_WALK_MAX_VOICES:
+            out, seen = DeviceBuffer((self.k, n, 1), np.float32), None
+        else:
+            if not self.ring or self.ring[0][0].shape != (self.k, n, 1):
+                self.ring = [[DeviceBuffer((self.k, n, 1), np.float32), None] for _ in range(3)]
+            self.ring_at = (self.ring_at + 1) % 3
+            out, seen = self.ring[self.ring_at]
+        if seen is None:
+            check(L.pgx_stream_fork(), "pgx_stream_fork")
+        else:
+            check(L.pgx_stream_fork_after(seen.ptr), "pgx_stream_fork_after")
         try:
             check(L.pgx_adsr_gated_periodic_to(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
                                                self.state.ptr, self.state_next.ptr, scratch.ptr),
@@ -621,6 +642,15 @@ class _AdsrGatedNode(_Node):
         finally:
             check(L.pgx_stream_detach(), "pgx_stream_detach")
         self.ahead = (start, n, out)
+
+    def mark_consumed(self, env) -> None:
+        """Called behind the launch that read `env` (a buffer take_ahead handed out): from here on the main stream is done
+        with it."""
+        for slot in self.ring:
+            if slot[0] is env:
+                if slot[1] is None:
+                    slot[1] = _dev.Event()
+                slot[1].record()
 
     def channels(self):
         return 1
@@ -856,6 +886,7 @@ class VoiceBank:
                     ch = x.shape[2]
                     out = DeviceBuffer((duration, ch), np.float32)
                     check(L.pgx_mix_batch(out.ptr, x.ptr, duration * ch, self.k, duration * ch), "pgx_mix_batch")
+                    gain.mark_consumed(g)                   # (read by the chain kernel, which is behind us too)
                     return Snippet(start, out)
             else:
                 check(L.pgx_stream_fork(), "pgx_stream_fork")
@@ -876,6 +907,8 @@ class VoiceBank:
             out = DeviceBuffer((duration, ch), np.float32)
             check(lib().pgx_gain_mix_batch(out.ptr, x.ptr, duration * ch, g.ptr, duration * gch, self.k,
                                            duration, ch, gch), "pgx_gain_mix_batch")
+            if isinstance(gain, _AdsrGatedNode):
+                gain.mark_consumed(g)
             return Snippet(start, out)
         stacked = root.render(start, duration)                   # [K][n][C]
         ch = stacked.shape[2]
