@@ -506,7 +506,9 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
     __shared__ int e_pos[WAVES][kParMaxGroups + 2];
     __shared__ unsigned char e_att[WAVES][kParMaxGroups + 2];
     const int lane = threadIdx.x & 63;
-    __builtin_amdgcn_s_setprio(3);
+    // (a walk a block ahead of the stream -- state_out is another buffer -- is nobody's critical path: it does not
+    // take instruction arbitration away from the oscillators it runs beside)
+    if (state_out == state) __builtin_amdgcn_s_setprio(3);
     const int j = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int inst = blockIdx.x;
     const pgx_adsr_params p = params[inst];
