@@ -40,6 +40,7 @@ MIN_VOICES = 4
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
+PIPELINE_FULL_SUPERSAW_BANK = True    # ... and for a bank that fills the chip (512 instances: the 17 us mix beside the next block's bank)
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
 FUSE_GAIN_IN_CHAIN = False   # ... and multiplied into the voices by the oscillator -> filter kernel: measured, no gain (render_mix)
 EARLY_WALK_MAX_VOICES = 256  # ... started at once (not behind the block's oscillators) for banks up to this size
@@ -827,8 +828,9 @@ class VoiceBank:
         root = self.root
         # (the voices-summed-on-chip bank + mix stay on one stream: with the bank one block ahead and the mix on the
         # side stream a rank's share went from 60.5 to 64.3 us -- the fork / join packets cost more than the 5 us mix)
-        if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and not root.fused()
-                and (PIPELINE_SUPERSAW_BANK or not root.banked(duration)) and duration >= 4096
+        if (PREFETCH_SUPERSAW_VOICES and isinstance(root, _SuperSawNode) and duration >= 4096
+                and (PIPELINE_FULL_SUPERSAW_BANK if root.fused()
+                     else (PIPELINE_SUPERSAW_BANK or not root.banked(duration)))
                 and not lib().pgx_stream_is_forked()):
             return self._supersaw_pipelined(start, duration)
         if isinstance(root, _GainNode) and root.gains is None:
