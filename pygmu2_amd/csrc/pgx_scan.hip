@@ -1954,46 +1954,68 @@ k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_para
 // quotient divides by it where it is small), the numerator sin(M theta_j) / P by the three-term recurrence
 // n[j+1] = 2 cos(M d) n[j] - n[j-1] (1 operation; M d = M pi inc lies within 2 d of pi/2, so the recurrence does not
 // amplify its roundings: ~1e-15 after 15 steps), the quotient with one Newton step on the reciprocal and no residual
-// correction (2^-48).  19 instruction slots per frame where saw_dirichlet_rot_body has 30.
+// correction (2^-48), one reciprocal per pair of frames.  16 instruction slots per frame where saw_dirichlet_rot_body has 30.
 // GUARD as there: the singularity test is only OR-ed together, a wave that met it runs the frames again with selects.
 template <int T, bool GUARD>
 __device__ __forceinline__ unsigned long long saw_rot_frames(double sd, double cd, double sn, double cn, double invP,
                                                              double m_over_p, double rsd, double rcd, double rsm,
                                                              double rcm, double two_cm, double (&xb)[T]) {
+    static_assert(T % 2 == 0, "frames are taken in pairs");
     unsigned long long any = 0ull;
     double n_prev = invP * sn;
     double n_cur = invP * __builtin_fma(sn, rcm, cn * rsm);
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-        double num;
-        if (j == 0) {
-            num = n_prev;
-        } else {
+    for (int j = 0; j < T; j += 2) {
+        // two frames: the denominators sin(theta_j), sin(theta_j+1) by rotation, the numerators by the recurrence
+        if (j) {
             const double s2 = __builtin_fma(sd, rcd, cd * rsd);
             cd = __builtin_fma(cd, rcd, -(sd * rsd));
             sd = s2;
-            num = n_cur;
-            if (j + 1 < T) {
-                const double nxt = __builtin_fma(two_cm, n_cur, -n_prev);
-                n_prev = n_cur;
-                n_cur = nxt;
-            }
         }
-        double y = __builtin_amdgcn_rcp(sd);
-        y = __builtin_fma(__builtin_fma(-sd, y, 1.0), y, y);
-        double blit = num * y;
-        if (GUARD) {
-            if (fabs(sd) < 1e-9) blit = m_over_p;
+        const double sd0 = sd;
+        {
+            const double s2 = __builtin_fma(sd, rcd, cd * rsd);
+            cd = __builtin_fma(cd, rcd, -(sd * rsd));
+            sd = s2;
+        }
+        const double sd1 = sd;
+        double num0, num1;
+        if (j == 0) {
+            num0 = n_prev;
+            num1 = n_cur;
         } else {
-            any |= __ballot(fabs(sd) < 1e-9);
+            num0 = __builtin_fma(two_cm, n_cur, -n_prev);
+            num1 = __builtin_fma(two_cm, num0, -n_cur);
+            n_prev = num0;
+            n_cur = num1;
         }
-        xb[j] = blit - invP;
+        // ONE reciprocal for the pair (v_rcp_f64 is a quarter-rate instruction: four slots): r = 1 / (sd0 sd1) with one
+        // Newton step, then 1 / sd0 = r sd1 and 1 / sd1 = r sd0 -- 4.5 slots per frame instead of 7.  |sin| <= 1, so the
+        // product is below 1e-9 whenever a factor is: the singularity test on the product has no false negatives (a
+        // false positive -- both factors near 3e-5 -- only sends the wave through the guarded pass).
+        const double pr = sd0 * sd1;
+        double y = __builtin_amdgcn_rcp(pr);
+        y = __builtin_fma(__builtin_fma(-pr, y, 1.0), y, y);
+        double blit0 = num0 * (y * sd1);
+        double blit1 = num1 * (y * sd0);
+        if (GUARD) {
+            // (the guarded pass: a wave that met a tiny product; each frame by its own reciprocal, the reference's test)
+            double y0 = __builtin_amdgcn_rcp(sd0), y1 = __builtin_amdgcn_rcp(sd1);
+            y0 = __builtin_fma(__builtin_fma(-sd0, y0, 1.0), y0, y0);
+            y1 = __builtin_fma(__builtin_fma(-sd1, y1, 1.0), y1, y1);
+            blit0 = fabs(sd0) < 1e-9 ? m_over_p : num0 * y0;
+            blit1 = fabs(sd1) < 1e-9 ? m_over_p : num1 * y1;
+        } else {
+            any |= __ballot(fabs(pr) < 1e-9);
+        }
+        xb[j] = blit0 - invP;
+        xb[j + 1] = blit1 - invP;
     }
     return any;
 }
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 2)                    // two waves per SIMD: 512 instances are two workgroups per CU
 k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels, const double *state,
                 double *state_out, const double *amp_scalar, int seg_tiles, const double *tables) {
     constexpr int T = kSswT, kTile = NW * 64 * T;
@@ -2155,15 +2177,15 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 if (tid == 0) sh.carry_y[v0 + u] = cn;         // every thread holds the same carry
             }
         };
-        int v = 0;
+        // (one voice at a time: two side by side -- one barrier for both scans, two instruction streams -- measured no
+        // faster and, with a reciprocal per pair of frames, no longer fit 256 registers)
 #pragma unroll 1
-        for (; v + 2 <= nv; v += 2) voices(std::integral_constant<int, 2>{}, v);
-        if (v < nv) voices(std::integral_constant<int, 1>{}, v);
+        for (int v = 0; v < nv; ++v) voices(std::integral_constant<int, 1>{}, v);
         float yf[T];
 #pragma unroll
         for (int j = 0; j < T; ++j) yf[j] = (float)(acc[j] * g);
         store_frames_tiled<T>(ob, f0, n, channels, yf);
-        if (nv <= 2) __syncthreads();                           // with more voices the carries written above are read
+        if (nv <= 1) __syncthreads();                           // with more voices the carries written above are read
                                                                 // again only after the other voices' barriers
     }
     if (frame_end == n && tid < nv) sv_out[tid * 2 + 0] = pgx::pgx_mod1(sh.phase0[tid] + (double)n * sh.tab[tid][0]);
