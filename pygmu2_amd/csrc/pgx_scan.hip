@@ -1996,20 +1996,18 @@ __device__ __forceinline__ unsigned long long saw_rot_frames(double sd, double c
         const double pr = sd0 * sd1;
         double y = __builtin_amdgcn_rcp(pr);
         y = __builtin_fma(__builtin_fma(-pr, y, 1.0), y, y);
-        double blit0 = num0 * (y * sd1);
-        double blit1 = num1 * (y * sd0);
         if (GUARD) {
             // (the guarded pass: a wave that met a tiny product; each frame by its own reciprocal, the reference's test)
             double y0 = __builtin_amdgcn_rcp(sd0), y1 = __builtin_amdgcn_rcp(sd1);
             y0 = __builtin_fma(__builtin_fma(-sd0, y0, 1.0), y0, y0);
             y1 = __builtin_fma(__builtin_fma(-sd1, y1, 1.0), y1, y1);
-            blit0 = fabs(sd0) < 1e-9 ? m_over_p : num0 * y0;
-            blit1 = fabs(sd1) < 1e-9 ? m_over_p : num1 * y1;
+            xb[j] = (fabs(sd0) < 1e-9 ? m_over_p : num0 * y0) - invP;
+            xb[j + 1] = (fabs(sd1) < 1e-9 ? m_over_p : num1 * y1) - invP;
         } else {
             any |= __ballot(fabs(pr) < 1e-9);
+            xb[j] = __builtin_fma(num0, y * sd1, -invP);           // blit - 1/P in one operation
+            xb[j + 1] = __builtin_fma(num1, y * sd0, -invP);
         }
-        xb[j] = blit0 - invP;
-        xb[j + 1] = blit1 - invP;
     }
     return any;
 }
@@ -2158,8 +2156,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 const double y_in = y;
 #pragma unroll
                 for (int j = 0; j < T; ++j) {
-                    const double z = leak[u] * y;
-                    y = z + xb[u][j];
+                    y = __builtin_fma(leak[u], y, xb[u][j]);       // (fused like the fold above: ~1e-16 per step)
                     // (the voice is not rounded to float32 before it joins the sum, as a BlitSawPE's output would be:
                     // <= 6e-8 of a voice's level each, inside this kernel's tolerance; three operations fewer per frame)
                     acc[j] = __builtin_fma(y, amp2[u], acc[j]);
@@ -2168,10 +2165,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                     const int jn = (int)(n - 1 - f0);
                     double yl = y_in;
 #pragma unroll
-                    for (int j = 0; j < T; ++j) {
-                        const double z = leak[u] * yl;
-                        yl = j <= jn ? z + xb[u][j] : yl;
-                    }
+                    for (int j = 0; j < T; ++j) yl = j <= jn ? __builtin_fma(leak[u], yl, xb[u][j]) : yl;
                     sv_out[(v0 + u) * 2 + 1] = yl;
                 }
                 if (tid == 0) sh.carry_y[v0 + u] = cn;         // every thread holds the same carry
@@ -2277,8 +2271,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         double yz[T];
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            const double z = leak * y;
-            y = z + xb[j];
+            y = __builtin_fma(leak, y, xb[j]);
             const double x = (double)(float)(y * amp2);           // (y * 2) * amp, the doubling exact
             const double yy = __builtin_fma(b0, x, ez.x);
             ez.x = __builtin_fma(na1, yy, __builtin_fma(b1, x, ez.y));
@@ -2319,8 +2312,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
             V2 z = zin;
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-                const double zz = leak * yl;
-                const double yn = zz + xb[j];
+                const double yn = __builtin_fma(leak, yl, xb[j]);
                 const double x = (double)(float)(yn * amp2);
                 const double yy = z.x + b0 * x;
                 const double z0 = (z.y + b1 * x) + na1 * yy;
