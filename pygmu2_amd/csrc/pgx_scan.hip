@@ -1906,8 +1906,10 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
 // Time segments as in k_supersaw_bank (closed-form integrator level on entering a later segment).
 constexpr int kSswT = 16;
 // per voice: [0] inc, M, P, 1/P, M/P, leak, 2*amp, (spare); [8] sin/cos(pi inc), sin/cos(M pi inc);
-// [12] (leak^16)^(2^k), k = 0..5; [18] leak^(16*64); [19] 2 cos(M pi inc); [20] lane powers [3][64]
-constexpr int kSswTabDoubles = 20 + 3 * 64;
+// [12] (leak^16)^(2^k), k = 0..5; [18] leak^(16*64); [19] 2 cos(M pi inc); [20] sin/cos of a 4096-frame tile's advance
+// pi*4096*inc and of M times that (the angles reduced exactly before the sincos); [24] lane powers [3][64]
+constexpr int kSswTabDoubles = 24 + 3 * 64;
+constexpr int kSswLanePw = 24;
 template <int NW>
 struct SswShared {
     double aff[4 * NW];                   // two images (used alternately) of two chains' wave aggregates
@@ -1933,9 +1935,9 @@ k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_para
             l = l * l;
         }
         const LanePowers lp = lane_powers(lamp, lane);
-        tab[20 + lane] = lp.lane;
-        tab[20 + 64 + lane] = lp.p16;
-        tab[20 + 128 + lane] = lp.p32;
+        tab[kSswLanePw + lane] = lp.lane;
+        tab[kSswLanePw + 64 + lane] = lp.p16;
+        tab[kSswLanePw + 128 + lane] = lp.p32;
         if (lane == 0) {
             const SawRot r = saw_rot(kt);
             tab[0] = kt.inc; tab[1] = kt.m; tab[2] = kt.P; tab[3] = kt.invP; tab[4] = kt.m / kt.P;
@@ -1945,6 +1947,17 @@ k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_para
             for (int k = 0; k < 6; ++k) tab[12 + k] = lamp[k];
             tab[18] = l;                                        // leak^(16 * 64)
             tab[19] = 2.0 * r.cm;                              // the numerator's three-term recurrence
+            // a tile's advance: 4096 * inc is exact (a power of two), M times it is taken with its rounding error
+            const double x = 4096.0 * kt.inc;
+            const double pm = kt.m * x, em = __builtin_fma(kt.m, x, -pm);
+            double st, ct, stm, ctm;
+            pgx::pgx_sincos_bounded(kPi * (x - floor(x)), st, ct);
+            pgx::pgx_sincos_bounded(kPi * ((pm - floor(pm)) + em), stm, ctm);
+            // (frac drops whole half-turns: an odd number of them flips both signs of a pair, and with M odd the pairs of
+            // theta and M theta flip together -- the quotient of the two sines never sees it)
+            const bool odd = fmod(floor(x), 2.0) != 0.0, odd_m = fmod(floor(pm), 2.0) != 0.0;
+            tab[20] = odd ? -st : st; tab[21] = odd ? -ct : ct;
+            tab[22] = odd_m ? -stm : stm; tab[23] = odd_m ? -ctm : ctm;
         }
     }
 }
@@ -2119,7 +2132,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
 #pragma unroll
                 for (int k = 0; k < 6; ++k) lamp[k] = tb[12 + k];
                 lam_wave[u] = tb[18];
-                lane_pw[u] = LanePowers{tb[20 + lane], tb[20 + 64 + lane], tb[20 + 128 + lane]};
+                lane_pw[u] = LanePowers{tb[kSswLanePw + lane], tb[kSswLanePw + 64 + lane], tb[kSswLanePw + 128 + lane]};
                 carry_y[u] = sh.carry_y[v0 + u];
                 const double ph = pgx::pgx_mod1(sh.phase0[v0 + u] + (double)(f0 + 1) * inc);
                 const double theta = kPi * ph;
@@ -2218,7 +2231,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
 #pragma unroll
     for (int k = 0; k < 6; ++k) lamp[k] = st[12 + k];
     const double lam_wave = st[18];
-    const LanePowers lane_pw{st[20 + lane], st[20 + 64 + lane], st[20 + 128 + lane]};
+    const LanePowers lane_pw{st[kSswLanePw + lane], st[kSswLanePw + 64 + lane], st[kSswLanePw + 128 + lane]};
     const double phase0 = saw_state[inst * 2 + 0];
     double carry_y = saw_state[inst * 2 + 1];
     const double b0 = coef[inst * 5 + 0], b1 = coef[inst * 5 + 1], b2 = coef[inst * 5 + 2];
@@ -2233,6 +2246,8 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
     const M2 m32 = load_m2(tb + 28 + 4 * ((lane & 31) + 1));
     const double *rows = tb + kBqRowsAt;
     V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
+    const double tile_s = st[20], tile_c = st[21], tile_sm = st[22], tile_cm = st[23];
+    double a_sd = 0.0, a_cd = 1.0, a_sn = 0.0, a_cn = 1.0;
     int parity = 0;
     const float *gb = GAIN ? gain + (int64_t)inst * gain_stride : nullptr;     // (GAIN: its own instantiation -- as a run-time
                                                                                 // option it cost the plain kernel 19 VGPRs and 8 %)
@@ -2253,11 +2268,23 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
             }
         }
         // ---- the oscillator (frames past the block's end are rendered like the others and never stored)
-        const double ph = pgx::pgx_mod1(phase0 + (double)(f0 + 1) * inc);
-        const double theta = kPi * ph;
-        double sd, cd, sn, cn;
-        pgx::pgx_sincos_bounded(theta, sd, cd);
-        pgx::pgx_sincos_bounded(m * theta, sn, cn);
+        // The anchor -- sin / cos of theta and M theta at the thread's first frame -- is evaluated for the first tile and
+        // turned by a tile's advance (table: angles reduced exactly) for every further one: 8 operations instead of two
+        // sincos (~60); a block's 12 tiles add ~1e-15.
+        if (base == 0) {
+            const double ph = pgx::pgx_mod1(phase0 + (double)(f0 + 1) * inc);
+            const double theta = kPi * ph;
+            pgx::pgx_sincos_bounded(theta, a_sd, a_cd);
+            pgx::pgx_sincos_bounded(m * theta, a_sn, a_cn);
+        } else {
+            const double s2 = __builtin_fma(a_sd, tile_c, a_cd * tile_s);
+            a_cd = __builtin_fma(a_cd, tile_c, -(a_sd * tile_s));
+            a_sd = s2;
+            const double n2 = __builtin_fma(a_sn, tile_cm, a_cn * tile_sm);
+            a_cn = __builtin_fma(a_cn, tile_cm, -(a_sn * tile_sm));
+            a_sn = n2;
+        }
+        const double sd = a_sd, cd = a_cd, sn = a_sn, cn = a_cn;
         double xb[T];
         if (saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb))
             saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);

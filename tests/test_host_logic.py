@@ -465,7 +465,7 @@ def test_segment_planner_of_the_wide_bank():
                 tiles = -(-n // 4096)
                 assert 1 <= k <= tiles
                 assert (k - 1) * -(-tiles // k) < tiles          # no empty segment
-    assert lib.pgx_supersaw_wide_table_bytes(3, 7) == 3 * 7 * 212 * 8
+    assert lib.pgx_supersaw_wide_table_bytes(3, 7) == 3 * 7 * 216 * 8
 
 
 def test_fft_convolution_sizes():
