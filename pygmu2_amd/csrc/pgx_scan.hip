@@ -1915,8 +1915,7 @@ struct SswShared {
     double aff[4 * NW];                   // two images (used alternately) of two chains' wave aggregates
     double carry_y[kSsMaxVoices];
     double phase0[kSsMaxVoices];
-    double tab[kSsMaxVoices][kSswTabDoubles];
-};
+};                                        // (the voices' tables and the threads' anchors: dynamic LDS, sized by the voice count)
 
 __global__ void __launch_bounds__(64)
 k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_params *params) {
@@ -2025,12 +2024,20 @@ __device__ __forceinline__ unsigned long long saw_rot_frames(double sd, double c
     return any;
 }
 
+struct alignas(16) SswAnchor {
+    double sd, cd, sn, cn;
+};
+constexpr int kSswAnchorVoices = 8;        // anchors are kept for banks of up to this many voices per instance (64 KB of LDS)
+
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2)                    // two waves per SIMD: 512 instances are two workgroups per CU
 k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels, const double *state,
-                double *state_out, const double *amp_scalar, int seg_tiles, const double *tables) {
+                double *state_out, const double *amp_scalar, int seg_tiles, const double *tables, int keep_anchors) {
     constexpr int T = kSswT, kTile = NW * 64 * T;
     __shared__ SswShared<NW> sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ssw_dynamic[];
+    double *tabs = reinterpret_cast<double *>(ssw_dynamic);                     // [nv][kSswTabDoubles]
+    SswAnchor *anchors = keep_anchors ? reinterpret_cast<SswAnchor *>(tabs + nv * kSswTabDoubles) : nullptr;   // [nv][threads]
     const int tid = threadIdx.x, lane = tid & 63;
     const int inst = blockIdx.x;
     const int64_t tile_first = (int64_t)blockIdx.y * seg_tiles;
@@ -2048,7 +2055,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
     const double st_phase = sv[vi * 2 + 0], st_level = sv[vi * 2 + 1];
     {
         const double *tab = tables + (int64_t)inst * nv * kSswTabDoubles;
-        double *dst = &sh.tab[0][0];
+        double *dst = tabs;
         const int total = nv * kSswTabDoubles;
         constexpr int U = 4;
         for (int base = 0; base < total; base += U * NW * 64) {
@@ -2076,7 +2083,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         // one wave per voice, the harmonics over its lanes
         const int wave = tid >> 6;
         for (int v = wave; v < nv; v += NW) {
-            const double *tb = sh.tab[v];
+            const double *tb = tabs + v * kSswTabDoubles;
             const double ph_b = sh.phase0[v];
             const double ph_a = pgx::pgx_mod1(ph_b + (double)frame_first * tb[0]);
             const int K = ((int)tb[1] - 1) / 2;
@@ -2123,7 +2130,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
             LanePowers lane_pw[V];
 #pragma unroll
             for (int u = 0; u < V; ++u) {
-                const double *tb = sh.tab[v0 + u];
+                const double *tb = tabs + (v0 + u) * kSswTabDoubles;
                 const double inc = tb[0], m = tb[1], invP = tb[3], m_over_p = tb[4], two_cm = tb[19];
                 leak[u] = tb[5];
                 amp2[u] = tb[6];
@@ -2134,11 +2141,26 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 lam_wave[u] = tb[18];
                 lane_pw[u] = LanePowers{tb[kSswLanePw + lane], tb[kSswLanePw + 64 + lane], tb[kSswLanePw + 128 + lane]};
                 carry_y[u] = sh.carry_y[v0 + u];
-                const double ph = pgx::pgx_mod1(sh.phase0[v0 + u] + (double)(f0 + 1) * inc);
-                const double theta = kPi * ph;
+                // The anchor -- sin / cos of theta and M theta at the thread's first frame: evaluated for the workgroup's
+                // first tile, kept per (voice, thread) in dynamic LDS and turned by a tile's advance for every further
+                // tile (16 instruction slots instead of ~60).  anchors == nullptr (more voices than the LDS holds
+                // anchors for): evaluated every tile.
                 double sd, cd, sn, cn;
-                pgx::pgx_sincos_bounded(theta, sd, cd);
-                pgx::pgx_sincos_bounded(m * theta, sn, cn);
+                SswAnchor *anc = anchors ? anchors + (v0 + u) * (NW * 64) + tid : nullptr;
+                if (anc == nullptr || base == frame_first) {
+                    const double ph = pgx::pgx_mod1(sh.phase0[v0 + u] + (double)(f0 + 1) * inc);
+                    const double theta = kPi * ph;
+                    pgx::pgx_sincos_bounded(theta, sd, cd);
+                    pgx::pgx_sincos_bounded(m * theta, sn, cn);
+                } else {
+                    const SswAnchor a = *anc;
+                    const double ts = tb[20], tc = tb[21], tsm = tb[22], tcm = tb[23];
+                    sd = __builtin_fma(a.sd, tc, a.cd * ts);
+                    cd = __builtin_fma(a.cd, tc, -(a.sd * ts));
+                    sn = __builtin_fma(a.sn, tcm, a.cn * tsm);
+                    cn = __builtin_fma(a.cn, tcm, -(a.sn * tsm));
+                }
+                if (anc != nullptr) *anc = SswAnchor{sd, cd, sn, cn};
                 if (saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]))
                     saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]);
                 double f = 0.0;
@@ -2195,7 +2217,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
         if (nv <= 1) __syncthreads();                           // with more voices the carries written above are read
                                                                 // again only after the other voices' barriers
     }
-    if (frame_end == n && tid < nv) sv_out[tid * 2 + 0] = pgx::pgx_mod1(sh.phase0[tid] + (double)n * sh.tab[tid][0]);
+    if (frame_end == n && tid < nv) sv_out[tid * 2 + 0] = pgx::pgx_mod1(sh.phase0[tid] + (double)n * tabs[tid * kSswTabDoubles]);
     PGX_SS_STAMP(15);
 }
 
@@ -3830,12 +3852,13 @@ int pgx_supersaw_wide_tables(double *tables, int batch, int nvoices, double samp
 // How many time segments: the count with the smallest estimated makespan.  Measured on MI355X (tools/ssw_probe.py,
 // tools/microbench/ss_phases.hip): a 4096-frame tile of 7 voices takes a workgroup 9.8 us when it has its CU to
 // itself (one wave per SIMD), 15.4 us for two workgroups sharing a CU (x1.57), ~x2.25 for three, x0.75 per
-// workgroup beyond; entering a later segment costs the tables (0.9 us) and the closed-form carries (1.9 us per round
-// of four voices) against 1.4 us per voice and tile -- 0.5 of a tile for 7 voices, 2 tiles for a lone oscillator;
-// taken a quarter higher (a plan with more segments has to win clearly).
+// workgroup beyond (with the anchors kept in LDS a tile after the first is 7.9 us: 1.13 us per voice); entering a
+// segment costs the tables (0.9 us), the closed-form carries (1.9 us per round of four voices) and the anchor sines of
+// its first tile (0.28 us per voice) -- 0.85 of a tile for 7 voices, 2.7 tiles for a lone oscillator; taken a
+// quarter higher (a plan with more segments has to win clearly).
 int pgx_supersaw_wide_segments(int batch, int nvoices, int64_t n) {
     if (batch <= 0 || n <= 0 || nvoices <= 0) return 1;
-    const double entry = 1.25 * (0.9 + 1.9 * (double)((nvoices + 3) / 4)) / (1.4 * (double)nvoices);
+    const double entry = 1.25 * (0.9 + 1.9 * (double)((nvoices + 3) / 4) + 0.28 * (double)nvoices) / (1.13 * (double)nvoices);
     constexpr int64_t tile = 4 * 64 * kSswT;
     const int64_t tiles = pgx::ceil_div(n, tile);
     static const int forced = getenv("PGX_SSW_SEGS") ? atoi(getenv("PGX_SSW_SEGS")) : 0;      // experiments
@@ -3870,8 +3893,16 @@ int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, in
     const int64_t tiles = pgx::ceil_div(n, tile);
     const int nseg = pgx_supersaw_wide_segments(batch, nvoices, n);
     const int seg_tiles = (int)pgx::ceil_div(tiles, nseg);
-    hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(4 * 64), 0, pgx::stream(), out, out_stride, nvoices,
-                       n, channels, state_in, state_out, amp_scalar, seg_tiles, tables);
+    const int keep_anchors = nvoices <= kSswAnchorVoices ? 1 : 0;
+    // dynamic LDS: the voices' tables (1.7 KB each) and, for up to 8 voices, the threads' anchors (8 KB per voice): 69 KB
+    // for 7 voices -- two workgroups per CU
+    const size_t lds = (size_t)nvoices * kSswTabDoubles * sizeof(double) +
+                       (keep_anchors ? (size_t)nvoices * 4 * 64 * sizeof(SswAnchor) : 0);
+    if (sizeof(SswShared<4>) + lds > 64 * 1024)
+        PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_supersaw_wide<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(4 * 64), lds, pgx::stream(), out, out_stride,
+                       nvoices, n, channels, state_in, state_out, amp_scalar, seg_tiles, tables, keep_anchors);
     PGX_LAUNCH_CHECK("k_supersaw_wide");
     return PGX_OK;
 }

@@ -60,9 +60,11 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(k_supersaw_wide_tables, dim3(batch), dim3(64), 0, 0, dtw, nv, 48000.0, dp);
         const int64_t tiles_w = (n + 4095) / 4096;
         seg_tiles_w = (int)((tiles_w + nseg - 1) / nseg);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_supersaw_wide<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)nv * (256 * 32 + kSswTabDoubles * 8)));
         for (int rep = 0; rep < 3; ++rep)
-            hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(256), 0, 0, out, n, nv, n, 1,
-                               (const double *)ds, ds2, (const double *)da, seg_tiles_w, (const double *)dtw);
+            hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(256), (size_t)nv * (256 * 32 + kSswTabDoubles * 8), 0, out, n, nv, n, 1,
+                               (const double *)ds, ds2, (const double *)da, seg_tiles_w, (const double *)dtw, 1);
     } else
     for (int rep = 0; rep < 3; ++rep)
         hipLaunchKernelGGL(k_supersaw_bank<8>, dim3(batch, nseg), dim3(512), 0, 0, out, n, nv, n, 1, 48000.0, dp,
