@@ -637,11 +637,15 @@ Tables tables_of(const cplx *spectrum, const ConvGeom &g, int fir_channels) {
 }
 
 // LDS images beyond the 64 KB a kernel gets by default (the 2^18-point geometry)
+// (per kernel once, for the largest geometry: the call costs tens of microseconds of host time)
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
+    static size_t allowed = 64 * 1024;
+    if (bytes > allowed) {
         PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)bytes));
+        allowed = bytes;
+    }
     return PGX_OK;
 }
 

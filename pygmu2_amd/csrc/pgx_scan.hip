@@ -3898,9 +3898,16 @@ int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, in
     // for 7 voices -- two workgroups per CU
     const size_t lds = (size_t)nvoices * kSswTabDoubles * sizeof(double) +
                        (keep_anchors ? (size_t)nvoices * 4 * 64 * sizeof(SswAnchor) : 0);
-    if (sizeof(SswShared<4>) + lds > 64 * 1024)
+    // (once: the call costs tens of microseconds of host time -- per launch it made a rank's 64-instance block
+    // host-bound, 48 -> 86 us)
+    static bool lds_allowed = false;
+    if (!lds_allowed) {
+        const size_t most = (size_t)kSswAnchorVoices * (kSswTabDoubles * sizeof(double) + 4 * 64 * sizeof(SswAnchor));
+        const size_t plain = (size_t)kSsMaxVoices * kSswTabDoubles * sizeof(double);
         PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_supersaw_wide<4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(most > plain ? most : plain)));
+        lds_allowed = true;
+    }
     hipLaunchKernelGGL(k_supersaw_wide<4>, dim3(batch, nseg), dim3(4 * 64), lds, pgx::stream(), out, out_stride,
                        nvoices, n, channels, state_in, state_out, amp_scalar, seg_tiles, tables, keep_anchors);
     PGX_LAUNCH_CHECK("k_supersaw_wide");
