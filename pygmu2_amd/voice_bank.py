@@ -37,6 +37,10 @@ from .snippet import Snippet
 from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
+LADDER_WINDOWS = True         # a ladder bank directly under the mix, streamed in equal blocks: several blocks per launch
+LADDER_WINDOW_FIRST = 2       # ... 2, then 4, then 8 blocks
+LADDER_WINDOW_MAX = 8
+LADDER_WINDOW_FRAMES = 1 << 20   # ... and at most this many frames
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
@@ -52,6 +56,19 @@ FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from whic
 
 def _is_pe(x) -> bool:
     return isinstance(x, ProcessingElement)
+
+
+class _Rows:
+    """Frames [offset, offset + n) of every voice of a [K][total][channels] buffer: what a node that renders several
+    blocks at once hands out per block (`.ptr` at the first voice's first frame, `.stride` elements from voice to voice)."""
+    __slots__ = ("buf", "ptr", "shape", "stride")
+
+    def __init__(self, buf, offset: int, n: int):
+        k, total, ch = buf.shape
+        self.buf = buf
+        self.ptr = buf.offset_ptr(offset * ch)
+        self.shape = (k, n, ch)
+        self.stride = total * ch
 
 
 class _Node:
@@ -430,6 +447,67 @@ class _LadderNode(_Node):
         self.settle = 0 if min(settles) == 0 else max(settles)     # one warm-up length for the batch
         self.accurate = max(pe._accurate_frames() for pe in pes) if self.settle else 0
         self.ahead = None          # (start, n, input buffer, (state copy, last_end)) rendered ahead of the caller
+        self.is_root = False       # directly under the bank's mix: may hand out rows of a window (VoiceBank.__init__)
+        self.win = None            # [first, end, n, buffer, served, (ladder state, oscillator state, last_end)]
+        self.last = None           # (start, n) of the last block handed out
+        self.grow = LADDER_WINDOW_FIRST
+
+    # ---- windows (root node only).  A lane of k_ladder_segments integrates 1024 warm-up samples to emit its share of the
+    # block -- 94 frames of a 48 000-frame block of 64 instances: 92 % of the work is warm-up.  A stream of equal blocks
+    # is therefore rendered several blocks at a time (2, 4, 8: the share per lane grows, the warm-up does not) and handed
+    # out block by block as rows of that window.  A pull that is not the next block puts the states back to the
+    # window's start and renders the consumed part again, quietly (exact: the same kernels over the same frames).
+    def _settle_window(self) -> None:
+        win, self.win = self.win, None
+        if win is None:
+            return
+        first, end, n, buf, served, (ladder_state, osc_state, osc_last_end) = win
+        if served >= end:
+            return                                       # consumed to the last frame: the states are already there
+        self._forget_ahead(restore=False)
+        src = self.children["source"]
+        check(lib().pgx_memcpy_d2d(self.state.ptr, ladder_state.ptr, ladder_state.nbytes), "pgx_memcpy_d2d")
+        check(lib().pgx_memcpy_d2d(src.state.ptr, osc_state.ptr, osc_state.nbytes), "pgx_memcpy_d2d")
+        src.last_end = osc_last_end
+        if served > first:
+            self._render_now(first, served - first)
+
+    def render(self, start, n):
+        win = self.win
+        if win is not None:
+            if start == win[4] and n == win[2] and start + n <= win[1]:
+                win[4] = start + n
+                self.last = (start, n)
+                return _Rows(win[3], start - win[0], n)
+            self._settle_window()
+        streaming = self.last == (start - n, n)
+        self.last = (start, n)
+        src = self.children["source"]
+        if (LADDER_WINDOWS and self.is_root and streaming and n >= 4096 and self.state is not None
+                and isinstance(src, (_SuperSawNode, _BlitSawNode)) and not lib().pgx_stream_is_forked()):
+            blocks = max(1, min(self.grow, LADDER_WINDOW_FRAMES // n))
+            if blocks > 1:
+                self.grow = min(self.grow * 2, LADDER_WINDOW_MAX)
+                if self.ahead is not None and not (self.ahead[0] == start and self.ahead[1] == n * blocks):
+                    self._forget_ahead(restore=True)
+                L = lib()
+                snap = (DeviceBuffer(self.state.shape, self.state.dtype), DeviceBuffer(src.state.shape, src.state.dtype))
+                check(L.pgx_memcpy_d2d(snap[0].ptr, self.state.ptr, snap[0].nbytes), "pgx_memcpy_d2d")
+                if self.ahead is not None:               # the oscillators already ran on: their states before that
+                    check(L.pgx_memcpy_d2d(snap[1].ptr, self.ahead[3][0].ptr, snap[1].nbytes), "pgx_memcpy_d2d")
+                    osc_last_end = self.ahead[3][1]
+                else:
+                    check(L.pgx_memcpy_d2d(snap[1].ptr, src.state.ptr, snap[1].nbytes), "pgx_memcpy_d2d")
+                    osc_last_end = src.last_end
+                big = self._render_now(start, n * blocks)
+                from . import look_ahead as _look_ahead
+                _look_ahead.STATS["window_frames"] += n * blocks          # (bench.py: frames rendered vs frames counted)
+                _look_ahead.STATS["windows"] += 1
+                self.win = [start, start + n * blocks, n, big, start + n, (snap[0], snap[1], osc_last_end)]
+                return _Rows(big, 0, n)
+        else:
+            self.grow = LADDER_WINDOW_FIRST
+        return self._render_now(start, n)
 
     def _forget_ahead(self, restore: bool) -> None:
         ahead, self.ahead = self.ahead, None
@@ -440,6 +518,9 @@ class _LadderNode(_Node):
             src.last_end = last_end
 
     def reset(self):
+        self.win = None
+        self.last = None
+        self.grow = LADDER_WINDOW_FIRST
         self._forget_ahead(restore=False)            # the oscillators start over anyway
         super().reset()
         if self.state is not None:
@@ -448,7 +529,7 @@ class _LadderNode(_Node):
     def channels(self):
         return self.children["source"].channels()
 
-    def render(self, start, n):
+    def _render_now(self, start, n):
         L = lib()
         src = self.children["source"]
         x = None
@@ -792,6 +873,8 @@ class VoiceBank:
     def __init__(self, inputs):
         self.k = len(inputs)
         self.root = _build(list(inputs))
+        if isinstance(self.root, _LadderNode):
+            self.root.is_root = True
 
     def reset(self) -> None:
         self.root.reset()
@@ -912,10 +995,10 @@ class VoiceBank:
             if isinstance(gain, _AdsrGatedNode):
                 gain.mark_consumed(g)
             return Snippet(start, out)
-        stacked = root.render(start, duration)                   # [K][n][C]
+        stacked = root.render(start, duration)                   # [K][n][C], or rows of a window (_Rows)
         ch = stacked.shape[2]
         out = DeviceBuffer((duration, ch), np.float32)
-        check(lib().pgx_mix_batch(out.ptr, stacked.ptr, duration * ch, self.k, duration * ch),
+        check(lib().pgx_mix_batch(out.ptr, stacked.ptr, getattr(stacked, "stride", duration * ch), self.k, duration * ch),
               "pgx_mix_batch")
         return Snippet(start, out)
 

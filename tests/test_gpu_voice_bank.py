@@ -281,3 +281,38 @@ def test_envelopes_one_block_ahead_change_nothing(monkeypatch, gain_in_chain):
     assert armed >= 7 and none == 0
     for a, b in zip(got, want):
         assert np.array_equal(a, b), float(np.max(np.abs(a - b)))
+
+
+def test_ladder_bank_windows_hand_out_the_block_by_block_samples(monkeypatch):
+    """A C4 bank streamed in equal blocks renders 2, 4, 8 blocks per ladder launch and hands out rows of that window
+    (voice_bank.LADDER_WINDOWS); a seek inside a window, another block length and a restart put the states back.
+    Against the same bank block by block: the time-segmented ladder's bound (<= 1e-6 of peak; its segments fall
+    elsewhere in a longer render)."""
+    from pygmu2_amd import voice_bank
+    from pygmu2_amd.sharding import c4_voice
+    pg.set_sample_rate(48000)
+    n = 8192
+    blocks = ([(i * n, n) for i in range(9)]                      # windows of 2, 4, (8: left after 2 of its blocks)
+              + [(9 * n + 100, n), (10 * n + 100, n), (11 * n + 100, n)]          # a seek inside the window
+              + [(12 * n + 100, 5000), (12 * n + 5100, 5000), (12 * n + 10100, 5000)]    # another block length
+              + [(0, n), (n, n), (2 * n, n)])                                    # and from the start again
+
+    def run(windows):
+        monkeypatch.setattr(voice_bank, "LADDER_WINDOWS", windows)
+        mix = pg.MixPE(*[c4_voice(pg, i) for i in range(0, 64, 4)])
+        r = pg.NullRenderer(sample_rate=48000)
+        r.set_source(mix)
+        r.start()
+        outs, opened = [], 0
+        for s, m in blocks:
+            outs.append(mix.render(s, m).data.copy())
+            opened += mix._voice_bank().root.win is not None
+        r.stop()
+        return outs, opened
+
+    got, opened = run(True)
+    want, none = run(False)
+    assert opened >= 8 and none == 0
+    for a, b in zip(got, want):
+        peak = float(np.max(np.abs(b)))
+        assert a.shape == b.shape and float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak
