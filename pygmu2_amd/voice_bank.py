@@ -37,6 +37,11 @@ from .snippet import Snippet
 from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
+BANK_WINDOWS = True           # a small bank streamed in equal blocks: 2, 4, 8 blocks per render, handed out as rows (VoiceBank)
+BANK_WINDOW_FIRST = 2
+BANK_WINDOW_MAX = 8
+BANK_WINDOW_FRAMES = 1 << 20
+BANK_WINDOW_MAX_VOICES = 255  # (a bank that fills the chip gains nothing: its launches are long)
 LADDER_WINDOWS = True         # a ladder bank directly under the mix, streamed in equal blocks: several blocks per launch
 LADDER_WINDOW_FIRST = 2       # ... 2, then 4, then 8 blocks
 LADDER_WINDOW_MAX = 8
@@ -84,6 +89,31 @@ class _Node:
         for c in self.children.values():
             c.reset()
 
+    # ---- what VoiceBank's windows need of a node: its carried state by name, and a way to come to rest
+    _STATE = ()                  # attributes (DeviceBuffers, numbers, None) that make up the carried state
+
+    def quiesce(self) -> None:
+        """Anything rendered ahead of the stream is dropped: the states are where the last block handed out left them."""
+
+    def snapshot(self) -> dict:
+        snap = {}
+        for name in self._STATE:
+            value = getattr(self, name)
+            if isinstance(value, DeviceBuffer):
+                twin = DeviceBuffer(value.shape, value.dtype)
+                check(lib().pgx_memcpy_d2d(twin.ptr, value.ptr, value.nbytes), "pgx_memcpy_d2d")
+                value = twin
+            snap[name] = value
+        return snap
+
+    def restore(self, snap: dict) -> None:
+        for name, value in snap.items():
+            mine = getattr(self, name)
+            if isinstance(value, DeviceBuffer) and isinstance(mine, DeviceBuffer) and mine.shape == value.shape:
+                check(lib().pgx_memcpy_d2d(mine.ptr, value.ptr, value.nbytes), "pgx_memcpy_d2d")
+            else:
+                setattr(self, name, value)
+
     def channels(self) -> int:
         raise NotImplementedError
 
@@ -112,6 +142,8 @@ class _SineNode(_Node):
 
 
 class _BlitSawNode(_Node):
+    _STATE = ("state", "last_end")
+
     def __init__(self, pes):
         super().__init__(pes, {})
         rec = np.zeros(self.k, dtype=_dev.BLITSAW_PARAMS)
@@ -196,6 +228,13 @@ class _SuperSawNode(_Node):
     (a rank's share of a sharded mix): the oscillators of all instances in one launch (`_voices`), then the
     ordered voice sum.  When the node feeds the bank's mix directly VoiceBank pipelines the two (see
     VoiceBank._supersaw_pipelined): `ahead` then holds the oscillator samples of the block after the last one."""
+
+    _STATE = ("state", "last_end")
+
+    def quiesce(self):
+        self._forget_ahead(restore=True)
+        if self.ahead_bank is not None:
+            self._forget_bank_ahead(restore=True)
 
     def __init__(self, pes):
         super().__init__(pes, {})
@@ -356,6 +395,8 @@ class _SuperSawNode(_Node):
 
 
 class _BiquadNode(_Node):
+    _STATE = ("state",)
+
     def __init__(self, pes, children):
         super().__init__(pes, children)
         coef = np.array([rbj_coefficients(pe._mode, pe._frequency, pe._q, pe._gain_db, self.sr)
@@ -433,6 +474,12 @@ class _LadderNode(_Node):
     goes through the ladder on the main stream, the oscillators of block k+1 are rendered on the side stream.
     The speculation is undone exactly if the next pull is not the next block: the oscillator states are
     snapshot before it and copied back."""
+
+    _STATE = ("state",)
+
+    def quiesce(self):
+        self._settle_window()
+        self._forget_ahead(restore=True)
 
     def __init__(self, pes, children):
         super().__init__(pes, children)
@@ -579,6 +626,8 @@ class _CombNode(_Node):
     """Bank of CombPEs with scalar frequency and feedback: every voice's D * C polyphase chains in one launch
     (two when the block is long enough to be cut into time segments), per-voice delay / feedback / ring."""
 
+    _STATE = ("ring", "total", "parity")
+
     def __init__(self, pes, children):
         super().__init__(pes, children)
         rec = np.concatenate([pe._param_record() for pe in pes])
@@ -637,6 +686,11 @@ class _GateNode(_Node):
 
 
 class _AdsrGatedNode(_Node):
+    _STATE = ("state", "last")
+
+    def quiesce(self):
+        self.forget_ahead()
+
     def __init__(self, pes, children):
         super().__init__(pes, children)
         rec = np.zeros(self.k, dtype=_dev.ADSR_PARAMS)
@@ -875,9 +929,77 @@ class VoiceBank:
         self.root = _build(list(inputs))
         if isinstance(self.root, _LadderNode):
             self.root.is_root = True
+        self.win = None              # [first, end, n, mixed window (Snippet), served, [(node, snapshot)]]
+        self.last = None             # (start, n) of the last block handed out
+        self.grow = BANK_WINDOW_FIRST
 
     def reset(self) -> None:
+        self.win = None
+        self.last = None
+        self.grow = BANK_WINDOW_FIRST
         self.root.reset()
+
+    # ---- windows.  A small bank's block (a rank's share of a sharded mix: 64 voices) is a handful of launches whose
+    # fixed parts -- launch, per-workgroup tables and carries, the first tile's anchor sines, the gaps between dependent
+    # kernels -- are as long as the work itself.  A stream of equal blocks is therefore rendered 2, 4, 8 blocks at a
+    # time and handed out block by block as rows of the mixed window (look_ahead.py does the same for PE graphs; a bank
+    # keeps its states in its nodes, so the snapshot is taken there).  A pull that is not the next block puts every
+    # node's state back to the window's start and renders the consumed part again, quietly.
+    def _nodes(self):
+        found, stack = [], [self.root]
+        while stack:
+            node = stack.pop()
+            found.append(node)
+            stack.extend(node.children.values())
+        return found
+
+    def _settle_window(self) -> None:
+        win, self.win = self.win, None
+        if win is None:
+            return
+        first, end, n, big, served, snaps = win
+        if served >= end:
+            return                                       # consumed to the last frame: the states are already there
+        for node in self._nodes():
+            node.quiesce()
+        for node, snap in snaps:
+            node.restore(snap)
+        if served > first:
+            self._render_mix_now(first, served - first)
+
+    def render_mix(self, start: int, duration: int) -> Snippet:
+        win = self.win
+        if win is not None:
+            if start == win[4] and duration == win[2] and start + duration <= win[1]:
+                win[4] = start + duration
+                self.last = (start, duration)
+                return Snippet.window_rows(start, win[3].dev, start - win[0], duration)
+            self._settle_window()
+        streaming = self.last == (start - duration, duration)
+        self.last = (start, duration)
+        # (SuperSaw banks below the size that fills the chip: measured 44 -> 23 us per block for a rank's 64 instances,
+        # 62 -> 42 for 128.  Not 256 and more -- rendered one block ahead already, a window ahead is too much thrown away
+        # when the stream ends: 97 -> 155 us; not the C5 graph -- its envelope walk and mixes do not shrink with the
+        # block, 56 -> 93 us for 64 voices.  A ladder root has windows of its own.)
+        if (BANK_WINDOWS and streaming and self.k <= BANK_WINDOW_MAX_VOICES and duration >= 4096
+                and isinstance(self.root, _SuperSawNode) and not self.root.fused()
+                and not lib().pgx_stream_is_forked()):
+            blocks = max(1, min(self.grow, BANK_WINDOW_FRAMES // duration))
+            if blocks > 1:
+                self.grow = min(self.grow * 2, BANK_WINDOW_MAX)
+                nodes = self._nodes()
+                for node in nodes:
+                    node.quiesce()
+                snaps = [(node, node.snapshot()) for node in nodes if node._STATE]
+                big = self._render_mix_now(start, duration * blocks)
+                from . import look_ahead as _look_ahead
+                _look_ahead.STATS["window_frames"] += duration * blocks
+                _look_ahead.STATS["windows"] += 1
+                self.win = [start, start + duration * blocks, duration, big, start + duration, snaps]
+                return Snippet.window_rows(start, big.dev, 0, duration)
+        elif not streaming:
+            self.grow = BANK_WINDOW_FIRST
+        return self._render_mix_now(start, duration)
 
     def _supersaw_pipelined(self, start: int, n: int) -> Snippet:
         """A bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8 -- or all 512).
@@ -907,7 +1029,7 @@ class VoiceBank:
             check(L.pgx_stream_join(), "pgx_stream_join")
         return Snippet(start, out)
 
-    def render_mix(self, start: int, duration: int) -> Snippet:
+    def _render_mix_now(self, start: int, duration: int) -> Snippet:
         root = self.root
         # (the voices-summed-on-chip bank + mix stay on one stream: with the bank one block ahead and the mix on the
         # side stream a rank's share went from 60.5 to 64.3 us -- the fork / join packets cost more than the 5 us mix)
