@@ -960,16 +960,22 @@ int adsr_run(float *out, int64_t out_stride, const float *ctl, int64_t ctl_strid
              bool detach_walk = false, double *state_out = nullptr) {
     constexpr int64_t kParFrames = (int64_t)kParMaxGroups * kGroupChunks * 64;
     static const bool chunk_on = !(getenv("PGX_ADSR_CHUNK") && atoi(getenv("PGX_ADSR_CHUNK")) == 0);
-    if (MODE == 1 || !chunk_on || detach_walk || batch > kParWalkBatch || n <= kParFrames)
+    if (MODE == 1 || !chunk_on || batch > kParWalkBatch || n <= kParFrames)
         return adsr_launch<MODE>(out, out_stride, ctl, ctl_stride, batch, start, n, gates, params, state, workspace,
                                  detach_walk, state_out);
     double *carried = state_out ? state_out : state;
+    if (detach_walk) {
+        // the caller joins: every chunk's edge search and walk go to the side stream (the edge search of a chunk needs the
+        // state its predecessor's walk leaves, so it cannot stay on the main stream as it does for a single piece)
+        if (int rc = pgx_stream_fork()) return rc;
+    }
     for (int64_t pos = 0; pos < n; pos += kParFrames) {
         const int64_t len = n - pos < kParFrames ? n - pos : kParFrames;
         if (int rc = adsr_launch<MODE>(out + pos, out_stride, ctl ? ctl + pos : nullptr, ctl_stride, batch, start + pos, len,
                                        gates, params, pos == 0 ? state : carried, workspace, false, carried))
             return rc;
     }
+    if (detach_walk) return pgx_stream_select(0);
     return PGX_OK;
 }
 

@@ -19,6 +19,8 @@ falls back to per-input rendering.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import device as _dev
@@ -38,6 +40,7 @@ from .super_saw_pe import SuperSawPE
 
 MIN_VOICES = 4
 BANK_WINDOWS = True           # a small bank streamed in equal blocks: 2, 4, 8 blocks per render, handed out as rows (VoiceBank)
+BANK_WINDOWS_ANY_ROOT = os.environ.get("PGX_BANK_WINDOWS_ANY_ROOT", "0") == "1"     # experiments (C5: measured slower)
 BANK_WINDOW_FIRST = 2
 BANK_WINDOW_MAX = 8
 BANK_WINDOW_FRAMES = 1 << 20
@@ -982,7 +985,7 @@ class VoiceBank:
         # when the stream ends: 97 -> 155 us; not the C5 graph -- its envelope walk and mixes do not shrink with the
         # block, 56 -> 93 us for 64 voices.  A ladder root has windows of its own.)
         if (BANK_WINDOWS and streaming and self.k <= BANK_WINDOW_MAX_VOICES and duration >= 4096
-                and isinstance(self.root, _SuperSawNode) and not self.root.fused()
+                and (isinstance(self.root, _SuperSawNode) and not self.root.fused() or BANK_WINDOWS_ANY_ROOT)
                 and not lib().pgx_stream_is_forked()):
             blocks = max(1, min(self.grow, BANK_WINDOW_FRAMES // duration))
             if blocks > 1:
