@@ -44,7 +44,7 @@ BANK_WINDOWS_ANY_ROOT = os.environ.get("PGX_BANK_WINDOWS_ANY_ROOT", "0") == "1" 
 BANK_WINDOW_FIRST = 2
 BANK_WINDOW_MAX = 8
 BANK_WINDOW_FRAMES = 1 << 20
-BANK_WINDOW_MAX_VOICES = 255  # (a bank that fills the chip gains nothing: its launches are long)
+BANK_WINDOW_MAX_VOICES = 256  # (a bank that fills the chip gains nothing: its launches are long)
 LADDER_WINDOWS = True         # a ladder bank directly under the mix, streamed in equal blocks: several blocks per launch
 LADDER_WINDOW_FIRST = 2       # ... 2, then 4, then 8 blocks
 LADDER_WINDOW_MAX = 8
@@ -59,7 +59,8 @@ EARLY_WALK_MAX_VOICES = 256  # ... started at once (not behind the block's oscil
 ENVELOPE_AHEAD = True        # a bank's AdsrGatedPE(PeriodicGate) envelopes one block ahead on the side stream (render_mix)
 WIDE_SUPERSAW = True         # the bank kernel with 16 frames per thread (pgx_supersaw_wide) where its conditions hold
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
-FUSED_SUPERSAW_MIN = 256     # SuperSaw instances (one workgroup each) from which the one-launch, summed-on-chip bank fills the chip
+FUSED_SUPERSAW_MIN = 257     # SuperSaw instances from which the bank is rendered in one segment per instance, one block ahead (256 -- a rank's
+                             # share at two ranks -- is better off in two time segments and windows: 97 -> 84 us per block)
 
 
 def _is_pe(x) -> bool:
