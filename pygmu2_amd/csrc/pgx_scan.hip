@@ -675,6 +675,7 @@ __device__ __forceinline__ V2 mv_add_fma(const M2 &p, const V2 &v, const V2 &q) 
 struct SbSine {
     double w, amp, phase0, sr, inv_sr, cos_d, sin_d;
     double two_cos_d;          // 2 cos(w / sr) for the three-term recurrence, or 0: rotate (very low frequencies)
+    double tile_cos, tile_sin; // cos / sin of a tile's advance, BLOCK * 16 frames of w / sr (the angle reduced on the host)
     int64_t start;
     double *state_backup;      // receives the carried state on entry (a look-ahead window's snapshot), or nullptr
 };
@@ -722,14 +723,27 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
 
     // first tile's frames are requested before anything else so that their latency covers the table loads
     float xn[kBqT];
+    int64_t anchor_tile = -(int64_t)1 << 40;                   // SINE: the tile the anchor (sin, cos) below belongs to
+    double anchor_s = 0.0, anchor_c = 1.0;
     auto request = [&](int64_t hh) {
         const int64_t w0 = hh * kSbHalf + (int64_t)(tid - lane) * kBqT;      // first frame of this wave
         const int64_t f0 = w0 + lane * kBqT;
         if (SINE) {
             xn_staged = false;
-            const double t = pgx::pgx_div_by((double)(sine.start + f0), sine.sr, sine.inv_sr);
+            // The thread's first frame: k_sine's evaluation for the first tile of a run of consecutive tiles, that pair
+            // turned by a tile's advance for every further one (4 operations instead of the division and the sincos, ~35;
+            // a workgroup's run is a dozen tiles: ~1e-15).
             double sn, cs;
-            pgx::pgx_sincos_bounded(sine.phase0 + sine.w * t, sn, cs);
+            if (hh == anchor_tile + kTileHalves) {
+                sn = __builtin_fma(anchor_s, sine.tile_cos, anchor_c * sine.tile_sin);
+                cs = __builtin_fma(anchor_c, sine.tile_cos, -(anchor_s * sine.tile_sin));
+            } else {
+                const double t = pgx::pgx_div_by((double)(sine.start + f0), sine.sr, sine.inv_sr);
+                pgx::pgx_sincos_bounded(sine.phase0 + sine.w * t, sn, cs);
+            }
+            anchor_tile = hh;
+            anchor_s = sn;
+            anchor_c = cs;
             if (sine.two_cos_d != 0.0) {
                 // three-term recurrence sin(p + (j+1)d) = 2 cos(d) sin(p + jd) - sin(p + (j-1)d): ONE fused multiply-add
                 // per frame instead of the four operations of the rotation (the cosine is not needed).  Its error
@@ -3616,6 +3630,14 @@ int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, do
     sine.cos_d = (double)cosl(d);
     sine.sin_d = (double)sinl(d);
     sine.two_cos_d = (fabsl(sinl(d)) >= 1e-3L) ? (double)(2.0L * cosl(d)) : 0.0;
+    {
+        // a tile's advance, block * 16 frames: the angle reduced in long double before the sine and cosine are taken
+        const long double turn = 6.283185307179586476925286766559L;
+        long double a = d * (long double)(sine_block() * kBqT);
+        a -= turn * floorl(a / turn);
+        sine.tile_cos = (double)cosl(a);
+        sine.tile_sin = (double)sinl(a);
+    }
     sine.start = start;
     sine.state_backup = state_backup;
     const dim3 grid(sp.groups == 1 ? 1 : (sp.groups + 7) / 8 * 8, 1);
