@@ -776,6 +776,8 @@ def mix_entry(pg, dist, config, steps, warmup, with_cpu):
            "voices_on_this_rank": info["owned"],
            "render_ms": info.get("render_ms"), "render_ms_max_over_ranks": info.get("render_ms_max"),
            "allreduce_wait_ms": info.get("allreduce_wait_ms"),
+           "collectives_in_timed_region": info.get("collectives_in_timed_region"),
+           "floats_reduced_in_timed_region": info.get("floats_reduced_in_timed_region"),
            "oscillator_msamples_s": round(per_voice * voices * frames * steps / dt / 1e6, 1),
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                         "achieved": round(4.0 * frames * steps / dt / 1e9, 4),

@@ -17,12 +17,17 @@ left-to-right float32 sum, so sharded output matches the unsharded one to ~1e-7 
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .extent import Extent
 from .mix_pe import MixPE
 from .processing_element import ProcessingElement
 from .snippet import Snippet
+
+
+WINDOW_COLLECTIVES = os.environ.get("PGX_WINDOW_COLLECTIVES", "1") != "0"   # a bank window = one collective
 
 
 def shard_indices(n_inputs: int, rank: int, world: int) -> list[int]:
@@ -73,11 +78,15 @@ class RcclReducer:
         self._device = device
         self._lib = device.ensure_init()
         self.rank, self.world = comm.info()
+        self.calls = 0                # collectives issued, floats reduced (bench.py reports them)
+        self.floats = 0
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         import ctypes as C
         dev, lib = self._device, self._lib
         src = snippet.dev
+        self.calls += 1
+        self.floats += src.nbytes // 4
         out = dev.DeviceBuffer(src.shape, np.float32)
         ticket = C.c_int64(0)
         dev.check(lib.pgx_allreduce_sum(out.ptr, src.ptr, src.nbytes // 4, C.byref(ticket)), "pgx_allreduce_sum")
@@ -178,6 +187,8 @@ class ShardedMixPE(ProcessingElement):
         else:
             self._local = _Silence(self._channels or 1)
         self._reducer = reducer
+        self._windows = None          # decided once, from what every rank knows (see _whole_windows)
+        self._reduced = None          # (local window buffer, its reduced Snippet, that Snippet's buffer)
 
     owned = property(lambda self: self._owned)
     local = property(lambda self: self._local)
@@ -197,13 +208,62 @@ class ShardedMixPE(ProcessingElement):
             ext = ext.union(pe.extent())
         return ext
 
+    def _whole_windows(self) -> bool:
+        """May a window of the rank-local bank be reduced in one collective?  Every rank has to answer alike -- a
+        rank that reduces a window while another reduces a block hangs the communicator -- so the answer comes
+        from what all ranks know: the full input list, the world size and voice_bank's window rule (SuperSaw banks
+        of MIN_VOICES .. BANK_WINDOW_MAX_VOICES instances open windows of 2, 4, 8 blocks from the second block of
+        a stream of equal blocks on; which blocks those are depends on the sequence of pulls alone, and that is the
+        same on every rank by ShardedMixPE's contract)."""
+        if self._windows is None:
+            from . import voice_bank as vb
+            from .super_saw_pe import SuperSawPE
+            n, world = len(self._all_inputs), self._world
+            sig = vb._signature(self._all_inputs[0])
+            seen = set()
+            self._windows = bool(
+                WINDOW_COLLECTIVES and vb.BANK_WINDOWS and not vb.BANK_WINDOWS_ANY_ROOT
+                and n // world >= vb.MIN_VOICES and -(-n // world) <= vb.BANK_WINDOW_MAX_VOICES
+                and -(-n // world) < vb.FUSED_SUPERSAW_MIN
+                and sig is not None and all(isinstance(pe, SuperSawPE) for pe in self._all_inputs)
+                and all(vb._signature(pe) == sig and vb._collect_ids(pe, seen) for pe in self._all_inputs))
+        return self._windows
+
     def _render(self, start, duration):
         part = self._local.render(start, duration)
         if self._world == 1:
             return part
         if self._reducer is None:
             self._reducer = default_reducer()
-        return self._reducer.all_reduce(part)
+        base = part._base
+        if base is None or not self._whole_windows():
+            return self._reducer.all_reduce(part)
+        # A row of the bank's window of 2, 4 or 8 blocks: the window is reduced whole when its first row is handed
+        # out -- one collective of up to 1.5 MB instead of eight of 192 KB, each of which costs the links' latency --
+        # and the blocks are rows of the reduced window.  Only a row that is USED orders the library stream behind
+        # the collective; dropping one does not (the window keeps the buffers), so the next window is rendered while
+        # this one is on the links, and the stream waits for it when the window after it replaces it.
+        window, first_row = base
+        if first_row == 0:
+            whole = self._reducer.all_reduce(Snippet(start, window))
+            self._reduced = (window, whole, whole._dev)       # (the previous window's wait is enqueued here, when it is dropped)
+        elif self._reduced is None or self._reduced[0] is not window:
+            raise RuntimeError("ShardedMixPE: a row of a window whose first row was never reduced")
+        _, whole, buf = self._reduced
+
+        def ready():
+            whole._resolve()
+        ready.on_use_only = True
+        if buf is None:                                       # a reducer that answers on the host
+            return Snippet(start, whole.data[first_row:first_row + duration])
+        row = Snippet.window_rows(start, buf, first_row, duration)
+        row._ready = ready
+        return row
+
+    def _on_start(self) -> None:
+        self._reduced = None
+
+    _on_stop = _on_start
 
 
 # ----------------------------------------------------------------------------- bench workload
@@ -253,6 +313,7 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     keep["s"].dev
     device.synchronize()
     dist.barrier()
+    calls0 = (getattr(root._reducer, "calls", 0), getattr(root._reducer, "floats", 0))
     t0 = time.perf_counter()
     for i in range(steps):
         keep["s"] = root.render((warmup + i) * block, block)
@@ -260,9 +321,13 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     device.synchronize()               # ... and wait for it: every block is rendered AND reduced
     dist.barrier()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
+    calls1 = (getattr(root._reducer, "calls", 0), getattr(root._reducer, "floats", 0))
     # what a block costs this rank before the exchange: the same stream continued on the rank-local mix alone (no
     # collective), and with it what the blocks above spent waiting for the slowest rank and the links
     info = {"owned": len(root.owned)}
+    if world > 1:                      # (a bank window of 2, 4, 8 blocks is one collective)
+        info["collectives_in_timed_region"] = calls1[0] - calls0[0]
+        info["floats_reduced_in_timed_region"] = calls1[1] - calls0[1]
     probe = max(3, min(20, steps))
     pos = (warmup + steps) * block
     root.local.render(pos, block)

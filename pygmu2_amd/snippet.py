@@ -84,6 +84,8 @@ class Snippet:
 
     def __del__(self):
         try:
+            if self._ready is not None and getattr(self._ready, "on_use_only", False):
+                self._ready = None              # (a row of a window somebody else keeps alive and waits for)
             self._resolve()
             if self._copy is not None:          # a prefetch nobody read: the payload must outlive the copy
                 from .device import fence_to_host

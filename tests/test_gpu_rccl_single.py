@@ -136,6 +136,34 @@ for x, y in zip(got, want64):
     # the share is rendered by the time-segmented fused bank (pgx_supersaw_wide: integrator carries from the closed
     # form, phases as products, voices summed in float64): the per-voice samples to one or two float32 ulps
     assert float(np.max(np.abs(x.astype(np.float64) - y))) <= 1e-6 * float(np.max(np.abs(y)))
+# a stream of equal blocks: the bank renders windows of 2, 4, 8 blocks and each window is ONE collective (16 blocks:
+# block 0 alone, then windows of 2, 4, 8 and 8 -- five collectives); rows dropped unread do not wait for it
+share = ShardedMixPE([supersaw_voice(pg, i) for i in range(512)], 0, 8, reducer=RcclReducer())
+sizes = []
+inner = share._reducer.all_reduce
+def counted(snippet):
+    sizes.append(snippet.duration)
+    return inner(snippet)
+share._reducer.all_reduce = counted
+r = pg.NullRenderer(48000); r.set_source(share); r.start()
+rows, keep = [], None
+for i in range(16):
+    keep = share.render(i * 48000, 48000)
+    if i in (0, 1, 2, 6, 9, 15):
+        rows.append((i, keep.data.copy()))
+    elif i == 12:
+        assert keep._ready is not None
+r.stop()
+assert sizes == [48000, 96000, 192000, 384000, 384000], sizes
+look_ahead.set_enabled(False)
+r = pg.NullRenderer(48000); r.set_source(plain64); r.start()
+for i in range(16):
+    y = plain64.render(i * 48000, 48000).data
+    for j, x in rows:
+        if j == i:
+            assert float(np.max(np.abs(x.astype(np.float64) - y))) <= 1e-6 * float(np.max(np.abs(y))), i
+r.stop()
+look_ahead.set_enabled(True)
 comm.destroy()
 assert not comm.initialised()
 assert "torch" not in sys.modules
