@@ -61,3 +61,17 @@ def test_sharded_mix_matches_full_mix_gloo(tmp_path, world, n_voices):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == want.shape
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("n_voices,world,expected", [(512, 2, True), (512, 3, True), (512, 8, True), (513, 2, False),
+                                                     (24, 8, False), (512, 256, False)])
+def test_every_rank_answers_the_window_question_alike(n_voices, world, expected):
+    """One collective per bank window or one per block: decided from the full input list and the world size, never from
+    a rank's own share (513 voices on two ranks: 257 and 256 instances -- one side of the bank's window rule each)."""
+    from pygmu2_amd.sharding import c5_voice, supersaw_voice
+    pg.set_sample_rate(48000)
+    voices = [supersaw_voice(pg, i) for i in range(n_voices)]
+    answers = {ShardedMixPE(voices, rank, world)._whole_windows() for rank in range(world)}
+    assert answers == {expected}
+    other = [c5_voice(pg, i) for i in range(64)]
+    assert {ShardedMixPE(other, rank, 4)._whole_windows() for rank in range(4)} == {False}
