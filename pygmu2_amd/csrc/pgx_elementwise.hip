@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(kBlock) k_mix_batch(float *out, const float *i
         } else {
             // one element per thread (blocks below 2^20 elements: a 48 000-frame block is 750 waves): 32 loads in
             // flight per lane, as k_gain_mix_batch keeps them, or the pass is latency-bound (512 inputs: 27 us)
+            // (the chunk the batch ends in is loaded as a whole too, predicated: no tail of dependent round trips)
             float acc = in[e], v[32];
             int b = 1;
             for (; b + 32 <= batch; b += 32) {
@@ -277,13 +278,13 @@ __global__ void __launch_bounds__(kBlock) k_mix_batch(float *out, const float *i
 #pragma unroll
                 for (int u = 0; u < 32; ++u) acc = acc + v[u];
             }
-            for (; b + 8 <= batch; b += 8) {
+            if (b < batch) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = in[(int64_t)(b + u) * in_stride + e];
+                for (int u = 0; u < 32; ++u) v[u] = (b + u < batch) ? in[(int64_t)(b + u) * in_stride + e] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc = acc + v[u];
+                for (int u = 0; u < 32; ++u)
+                    if (b + u < batch) acc = acc + v[u];
             }
-            for (; b < batch; ++b) acc = acc + in[(int64_t)b * in_stride + e];
             out[e] = acc;
         }
     }
@@ -292,6 +293,27 @@ __global__ void __launch_bounds__(kBlock) k_mix_batch(float *out, const float *i
 // out = sum_b float32(x_b * g_b): GainPE(voice, gain=<PE>) fused into the mix (gain_pe.py:104-119 then
 // mix_pe.py:91-94).  Each product is rounded to float32 before the ordered float32 addition, exactly as
 // when the two PEs run separately.  g is (frames, 1) or (frames, channels) per voice.
+// (U voices of one frame: all 2U loads issued before the first product -- what keeps HBM busy is the number of loads in
+// flight per thread.  PARTIAL: the batch ends inside the chunk; the loads stay unconditional in form (predicated), so
+// a bank of 64 voices is two batched chunks, not one chunk and 31 dependent round trips: 16.5 -> 6 us.)
+template <int U, bool FIRST, bool PARTIAL>
+__device__ __forceinline__ void gain_mix_chunk(float &acc, const float *x, const float *g, int64_t x_stride,
+                                               int64_t g_stride, int64_t e, int64_t ge, int b, int batch) {
+    float xv[U], gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool on = !PARTIAL || b + u < batch;
+        xv[u] = on ? x[(int64_t)(b + u) * x_stride + e] : 0.0f;
+        gv[u] = on ? g[(int64_t)(b + u) * g_stride + ge] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float prod = xv[u] * gv[u];
+        if (FIRST && u == 0) acc = prod;
+        else if (!PARTIAL || b + u < batch) acc = acc + prod;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_gain_mix_batch(float *out, const float *x, const float *g,
                                                            int64_t x_stride, int64_t g_stride, int batch,
                                                            int64_t n, int channels, int gain_channels) {
@@ -299,27 +321,17 @@ __global__ void __launch_bounds__(kBlock) k_gain_mix_batch(float *out, const flo
     int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elems; e += stride) {
         const int64_t ge = (gain_channels == channels) ? e : e / channels;
-        float acc = x[e] * g[ge];
-        // one thread per frame (the additions are ordered by voice): what keeps HBM busy is the number of loads in
-        // flight per thread -- 32 voices x 2 streams
+        // one thread per frame (the additions are ordered by voice), 32 voices x 2 streams in flight
         constexpr int U = 32;
-        float xv[U], gv[U];
-        int b = 1;
-        for (; b + U <= batch; b += U) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                xv[u] = x[(int64_t)(b + u) * x_stride + e];
-                gv[u] = g[(int64_t)(b + u) * g_stride + ge];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float prod = xv[u] * gv[u];
-                acc = acc + prod;
-            }
-        }
-        for (; b < batch; ++b) {
-            float prod = x[(int64_t)b * x_stride + e] * g[(int64_t)b * g_stride + ge];
-            acc = acc + prod;
+        float acc;
+        int b = 0;
+        if (batch >= U) {
+            gain_mix_chunk<U, true, false>(acc, x, g, x_stride, g_stride, e, ge, 0, batch);
+            for (b = U; b + U <= batch; b += U)
+                gain_mix_chunk<U, false, false>(acc, x, g, x_stride, g_stride, e, ge, b, batch);
+            if (b < batch) gain_mix_chunk<U, false, true>(acc, x, g, x_stride, g_stride, e, ge, b, batch);
+        } else {
+            gain_mix_chunk<U, true, true>(acc, x, g, x_stride, g_stride, e, ge, 0, batch);
         }
         out[e] = acc;
     }
