@@ -63,6 +63,8 @@ class MixPE(ProcessingElement):
         if self._bank is None:
             from .voice_bank import try_build_bank
             self._bank = try_build_bank(self._inputs) or False
+            if self._bank and self.__dict__.get("_mix_windows"):
+                self._bank.set_mix_windows()
         return self._bank
 
     def _read_ahead_condition(self) -> bool:

@@ -189,6 +189,8 @@ class ShardedMixPE(ProcessingElement):
         self._reducer = reducer
         self._windows = None          # decided once, from what every rank knows (see _whole_windows)
         self._reduced = None          # (local window buffer, its reduced Snippet, that Snippet's buffer)
+        if world > 1 and isinstance(self._local, MixPE) and self._whole_windows():
+            self._local.__dict__["_mix_windows"] = True       # the bank makes its windows at the level of the mix
 
     owned = property(lambda self: self._owned)
     local = property(lambda self: self._local)
@@ -211,13 +213,12 @@ class ShardedMixPE(ProcessingElement):
     def _whole_windows(self) -> bool:
         """May a window of the rank-local bank be reduced in one collective?  Every rank has to answer alike -- a
         rank that reduces a window while another reduces a block hangs the communicator -- so the answer comes
-        from what all ranks know: the full input list, the world size and voice_bank's window rule (SuperSaw banks
-        of MIN_VOICES .. BANK_WINDOW_MAX_VOICES instances open windows of 2, 4, 8 blocks from the second block of
-        a stream of equal blocks on; which blocks those are depends on the sequence of pulls alone, and that is the
-        same on every rank by ShardedMixPE's contract)."""
+        from what all ranks know: the full input list, the world size and voice_bank's window rule (banks of
+        MIN_VOICES .. BANK_WINDOW_MAX_VOICES SuperSaw instances, or ladders over them, open windows of 2, 4, 8 blocks
+        from the second block of a stream of equal blocks on; which blocks those are depends on the sequence of pulls
+        alone, and that is the same on every rank by ShardedMixPE's contract)."""
         if self._windows is None:
             from . import voice_bank as vb
-            from .super_saw_pe import SuperSawPE
             n, world = len(self._all_inputs), self._world
             sig = vb._signature(self._all_inputs[0])
             seen = set()
@@ -225,7 +226,7 @@ class ShardedMixPE(ProcessingElement):
                 WINDOW_COLLECTIVES and vb.BANK_WINDOWS and not vb.BANK_WINDOWS_ANY_ROOT
                 and n // world >= vb.MIN_VOICES and -(-n // world) <= vb.BANK_WINDOW_MAX_VOICES
                 and -(-n // world) < vb.FUSED_SUPERSAW_MIN
-                and sig is not None and all(isinstance(pe, SuperSawPE) for pe in self._all_inputs)
+                and sig is not None and (sig[0] == "supersaw" or (sig[0] == "ladder" and sig[1][0] == "supersaw"))
                 and all(vb._signature(pe) == sig and vb._collect_ids(pe, seen) for pe in self._all_inputs))
         return self._windows
 

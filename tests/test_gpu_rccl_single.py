@@ -164,6 +164,27 @@ for i in range(16):
             assert float(np.max(np.abs(x.astype(np.float64) - y))) <= 1e-6 * float(np.max(np.abs(y))), i
 r.stop()
 look_ahead.set_enabled(True)
+# the same for a rank's share of C4 (8 of the 64 SuperSaw -> ladder instances): ShardedMixPE asks the bank for windows at
+# the level of the mix (the ladder node's own windows hand out rows BELOW the mix: a collective per block)
+from pygmu2_amd.sharding import c4_voice
+share4 = ShardedMixPE([c4_voice(pg, i) for i in range(64)], 0, 8, reducer=RcclReducer())
+assert len(share4.owned) == 8
+sizes4 = []
+inner4 = share4._reducer.all_reduce
+def counted4(snippet):
+    sizes4.append(snippet.duration)
+    return inner4(snippet)
+share4._reducer.all_reduce = counted4
+r = pg.NullRenderer(48000); r.set_source(share4); r.start()
+got4 = [share4.render(i * 48000, 48000).data.copy() for i in range(8)]
+r.stop()
+assert sizes4 == [48000, 96000, 192000, 384000], sizes4
+plain8 = pg.MixPE(*[c4_voice(pg, i) for i in shard_indices(64, 0, 8)])
+r = pg.NullRenderer(48000); r.set_source(plain8); r.start()
+for i in range(8):
+    y = plain8.render(i * 48000, 48000).data
+    assert float(np.max(np.abs(got4[i].astype(np.float64) - y))) <= 1e-5 * float(np.max(np.abs(y))), i
+r.stop()
 comm.destroy()
 assert not comm.initialised()
 assert "torch" not in sys.modules
