@@ -194,7 +194,10 @@ k_adsr_edges_sparse(unsigned long long *masks, unsigned long long *group_bits, f
     else first_before = adsr_control<2>(nullptr, gp, start, c0 * 64 - 1);
     const float before = __int_as_float(__builtin_amdgcn_update_dpp(
         __float_as_int(first_before), __float_as_int(v_last), 0x138, 0xf, 0xf, false));      // wave_shr:1
-    const bool edge = valid && before != v_last;
+    // (the block's first chunk is always expanded: its "sample before" is the carried one, which at the start of a
+    // stream -- zero -- or after a seek is not the gate's own previous value, and a rise made of that plus the gate's
+    // own fall inside the chunk are two transitions that leave first and last sample equal)
+    const bool edge = valid && (before != v_last || chunk == 0);
     if (valid && !edge) {
         masks[((int64_t)inst * nchunks + chunk) * 2 + 0] = 0ull;
         masks[((int64_t)inst * nchunks + chunk) * 2 + 1] = 0ull;

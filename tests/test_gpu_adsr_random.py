@@ -154,3 +154,47 @@ def test_adsr_batch_bit_exact_random(case):
     bad = np.argwhere(got != want)
     assert bad.size == 0, (f"{len(bad)} samples differ; first at envelope {bad[0][0]} sample {bad[0][1]}: "
                            f"got {got[tuple(bad[0])]!r} want {want[tuple(bad[0])]!r}, params {rec[bad[0][0]]}")
+
+
+@pytest.mark.parametrize("k", [7, 96, 300])
+def test_fused_periodic_gate_matches_rendered_gate(k):
+    """pgx_adsr_gated_periodic[_to] -- the gate evaluated inside the edge search, one bitmap byte per wave, no clearing
+    launch -- against pgx_periodic_gate + pgx_adsr_gated (bit-exact against the oracle's loop, above), bit for bit:
+    slow gates (one look per 64 chunks), gates with a phase shorter than 65 samples (every chunk expanded), duty
+    cycles near 0 and 1, odd block lengths, states carried, and the variant that writes its states elsewhere."""
+    lib = device.ensure_init()
+    rng = np.random.default_rng(500 + k)
+    rec = _params(rng, k, False)
+    gates = np.zeros(k, dtype=device.GATE_PARAMS)
+    for i in range(k):
+        kind = i % 4
+        freq = [rng.uniform(0.3, 12.0), rng.uniform(200.0, 5000.0), rng.uniform(20.0, 200.0), 48000.0 / 130.0][kind]
+        duty = [0.5, 0.1, 0.9, 0.01, 0.999, float(rng.uniform(0.02, 0.98))][int(rng.integers(0, 6))]
+        gates[i] = (freq / SR, float(rng.uniform(0.0, 1.0)), duty)
+    blocks = [4096, 777, 48000, 65, 1, 20000, 65536, 100000]
+    gp, params = device.DeviceBuffer.from_host(gates), device.DeviceBuffer.from_host(rec)
+    st_ref = device.DeviceBuffer((k, 3), np.float64, zero=True)
+    st_fused = device.DeviceBuffer((k, 3), np.float64, zero=True)
+    st_a = device.DeviceBuffer((k, 3), np.float64, zero=True)
+    st_b = device.DeviceBuffer((k, 3), np.float64, zero=True)
+    ws = [device.DeviceBuffer((lib.pgx_adsr_workspace_bytes(k, max(blocks)),), np.uint8) for _ in range(3)]
+    pos = 1000
+    for b in blocks:
+        g = device.DeviceBuffer((k, b), np.float32)
+        device.check(lib.pgx_periodic_gate(g.ptr, b, k, pos, b, gp.ptr))
+        want = device.DeviceBuffer((k, b), np.float32)
+        device.check(lib.pgx_adsr_gated(want.ptr, b, g.ptr, b, k, b, params.ptr, st_ref.ptr, ws[0].ptr))
+        fused = device.DeviceBuffer((k, b), np.float32)
+        device.check(lib.pgx_adsr_gated_periodic(fused.ptr, b, k, pos, b, gp.ptr, params.ptr, st_fused.ptr, ws[1].ptr, 0))
+        to = device.DeviceBuffer((k, b), np.float32)
+        device.check(lib.pgx_adsr_gated_periodic_to(to.ptr, b, k, pos, b, gp.ptr, params.ptr, st_a.ptr, st_b.ptr,
+                                                    ws[2].ptr))
+        st_a, st_b = st_b, st_a
+        w = want.to_host()
+        for name, got in (("fused", fused.to_host()), ("fused, states elsewhere", to.to_host())):
+            bad = np.argwhere(got != w)
+            assert bad.size == 0, (f"{name}, block of {b} at {pos}: {len(bad)} samples differ; first at envelope "
+                                   f"{bad[0][0]} sample {bad[0][1]}: {got[tuple(bad[0])]!r} != {w[tuple(bad[0])]!r}, "
+                                   f"gate {gates[bad[0][0]]}")
+        assert np.array_equal(st_fused.to_host(), st_ref.to_host()) and np.array_equal(st_a.to_host(), st_ref.to_host())
+        pos += b
