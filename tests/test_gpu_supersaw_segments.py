@@ -188,3 +188,57 @@ def test_small_bank_windows_hand_out_the_block_by_block_samples(monkeypatch):
     for a, b in zip(got, want):
         peak = float(np.max(np.abs(b)))
         assert a.shape == b.shape and float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_wide_bank_random_configurations(seed):
+    """Random banks through pgx_supersaw_wide -- instance counts from 4 to 300 (one to many time segments, both sides of
+    the fused-bank threshold), 1 to 16 oscillators per instance, frequencies from 1 Hz (M ~ 24 000 harmonics) to near
+    Nyquist (M = 1), wide detune, mono and stereo, block lengths from 1 frame to 120 000 with odd tails, a seek -- against
+    the oscillator-by-oscillator bank (k_blitsaw + ordered sum: the single PE's samples), <= 1e-6 of the peak."""
+    import pygmu2_amd as pg
+    from pygmu2_amd import voice_bank
+    rng = np.random.default_rng(9000 + seed)
+    pg.set_sample_rate(48000)
+    count = int([4, 9, 33, 64, 130, 300][seed - 1])
+    voices = int(rng.choice([1, 2, 3, 7, 11, 16]))
+    channels = int(rng.choice([1, 2]))
+    lo, hi = [(1.0, 40.0), (20.0, 2000.0), (2000.0, 16000.0)][int(rng.integers(0, 3))]
+    freqs = np.exp(rng.uniform(np.log(lo), np.log(hi), count))
+    detune = float(rng.choice([0.0, 5.0, 20.0, 50.0]))
+    sizes = [int(rng.choice([1, 15, 17, 4095, 4096, 4097, 12_289, 48_000, 120_000])) for _ in range(5)]
+    blocks, pos = [], 0
+    for i, n in enumerate(sizes):
+        if i == 3:
+            pos += 777_777                               # a seek: the oscillators start over
+        blocks.append((pos, n))
+        pos += n
+
+    def run(wide):
+        keep = voice_bank.WIDE_SUPERSAW, voice_bank.SEGMENTED_SUPERSAW, voice_bank.BANK_WINDOWS
+        voice_bank.WIDE_SUPERSAW = wide
+        voice_bank.SEGMENTED_SUPERSAW = wide
+        voice_bank.BANK_WINDOWS = False
+        try:
+            mix = pg.MixPE(*[pg.SuperSawPE(frequency=float(f), voices=voices, detune_cents=detune, seed=int(i),
+                                           channels=channels) for i, f in enumerate(freqs)])
+            r = pg.NullRenderer(sample_rate=48000)
+            r.set_source(mix)
+            r.start()
+            root = mix._voice_bank().root
+            used = root.wide()
+            outs = [mix.render(s, n).data.copy() for s, n in blocks]
+            r.stop()
+            return outs, used
+        finally:
+            voice_bank.WIDE_SUPERSAW, voice_bank.SEGMENTED_SUPERSAW, voice_bank.BANK_WINDOWS = keep
+
+    got, used = run(True)
+    want, _ = run(False)
+    if not used:
+        pytest.skip("this bank keeps the oscillator-by-oscillator path (a harmonic count the rotation form excludes)")
+    peak = max(float(np.max(np.abs(w))) for w in want)
+    for (s, n), g, w in zip(blocks, got, want):
+        assert g.shape == w.shape
+        err = float(np.max(np.abs(g.astype(np.float64) - w)))
+        assert err <= 1e-6 * peak, (s, n, err, peak, count, voices, channels, lo, hi, detune)
