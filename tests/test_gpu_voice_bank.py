@@ -316,3 +316,47 @@ def test_ladder_bank_windows_hand_out_the_block_by_block_samples(monkeypatch):
     for a, b in zip(got, want):
         peak = float(np.max(np.abs(b)))
         assert a.shape == b.shape and float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_oscillator_filter_chain_random_banks(monkeypatch, seed):
+    """pgx_blitsaw_biquad_wide on random banks -- 128 .. 300 voices, oscillators from 20 Hz to 9 kHz, every RBJ mode,
+    corner frequencies from 40 Hz to 18 kHz, q from 0.3 to 12, block lengths from 1 frame to 48 000 with odd tails and
+    a seek -- against the two-launch bank (k_blitsaw's samples through pgx_biquad_const): <= 2e-6 of the peak."""
+    from pygmu2_amd import voice_bank
+    from pygmu2_amd.biquad_pe import BiquadMode
+    rng = np.random.default_rng(4200 + seed)
+    pg.set_sample_rate(48000)
+    count = [128, 131, 200, 300][seed - 1]
+    modes = list(BiquadMode)
+    spec = [(float(np.exp(rng.uniform(np.log(20.0), np.log(9000.0)))), modes[int(rng.integers(0, len(modes)))],
+             float(np.exp(rng.uniform(np.log(40.0), np.log(18000.0)))), float(np.exp(rng.uniform(np.log(0.3), np.log(12.0)))),
+             float(rng.uniform(-12.0, 12.0))) for _ in range(count)]
+    mode0 = spec[0][1]                                     # one bank: same structure, the mode is part of it
+
+    def make():
+        return pg.MixPE(*[pg.BiquadPE(pg.BlitSawPE(f), frequency=fc, q=q, mode=mode0, gain_db=g)
+                          for f, _, fc, q, g in spec])
+
+    sizes = [int(rng.choice([1, 15, 17, 4095, 4097, 12_289, 48_000])) for _ in range(5)]
+    blocks, pos = [], 0
+    for i, n in enumerate(sizes):
+        if i == 3:
+            pos += 123_457
+        blocks.append((pos, n))
+        pos += n
+    monkeypatch.setattr(voice_bank, "WIDE_SUPERSAW", True)
+    fused = make()
+    got = _render_blocks(fused, 48000, blocks)
+    assert fused._bank and fused._bank.k == count
+    used = fused._bank.root.children["source"].wide()
+    monkeypatch.setattr(voice_bank, "FUSED_VOICE_MIN", 10 ** 9)
+    monkeypatch.setattr(voice_bank, "WIDE_SUPERSAW", False)
+    want = _render_blocks(make(), 48000, blocks)
+    if not used:
+        pytest.skip("an oscillator the rotation form excludes: the bank kept the eight-frames-per-thread kernel")
+    peak = max(float(np.max(np.abs(b))) for b in want)
+    for (s, n), a, b in zip(blocks, got, want):
+        assert a.shape == b.shape
+        err = float(np.max(np.abs(a.astype(np.float64) - b)))
+        assert err <= 2e-6 * peak, (s, n, err, peak, mode0)
