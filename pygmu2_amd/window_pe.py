@@ -49,11 +49,15 @@ class WindowPE(ProcessingElement):
         return True
 
     # max / min of a window do not depend on how the stream is cut into blocks (the float64 sums of mean / RMS are
-    # grouped by 64-frame blocks counted from the request's start: equal only to rounding): read-ahead for those
+    # grouped by 64-frame blocks counted from the request's start: equal only to rounding): read-ahead for those --
+    # over a PURE source only.  The padded pulls of two neighbouring blocks overlap, so a stateful PE below is pulled
+    # out of sequence and starts over at every block (window_pe.py:135-141 does the same): what a block holds then
+    # depends on where it begins, and a window rendered in one piece is not the blocks it is cut into.
     _READ_AHEAD_SAFE = True
 
     def _read_ahead_condition(self) -> bool:
-        return self._mode in (WindowMode.MAX, WindowMode.MIN)
+        from .loop_pe import _subtree_pure
+        return self._mode in (WindowMode.MAX, WindowMode.MIN) and _subtree_pure(self._source)
 
     def channel_count(self) -> int | None:
         return self._source.channel_count()
