@@ -120,3 +120,32 @@ def test_convolve_pe_streams_through_the_fft_path(dev):
     want = np.stack([fftconvolve(x[:, c].astype(np.float64), h.astype(np.float64))[:T] for c in range(2)], axis=1)
     peak = float(np.max(np.abs(want)))
     assert float(np.max(np.abs(got.astype(np.float64) - want))) <= REL_TOL * peak
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_FFTCONV", "40"))))
+def test_fft_conv_random_geometries(dev, seed):
+    """Random filter lengths (2 .. 100 000 taps), block lengths (1 .. 200 000 frames, also just around multiples of the
+    hop), any transform size the library accepts for the filter (the smallest and larger ones), every channel rule, a
+    carried history or a fresh stream -- against numpy's float64 convolution."""
+    lib = dev.ensure_init()
+    rng = np.random.default_rng(31_000 + seed)
+    L = int(rng.choice([2, 3, 63, 64, 65, 2047, 2048, 2049, int(rng.integers(3, 100_000))]))      # (fir_len >= 2: the ABI's rule)
+    smallest = lib.pgx_convolve_fft_size(L)
+    assert smallest
+    sizes = [f for f in (4096, 8192, 16384, 32768, 65536, 131072, 262144) if f >= smallest]
+    fft_size = int(sizes[int(rng.integers(0, min(3, len(sizes))))])
+    hop = fft_size - (L - 1)
+    n = int(rng.choice([1, hop - 1, hop, hop + 1, 2 * hop, 3 * hop + 1, int(rng.integers(1, 200_000))]))
+    n = max(1, min(n, 400_000))
+    src_ch, fir_ch = [(1, 1), (2, 1), (2, 2), (1, 2)][int(rng.integers(0, 4))]
+    out_ch = max(src_ch, fir_ch)
+    x = (rng.standard_normal((n, src_ch)) * 0.1).astype(np.float32)
+    h = (rng.standard_normal((L, fir_ch)) * np.exp(-np.arange(L) / max(1.0, L / 8.0))[:, None]).astype(np.float32)
+    fresh = int(rng.random() < 0.3)
+    hist = (rng.standard_normal((max(L - 1, 0), out_ch)) * 0.1).astype(np.float32)
+    got, got_hist = _fft_conv(dev, x, h, hist, fft_size, hist_is_zero=fresh)
+    want, want_hist = _numpy_conv(x, h, np.zeros_like(hist) if fresh else hist)
+    assert np.array_equal(got_hist, want_hist.astype(np.float32)), (L, n, fft_size, src_ch, fir_ch, fresh)
+    peak = float(np.max(np.abs(want))) or 1.0
+    err = float(np.max(np.abs(got.astype(np.float64) - want)))
+    assert err <= 1e-6 * peak + 1e-9, (err, peak, L, n, fft_size, src_ch, fir_ch, fresh)
