@@ -86,3 +86,48 @@ def test_fused_path_is_taken_and_declined():
     fm = pg.BiquadPE(pg.SinePE(frequency=pg.SinePE(frequency=2.0, amplitude=100.0)), frequency=1000.0, q=0.707)
     assert fm._render_sine_source(0, 1_000_000) is None
     assert lib.pgx_biquad_sine_supported(1_000_000, 1024) == 1 and lib.pgx_biquad_sine_supported(1_000_000, 0) == 0
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_C2", "16"))))
+def test_random_chains_against_the_oracle(seed):
+    """BiquadPE(SinePE) with random tone, filter and block lengths -- short blocks (one workgroup, carried state), blocks
+    of millions of frames (1024 workgroups, anchors turned from tile to tile), a seek to a far start -- whichever form the
+    PE picks (fused, or the two-launch chain where the fused form declines), every block against np.sin + lfilter."""
+    from oracle import pe_oracle as O
+    import pygmu2_amd as pg
+    from pygmu2_amd import look_ahead
+    rng = np.random.default_rng(12_000 + seed)
+    sr = int(rng.choice([22050, 44100, 48000, 96000]))
+    freq = float(np.exp(rng.uniform(np.log(20.0), np.log(0.45 * sr))))
+    amp, phase = float(rng.uniform(0.05, 1.0)), float(rng.uniform(-3.0, 3.0))
+    mode = str(rng.choice(["lowpass", "highpass", "bandpass", "notch", "allpass", "peaking", "lowshelf", "highshelf"]))
+    cutoff = float(np.exp(rng.uniform(np.log(30.0), np.log(0.45 * sr))))
+    q, gain_db = float(np.exp(rng.uniform(np.log(0.3), np.log(8.0)))), float(rng.uniform(-12.0, 12.0))
+    sizes = [int(rng.choice([1, 1000, 4097, 65_536, 1_000_000, 3_300_001])) for _ in range(3)]
+    blocks, pos = [], int(rng.choice([0, 0, 12_345, 10 ** 9]))
+    for i, n in enumerate(sizes):
+        if i == 2 and rng.random() < 0.5:
+            pos += 10 ** 8                                       # a seek: the filter state carries on, as in the reference
+        blocks.append((pos, n))
+        pos += n
+    pg.set_sample_rate(sr)
+    look_ahead.set_enabled(False)
+    try:
+        pe = pg.BiquadPE(pg.SinePE(frequency=freq, amplitude=amp, phase=phase), frequency=cutoff, q=q,
+                         mode=pg.BiquadMode(mode), gain_db=gain_db)
+        r = pg.NullRenderer(sample_rate=sr)
+        r.set_source(pe)
+        r.start()
+        got = [pe.render(s, n).data.copy() for s, n in blocks]
+        r.stop()
+    finally:
+        look_ahead.set_enabled(True)
+    st = O.biquad_state(1)
+    peak = 0.0
+    wants = []
+    for s, n in blocks:
+        wants.append(O.biquad_const(st, O.sine_pure(s, n, freq, amp, phase, sr=sr), cutoff, q, mode, gain_db, sr))
+        peak = max(peak, float(np.max(np.abs(wants[-1]))))
+    for (s, n), g, w in zip(blocks, got, wants):
+        err = float(np.max(np.abs(g.astype(np.float64) - w)))
+        assert err <= 1e-6 * peak + 1e-9, (s, n, err, peak, sr, freq, amp, phase, mode, cutoff, q, gain_db)
