@@ -180,3 +180,49 @@ def test_frequency_stream_over_a_long_window():
     got, want = _hip(spec, 48000, blocks), _oracle(spec, 48000, blocks)
     for i, (g, w) in enumerate(zip(got, want)):
         assert np.array_equal(g, w), (i, int(np.sum(g != w)))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_COMB", "16"))))
+def test_random_combs_against_the_oracle(seed):
+    """Random CombPEs -- scalar or PE-driven frequency (swept through and below min_frequency), scalar or PE-driven
+    feedback, smoothing from 1 to 4800 samples, min_frequency from 2 Hz (ring in HBM) to 60 Hz, mono / stereo noise or an
+    oscillator in front, and pulls from 1 frame to 300 000 (one segment, many segments, streams of equal small blocks
+    through look-ahead windows, a seek) -- every block against the oracle's loop (bit-exact where the docstring above
+    says so; this test does not tell the cases apart)."""
+    S = _S()
+    rng = np.random.default_rng(77_000 + seed)
+    sr = int(rng.choice([44100, 48000]))
+    ch = int(rng.choice([1, 2]))
+    src = [S("ArrayPE", data=NOISE1 if ch == 1 else NOISE),
+           S("BlitSawPE", frequency=float(rng.uniform(50.0, 900.0)), channels=ch),
+           S("SinePE", frequency=float(rng.uniform(50.0, 5000.0)), amplitude=0.5, channels=ch)][int(rng.integers(0, 3))]
+    kw = {}
+    if rng.random() < 0.5:
+        kw["frequency"] = float(np.exp(rng.uniform(np.log(25.0), np.log(20000.0))))
+    else:
+        lo, hi = sorted(float(v) for v in np.exp(rng.uniform(np.log(10.0), np.log(3000.0), 2)))
+        kw["frequency"] = _sweep(lo if rng.random() < 0.8 else -lo, hi, float(rng.uniform(0.2, 8.0)))
+        kw["min_frequency"] = float(rng.choice([2.0, 20.0, 30.0, 60.0]))
+        kw["smoothing_samples"] = int(rng.choice([1, 50, 480, 2400, 4800]))
+    kw["feedback"] = (float(rng.uniform(-0.98, 0.98)) if rng.random() < 0.6
+                      else S("SinePE", frequency=float(rng.uniform(0.1, 5.0)), amplitude=float(rng.uniform(0.3, 1.2))))
+    spec = S("CombPE", source=src, **kw)
+    pattern = int(rng.integers(0, 3))
+    if pattern == 0:
+        sizes = [int(rng.choice([1, 17, 1000, 5000, 44_100])) for _ in range(5)]
+    elif pattern == 1:
+        sizes = [int(rng.choice([44_100, 100_001, 300_000])), 2000, int(rng.choice([1, 48_000]))]
+    else:
+        sizes = [int(rng.choice([256, 1024, 4096]))] * int(rng.integers(12, 40))
+    blocks = _contig(sizes, start=int(rng.choice([0, 0, 777])))
+    if rng.random() < 0.4 and len(blocks) > 3:                       # a seek in the middle of the stream
+        k = len(blocks) // 2
+        blocks = blocks[:k] + [(s + 100_000, n) for s, n in blocks[k:]]
+    got, want = _hip(spec, sr, blocks), _oracle(spec, sr, blocks)
+    peak = max(float(np.max(np.abs(w))) for w in want) or 1.0
+    # the comb itself: 1e-6 (float32 noise in, exact or 1e-7 out).  Behind an oscillator it repeats what the oscillator's
+    # long-block kernels are off by (<= 1e-6 of THEIR peak) with its own gain, 1 / (1 - |feedback|): the 1e-5 budget
+    tol = 1e-6 if src["pe"] == "ArrayPE" else 1e-5
+    for i, ((s, n), g, w) in enumerate(zip(blocks, got, want)):
+        err = float(np.max(np.abs(g.astype(np.float64) - w)))
+        assert err <= tol * peak, (i, s, n, err, peak, sr, ch, kw)
