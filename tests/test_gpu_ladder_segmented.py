@@ -153,3 +153,56 @@ def test_pe_driven_cutoff_and_resonance_run_in_time_segments():
         peak = float(np.max(np.abs(w)))
         assert float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak
         assert float(np.max(np.abs(a.astype(np.float64) - w))) <= 1e-5 * peak
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_LADDER", "12"))))
+def test_random_ladders_with_streams_against_the_oracle(seed):
+    """Random LadderPEs -- every mode, oversample 1..4, scalar or PE-driven cutoff / resonance / drive (sweeps of random
+    depth and rate), mono or stereo oscillator in front, pulls from 17 frames to 150 000 (sequential kernel, time
+    segments with the warm-up taken from the block's own range, look-ahead windows over streams of small blocks) --
+    against the oracle's loop.  Resonance stays below 0.6: the region where the reference is well-conditioned."""
+    import pygmu2_amd as pg
+    import spec_build
+    from oracle import graph_eval
+    from oracle.golden_cases import S
+    rng = np.random.default_rng(88_000 + seed)
+    sr = int(rng.choice([44100, 48000]))
+    ch = int(rng.choice([1, 2]))
+    sine = lambda f, a: S("SinePE", frequency=f, amplitude=a)
+
+    def maybe_stream(lo, hi):
+        mid, dev = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        if rng.random() < 0.5:
+            return float(rng.uniform(lo, hi))
+        return S("MixPE", inputs=[S("ConstantPE", value=mid), sine(float(rng.uniform(0.1, 6.0)), float(rng.uniform(0.1, 1.0)) * dev)])
+
+    src = (S("BlitSawPE", frequency=float(rng.uniform(40.0, 800.0)), channels=ch) if rng.random() < 0.6
+           else S("SuperSawPE", frequency=float(rng.uniform(40.0, 400.0)), voices=int(rng.integers(2, 6)), seed=int(seed),
+                  channels=ch))
+    spec = S("LadderPE", source=src, frequency=maybe_stream(150.0, 5000.0), resonance=maybe_stream(0.0, 0.6),
+             mode=str(rng.choice(["lp24", "lp12", "bp12", "hp24", "hp12"])), drive=maybe_stream(0.5, 2.0),
+             oversample=int(rng.integers(1, 5)))
+    pattern = int(rng.integers(0, 3))
+    if pattern == 0:
+        sizes = [int(rng.choice([17, 1000, 5000, 20_000])) for _ in range(4)]
+    elif pattern == 1:
+        sizes = [int(rng.choice([48_000, 100_001, 150_000])), 4096, int(rng.choice([17, 48_000]))]
+    else:
+        sizes = [int(rng.choice([1024, 4096]))] * int(rng.integers(12, 30))
+    blocks, pos = [], 0
+    for n in sizes:
+        blocks.append((pos, n))
+        pos += n
+    pg.set_sample_rate(sr)
+    pe = spec_build.build(spec)
+    r = pg.NullRenderer(sample_rate=sr)
+    r.set_source(pe)
+    r.start()
+    got = [pe.render(s, n).data.copy() for s, n in blocks]
+    r.stop()
+    g = graph_eval.Node(spec, sr)
+    want = [g.render(s, n) for s, n in blocks]
+    peak = max(float(np.max(np.abs(w))) for w in want) or 1.0
+    for i, ((s, n), a, w) in enumerate(zip(blocks, got, want)):
+        err = float(np.max(np.abs(a.astype(np.float64) - w)))
+        assert err <= 1e-5 * peak, (i, s, n, err, peak, sr, spec)
