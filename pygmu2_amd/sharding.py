@@ -249,7 +249,9 @@ class ShardedMixPE(ProcessingElement):
             whole = self._reducer.all_reduce(Snippet(start, window))
             self._reduced = (window, whole, whole._dev)       # (the previous window's wait is enqueued here, when it is dropped)
         elif self._reduced is None or self._reduced[0] is not window:
-            raise RuntimeError("ShardedMixPE: a row of a window whose first row was never reduced")
+            # a window whose first row did not pass through here (somebody pulled the local mix directly -- on every
+            # rank, by the contract): its rows are reduced one by one
+            return self._reducer.all_reduce(part)
         _, whole, buf = self._reduced
 
         def ready():

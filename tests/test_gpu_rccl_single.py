@@ -185,6 +185,43 @@ for i in range(8):
     y = plain8.render(i * 48000, 48000).data
     assert float(np.max(np.abs(got4[i].astype(np.float64) - y))) <= 1e-5 * float(np.max(np.abs(y))), i
 r.stop()
+# random pulls (streams of equal blocks with seeks, steps back, odd lengths, a direct pull of the local mix in between):
+# the share through the reducer -- windows reduced whole, rows handed out, windows abandoned half-way -- equals the local
+# mix of the owned voices rendered pull by pull (one rank: the sum over ranks is the identity)
+from pygmu2_amd import voice_bank
+for case in range(6):
+    rng = np.random.default_rng(300 + case)
+    make, total = ((supersaw_voice, 512), (c4_voice, 64))[case % 2]
+    n = int(rng.choice([4096, 12_288, 48_000]))
+    pos, pulls = 0, []
+    for _ in range(int(rng.integers(14, 26))):
+        what = rng.random()
+        if what < 0.08:
+            pos += int(rng.integers(1, 100_000))
+        elif what < 0.12:
+            pos = max(0, pos - int(rng.integers(1, 3 * n)))
+        size = n if rng.random() < 0.9 else int(rng.choice([17, 5000, 2 * n]))
+        pulls.append((pos, size, rng.random() < 0.05))
+        pos += size
+    shard = ShardedMixPE([make(pg, i) for i in range(total)], 0, 8, reducer=RcclReducer())
+    r = pg.NullRenderer(48000); r.set_source(shard); r.start()
+    got = []
+    for s, m, direct in pulls:
+        got.append((shard.local if direct else shard).render(s, m).data.copy())
+    r.stop()
+    keep_switches = {k: getattr(voice_bank, k) for k in ("BANK_WINDOWS", "LADDER_WINDOWS", "PREFETCH_SUPERSAW_VOICES",
+                                                          "PREFETCH_LADDER_INPUT")}
+    for k in keep_switches:
+        setattr(voice_bank, k, False)
+    plain = pg.MixPE(*[make(pg, i) for i in shard_indices(total, 0, 8)])
+    r = pg.NullRenderer(48000); r.set_source(plain); r.start()
+    want = [plain.render(s, m).data.copy() for s, m, _ in pulls]
+    r.stop()
+    for k, v in keep_switches.items():
+        setattr(voice_bank, k, v)
+    peak = max(float(np.max(np.abs(w))) for w in want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak, (case, i, pulls[i])
 comm.destroy()
 assert not comm.initialised()
 assert "torch" not in sys.modules
