@@ -66,9 +66,9 @@ class RcclReducer:
     a row view of a read-ahead window, a pass-through Snippet), so it is only read.  Every rank issues the
     same collective whatever its local payload was (a rank that owns nothing uploads its zeros).  The host
     does not block: the collective is ordered behind the library stream, and the returned Snippet carries a
-    `ready` hook that orders the library stream behind the collective only when the payload is used or
-    dropped -- rendering the next block overlaps this block's all-reduce over xGMI.  The local payload is
-    kept alive by that hook until then.
+    `ready` hook that orders the library stream behind the collective only when the payload is USED --
+    rendering the next block overlaps this block's all-reduce over xGMI.  A result dropped unread makes nobody
+    wait: its buffers (and the local payload) are parked and released by a later wait (all_reduce).
     """
 
     def __init__(self):
@@ -80,6 +80,9 @@ class RcclReducer:
         self.rank, self.world = comm.info()
         self.calls = 0                # collectives issued, floats reduced (bench.py reports them)
         self.floats = 0
+        self._parked = []             # (ticket, buffers kept alive) of results dropped unread, oldest first
+
+    PARK_MAX = 8                      # results dropped unread before the library stream is made to wait for them
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         import ctypes as C
@@ -90,12 +93,38 @@ class RcclReducer:
         out = dev.DeviceBuffer(src.shape, np.float32)
         ticket = C.c_int64(0)
         dev.check(lib.pgx_allreduce_sum(out.ptr, src.ptr, src.nbytes // 4, C.byref(ticket)), "pgx_allreduce_sum")
-        hold = [snippet]
+        hold = [snippet, out]
+        parked = self._parked
 
         def ready():
+            # the payload is about to be used: the library stream waits for this collective -- and with it for every
+            # earlier one (one in-order collective stream), so whatever was parked before it may go back to the pool
             dev.check(lib.pgx_allreduce_wait(ticket.value), "pgx_allreduce_wait")
-            hold.clear()                                # the local payload may return to the pool now
+            hold.clear()
+            while parked and parked[0][0] <= ticket.value:
+                parked.pop(0)[1].clear()
+
+        def dropped():
+            # nobody looked at this block (a pipelined caller that keeps only the latest): nothing has to wait for it
+            # NOW -- a wait is a barrier packet on the library stream, and a stalled queue costs ~17 us to wake -- but its
+            # buffers must outlive the collective: they are parked, and one wait per PARK_MAX blocks releases them
+            parked.append((ticket.value, hold))
+            if len(parked) >= self.PARK_MAX:
+                newest = parked[-1][0]
+                dev.check(lib.pgx_allreduce_wait(newest), "pgx_allreduce_wait")
+                for _, h in parked:
+                    h.clear()
+                parked.clear()
+        ready.on_drop = dropped
         return Snippet(snippet.start, out, ready=ready)
+
+    def __del__(self):
+        try:
+            if self._parked:
+                self._device.check(self._lib.pgx_allreduce_wait(self._parked[-1][0]), "pgx_allreduce_wait")
+                self._parked.clear()
+        except Exception:
+            pass
 
 
 class TorchReducer:

@@ -84,8 +84,12 @@ class Snippet:
 
     def __del__(self):
         try:
-            if self._ready is not None and getattr(self._ready, "on_use_only", False):
+            ready = self._ready
+            if ready is not None and getattr(ready, "on_use_only", False):
                 self._ready = None              # (a row of a window somebody else keeps alive and waits for)
+            elif ready is not None and getattr(ready, "on_drop", None) is not None:
+                self._ready = None              # (dropped unread: the producer has its own way of letting go)
+                ready.on_drop()
             self._resolve()
             if self._copy is not None:          # a prefetch nobody read: the payload must outlive the copy
                 from .device import fence_to_host
