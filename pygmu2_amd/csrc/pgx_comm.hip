@@ -210,7 +210,15 @@ int pgx_comm_init(int rank, int world, const void *id_host, size_t len) {
     }
     int least = 0, greatest = 0;
     ok = ok && step(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    ok = ok && step(hipStreamCreateWithPriority(&cstream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    // Normal priority.  The library's side stream (envelope walks a block ahead) is the high-priority queue of the
+    // process; a second one for the collectives made the two take turns: with a 1-rank communicator a rank's 64 C5
+    // voices went from 53 us per block to 104-111 (edge search 5 -> 45 us, walk 34 -> 57 us in the kernel trace), at
+    // normal priority 55.6.  PGX_COMM_PRIORITY overrides (-1 high, 1 low: 68-173 us).
+    (void)least;
+    (void)greatest;
+    int prio = 0;
+    if (getenv("PGX_COMM_PRIORITY")) prio = atoi(getenv("PGX_COMM_PRIORITY"));
+    ok = ok && step(hipStreamCreateWithPriority(&cstream, hipStreamNonBlocking, prio), "hipStreamCreateWithPriority");
     for (int i = 0; ok && i < kRing; ++i) ok = step(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming), "hipEventCreateWithFlags");
     for (int i = 0; ok && i < kRing; ++i) ok = step(hipEventCreateWithFlags(&done[i], hipEventDisableTiming), "hipEventCreateWithFlags");
     ok = ok && step(hipMalloc(&scratch, sizeof(double)), "hipMalloc");
