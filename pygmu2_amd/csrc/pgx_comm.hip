@@ -71,15 +71,20 @@ struct Comm {
     bool stop = false;
     std::string worker_error;    // first failure of the issue thread (sticky)
 
-    ~Comm() { stop_worker(); }   // (a process that exits without pgx_comm_destroy: the thread is idle, it just ends)
-    void stop_worker() {
+    // (a process that exits without pgx_comm_destroy: an idle thread just ends; one that is inside a collective whose
+    // peers are gone would never come back -- it is left behind instead of joined, and ends with the process)
+    ~Comm() { stop_worker(true); }
+    void stop_worker(bool at_exit = false) {
         if (!worker.joinable()) return;
+        bool busy;
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
+            busy = recorded < issued;
         }
         cv_work.notify_all();
-        worker.join();
+        if (at_exit && busy) worker.detach();
+        else worker.join();
         stop = false;
     }
 };
