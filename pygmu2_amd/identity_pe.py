@@ -13,7 +13,14 @@ class IdentityPE(SourcePE):
     def __init__(self, channels: int = 1):
         self._channels = channels
 
+    # read_ahead.py / look_ahead.py: below 2^24 every index is a float32, whatever block it is rendered in
+    _READ_AHEAD_SAFE = True
+
     def _render(self, start: int, duration: int) -> Snippet:
+        if max(abs(start), abs(start + duration)) >= 1 << 24:
+            from . import look_ahead, read_ahead
+            if read_ahead.busy() or look_ahead._busy():
+                raise read_ahead.Declined("IdentityPE beyond 2^24: the arange fill depends on the block start")
         out = new_output(duration, self._channels)
         # The reference builds np.arange(start, start+n, dtype=float32); numpy fills that as
         # first + i*delta in float32 with first = float32(start), delta = float32(start+1) - first.

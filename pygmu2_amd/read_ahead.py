@@ -6,10 +6,10 @@ overhead (the reference's own profile_biquad_vs_svfilter.py / AudioRenderer loop
 such blocks).  A pure PE is a function of (start, duration) only, so when a pure sub-graph is
 pulled sequentially in small blocks the root of that sub-graph renders 64 blocks in ONE launch
 sequence and hands out row-views of the resident result.  The samples are the same samples: every
-kernel on these paths computes a frame from its absolute index alone (IdentityPE is excluded: its
-numpy `arange` fill rule depends on the block start for |index| >= 2^24).
+kernel on these paths computes a frame from its absolute index alone (IdentityPE up to |index| < 2^24: beyond,
+its numpy `arange` fill rule depends on the block start, and it declines the window).
 
-Scope: SinePE with scalar parameters, GainPE, MixPE, ConstantPE, DiracPE, ArrayPE, CropPE,
+Scope: SinePE with scalar parameters, GainPE, MixPE, ConstantPE, IdentityPE, DiracPE, ArrayPE, CropPE,
 PeriodicGate, PeriodicTrigger -- and only when every input is itself eligible.  MixPE only while all
 of its inputs have unbounded extents: its rule "skip an input whose extent misses the requested window"
 (mix_pe.py:81-85) makes the output depend on the window, not just the frame index, as soon as an input
@@ -32,6 +32,16 @@ AHEAD_FRAMES = 1 << 25      # ... and about this many frames (128 MB per channel
 
 _tls = threading.local()
 _ENABLED = os.environ.get("PYGMU_READ_AHEAD", "1").strip().lower() not in ("0", "false", "no", "off")
+
+
+class Declined(Exception):
+    """Raised by a PE's _render while a window is being rendered for it (busy()): this particular range cannot be
+    rendered in one piece with the blocks' samples (IdentityPE beyond 2^24).  The window is given up, the request takes
+    the block-by-block path and the sub-graph stops opening windows."""
+
+
+def busy() -> bool:
+    return getattr(_tls, "busy", False)
 
 
 def enabled() -> bool:
@@ -85,6 +95,10 @@ def render(pe, start: int, duration: int):
     _tls.busy = True
     try:
         big = pe._render(start, duration * max(2, min(grow, ahead_blocks(duration))))
+    except Declined:
+        d["_ra_ok"] = False
+        d.pop("_ra_win", None)
+        return None
     finally:
         _tls.busy = False
     if not big.on_device:

@@ -55,7 +55,6 @@ def test_read_ahead_is_sample_identical(graph):
 def test_read_ahead_skips_stateful_and_index_quirk_graphs():
     pg.set_sample_rate(44100)
     assert not read_ahead.eligible(pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707))
-    assert not read_ahead.eligible(pg.GainPE(pg.IdentityPE(), 2.0))
     assert not read_ahead.eligible(pg.SinePE(frequency=pg.SinePE(5.0)))
     assert not read_ahead.eligible(pg.WindowPE(pg.SinePE(440.0), mode=pg.WindowMode.RMS))    # block-grouped sums
     assert not read_ahead.eligible(pg.LoopPE(pg.BiquadPE(pg.SinePE(440.0), 1000.0, 0.707), 0, 1000))
@@ -93,3 +92,31 @@ def test_mix_with_bounded_inputs_is_not_read_ahead():
     g = graph_eval.Node(spec, 48000)
     for (s, n), out in zip(blocks, got):
         assert np.array_equal(out, g.render(s, n)), (s, n)
+
+
+def test_identity_pe_streams_through_windows_below_2_24_and_declines_beyond():
+    """np.arange(start, start + n, dtype=float32) is filled as first + i * delta in float32: every index below 2^24 is a
+    float32 whatever block it is rendered in (read-ahead windows), beyond that the samples depend on the block start --
+    IdentityPE declines the window that would cross the line and the stream goes on block by block, same samples."""
+    pg.set_sample_rate(44100)
+
+    def want(start, n):
+        return np.arange(start, start + n, dtype=np.float32).reshape(-1, 1)
+
+    pe = pg.GainPE(pg.IdentityPE(), 2.0)
+    assert read_ahead.eligible(pe)
+    r = pg.NullRenderer(44100)
+    r.set_source(pe)
+    r.start()
+    opened = False
+    for i in range(40):
+        got = pe.render(i * 1024, 1024).data
+        opened = opened or pe.__dict__.get("_ra_win") is not None
+        assert np.array_equal(got, 2.0 * want(i * 1024, 1024))
+    assert opened
+    base = (1 << 24) - 20 * 1024 - 7                       # a stream that walks across 2^24 (odd start: odd / even indices)
+    for i in range(60):
+        got = pe.render(base + i * 1024, 1024).data
+        assert np.array_equal(got, 2.0 * want(base + i * 1024, 1024)), i
+    assert not read_ahead.eligible(pe)                     # declined once: block by block from there on
+    r.stop()
