@@ -257,7 +257,11 @@ __device__ __forceinline__ double ladder_tanh_mid(double x) {
 
 // STREAMS: cutoff / resonance / drive per sample from the control streams (the coefficient polynomials then sit in
 // the sample loop: ~15 more operations, none of them on the feedback chain).
-template <bool FAST, int OS, bool STREAMS = false>
+// EMIT: the same arithmetic WITH the output taps, samples written (a time segment's own samples in k_ladder_segments:
+// what a segment emits is within ~1e-10 of the reference's trajectory anyway -- it started from a warm-up, not from
+// the true state -- so the fused, regrouped stages and the ~1e-11 tanh cost nothing that the form had not given up
+// already, and a sample is 38 dependent operations instead of 60).
+template <bool FAST, int OS, bool STREAMS = false, bool EMIT = false>
 __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderState &s, int64_t i0, int64_t i1) {
     const double state_decay = 0.95, input_threshold = 1e-5, resonance_multiplier = 1.8;
     const double two_pi = 2.0 * 3.141592653589793;
@@ -283,7 +287,9 @@ __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderSt
     if (!STREAMS) coefficients(0);
     const int oversample = OS ? OS : c.oversample;               // OS = 2: a constant trip count, unrolled
 
-    auto sample = [&](float x, int64_t i) {
+    const int mode = EMIT ? __builtin_amdgcn_readfirstlane(c.mode) : 0;
+    const bool mode_uniform = EMIT ? (bool)__all(c.mode == mode) : true;
+    auto sample = [&](float x, int64_t i) -> float {
         if (STREAMS) coefficients(i);
         const double input_sample = (double)x * drive_scaled;
         const double decay = fabs(input_sample) < input_threshold ? state_decay : 1.0;   // a select: no branch
@@ -293,7 +299,7 @@ __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderSt
             s.z1[q] *= decay;
         }
         s.old_input *= decay;
-        double interp = 0.0;
+        double interp = 0.0, total = 0.0;
 #pragma unroll
         for (int os = 0; os < oversample; ++os) {
             const double in_interp = __builtin_fma(interp, s.old_input, (1.0 - interp) * input_sample);
@@ -304,32 +310,60 @@ __device__ __forceinline__ void ladder_warm_impl(const LadderConsts &c, LadderSt
             double w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] = __builtin_fma(ac1, s.z0[q], oma * s.z1[q]);
-            double stage_in = FAST ? ladder_tanh_fast(g) : ladder_tanh_mid(g);
+            const double u = FAST ? ladder_tanh_fast(g) : ladder_tanh_mid(g);
+            double stage_in = u, st[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double ft = __builtin_fma(ac0, stage_in, w[q]);
                 s.z1[q] = ft;
                 s.z0[q] = stage_in;
                 stage_in = ft;
+                st[q] = ft;
+            }
+            if (EMIT) {                                          // the output taps of ladder_pe.py:183-197
+                const int m = mode_uniform ? mode : c.mode;
+                double weighted;
+                if (m == 0) weighted = st[3];
+                else if (m == 1) weighted = st[1];
+                else if (m == 2) weighted = (st[1] + st[3]) * 4.0 - st[2] * 8.0;
+                else if (m == 3) weighted = (st[0] - st[1]) * 2.0;
+                else if (m == 4) weighted = u + st[3] - (st[0] + st[2]) * 4.0 + st[1] * 6.0;
+                else weighted = u + st[1] - st[0] * 2.0;
+                total += weighted * c.oversample_recip;
             }
             interp += c.oversample_recip;
         }
         s.old_input = input_sample;
+        return (float)total;
     };
     int64_t base = i0;
     if (i1 - i0 >= kLadderChunk) {
         float xn[kLadderChunk];
         ladder_load8(c, base, xn);
         for (; base + kLadderChunk <= i1; base += kLadderChunk) {
-            float xc[kLadderChunk];
+            float xc[kLadderChunk], yc[kLadderChunk];
 #pragma unroll
             for (int j = 0; j < kLadderChunk; ++j) xc[j] = xn[j];
             if (base + 2 * kLadderChunk <= i1) ladder_load8(c, base + kLadderChunk, xn);
 #pragma unroll
-            for (int j = 0; j < kLadderChunk; ++j) sample(xc[j], base + j);
+            for (int j = 0; j < kLadderChunk; ++j) yc[j] = sample(xc[j], base + j);
+            if (EMIT) ladder_store8(c, base, yc);
         }
     }
-    for (; base < i1; ++base) sample(c.x[base * c.channels + c.ch], base);
+    for (; base < i1; ++base) {
+        const float y = sample(c.x[base * c.channels + c.ch], base);
+        if (EMIT) c.o[base * c.channels + c.ch] = y;
+    }
+}
+
+// A time segment's own samples [i0, i1), written (k_ladder_segments).
+__device__ __forceinline__ void ladder_emit(const LadderConsts &c, LadderState &s, int64_t i0, int64_t i1) {
+    if (c.freq || c.resonance || c.drive) {                                      // kernel arguments: uniform
+        ladder_warm_impl<false, 0, true, true>(c, s, i0, i1);
+        return;
+    }
+    if (__all(c.oversample == 2)) ladder_warm_impl<false, 2, false, true>(c, s, i0, i1);
+    else ladder_warm_impl<false, 0, false, true>(c, s, i0, i1);
 }
 
 template <bool FAST>
@@ -390,6 +424,7 @@ k_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int
 
 // One lane per (chain, segment).  warm[chain][seg] = state on entering the segment's first output
 // sample, ends[chain][seg] = state after its last one.
+template <bool EXACT_EMIT>
 __global__ void __launch_bounds__(256)
 k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
                   int channels, double sr, const pgx_ladder_params *params, const float *freq,
@@ -432,7 +467,12 @@ k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_st
     (void)scalar_params;             // (control streams take the same three phases: ladder_warm reads them per sample)
     ladder_warm<true>(c, s, w0, w1);
     ladder_warm<false>(c, s, w1, sb);
-    ladder_advance(c, s, sb, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
+    if (EXACT_EMIT) {                                            // PGX_LADDER_EXACT_EMIT=1: the reference's operation order
+        ladder_advance(c, s, sb, sb, se, warm + ((int64_t)chain * nseg + seg) * 9);
+    } else {
+        ladder_store(warm + ((int64_t)chain * nseg + seg) * 9, s);   // state on entering the first output sample
+        ladder_emit(c, s, sb, se);
+    }
     ladder_store(ends + ((int64_t)chain * nseg + seg) * 9, s);
 }
 
@@ -492,7 +532,27 @@ LadderPlan ladder_plan(int batch, int64_t n, int channels, int64_t settle) {
     // CU: measured on C4 (64 chains x 48 000 frames, settle 1024), ms per block by lane count: 8 Ki 0.66, 16 Ki
     // 0.58, 24 Ki 0.56, 32 Ki 0.555, 48 Ki 0.78, 64 Ki 0.83 (the unrolled sample loop is ~40 KB of code: more waves
     // per CU at different places in it fall out of the instruction cache).  Never shorter than 32 samples.
-    static const int64_t lanes_target = getenv("PGX_LADDER_LANES") ? atoll(getenv("PGX_LADDER_LANES")) : 32768;
+    // With windows of several blocks (voice_bank.py) the segments are long enough for more lanes to pay: C4 in
+    // 8-block windows, ms per block by lane count: 16 Ki 0.1205, 24 Ki 0.0928, 32 Ki 0.0805, 40 Ki 0.0742, 48 Ki 0.0710,
+    // 64 Ki 0.0736, 96 Ki 0.089.  Both sets of numbers fit time ~ (0.6 settle + seg_len) x cost(lanes), the warm-up
+    // being mostly float32-tanh steps and cost = what a step slows down by as the waves per CU grow: the plan is the
+    // lane count that minimises it (PGX_LADDER_LANES fixes the count).
+    static const int64_t lanes_fixed = getenv("PGX_LADDER_LANES") ? atoll(getenv("PGX_LADDER_LANES")) : 0;
+    int64_t lanes_target = lanes_fixed;
+    if (lanes_target <= 0) {
+        static const struct { int64_t lanes; double cost; } kChoices[] = {
+            {16384, 0.96}, {24576, 0.97}, {32768, 1.0}, {40960, 1.04}, {49152, 1.08}, {65536, 1.27}};
+        double best = 0.0;
+        for (const auto &choice : kChoices) {
+            double seg = (double)n * (double)chains / (double)choice.lanes;
+            if (seg < 32.0) seg = 32.0;
+            const double t = (0.6 * (double)settle + seg) * choice.cost;
+            if (lanes_target <= 0 || t < best) {
+                best = t;
+                lanes_target = choice.lanes;
+            }
+        }
+    }
     int64_t seg_len = pgx::ceil_div(n * chains, lanes_target);
     if (seg_len < 32) seg_len = 32;
     if (n < 2 * (settle + seg_len)) return p;                     // nothing to win
@@ -547,16 +607,23 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
         lds = (size_t)lds_claim;
         static bool allowed = false;
         if (!allowed && lds > 64 * 1024) {
-            PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ladder_segments),
+            PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ladder_segments<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ladder_segments<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             allowed = true;
         }
     }
-    hipLaunchKernelGGL(k_ladder_segments, dim3(groups), dim3(wg), lds, pgx::stream(), out,
-                       out_stride, in, in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
-                       (const double *)state, settle_frames,
-                       accurate_frames > 0 && accurate_frames < settle_frames ? accurate_frames : settle_frames,
-                       p.seg_len, p.nseg, warm, ends);
+    static const bool exact_emit = getenv("PGX_LADDER_EXACT_EMIT") && atoi(getenv("PGX_LADDER_EXACT_EMIT")) != 0;
+    const int64_t tail = accurate_frames > 0 && accurate_frames < settle_frames ? accurate_frames : settle_frames;
+    if (exact_emit)
+        hipLaunchKernelGGL(k_ladder_segments<true>, dim3(groups), dim3(wg), lds, pgx::stream(), out, out_stride, in,
+                           in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
+                           (const double *)state, settle_frames, tail, p.seg_len, p.nseg, warm, ends);
+    else
+        hipLaunchKernelGGL(k_ladder_segments<false>, dim3(groups), dim3(wg), lds, pgx::stream(), out, out_stride, in,
+                           in_stride, batch, n, channels, sample_rate, params, freq, resonance, drive,
+                           (const double *)state, settle_frames, tail, p.seg_len, p.nseg, warm, ends);
     PGX_LAUNCH_CHECK("k_ladder_segments");
     hipLaunchKernelGGL(k_ladder_finish, dim3(chains), dim3(64), 0, pgx::stream(), out, out_stride, in, in_stride, n,
                        channels, sample_rate, params, freq, resonance, drive, state, settle_frames, p.seg_len,
