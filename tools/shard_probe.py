@@ -17,13 +17,16 @@ for world in [int(w) for w in os.environ.get("PGX_WORLDS", "1,2,4,8").split(",")
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
     r.start()
-    for i in range(3):
+    # (15 blocks of warm-up: a small bank's windows of 2, 4, 8 blocks open -- and their buffers are allocated, a hipMalloc
+    # of a few hundred MB is milliseconds on some boxes -- before the clock starts; 24 timed blocks = three whole windows)
+    warm = 15
+    for i in range(warm):
         root.render(i * block, block)
     device.synchronize()
     t0 = time.perf_counter()
-    reps = 20
+    reps = 24
     for i in range(reps):
-        keep = root.render((3 + i) * block, block)
+        keep = root.render((warm + i) * block, block)
     device.synchronize()
     dt = (time.perf_counter() - t0) / reps
     r.stop()
