@@ -16,7 +16,7 @@ for world in (8, 4, 2):
         root = ShardedMixPE([make(pg, i) for i in range(voices)], 0, world, reducer=RcclReducer())
         r = pg.NullRenderer(48000); r.set_source(root); r.start()
         keep = None
-        for i in range(7):
+        for i in range(15):             # (the windows of 2, 4, 8 blocks open, their buffers are allocated)
             keep = root.render(i * block, block)
         keep.dev
         device.synchronize()
@@ -24,7 +24,7 @@ for world in (8, 4, 2):
         t0 = time.perf_counter()
         reps = 48
         for i in range(reps):
-            keep = root.render((7 + i) * block, block)
+            keep = root.render((15 + i) * block, block)
         keep.dev
         device.synchronize()
         dt = (time.perf_counter() - t0) / reps
