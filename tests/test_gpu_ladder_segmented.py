@@ -206,3 +206,43 @@ def test_random_ladders_with_streams_against_the_oracle(seed):
     for i, ((s, n), a, w) in enumerate(zip(blocks, got, want)):
         err = float(np.max(np.abs(a.astype(np.float64) - w)))
         assert err <= 1e-5 * peak, (i, s, n, err, peak, sr, spec)
+
+
+def test_segment_samples_on_fused_arithmetic_against_the_reference_order(tmp_path):
+    """A segment's own samples run on the warm-up's fused, regrouped stages and a tanh good to ~1e-11 (ladder_emit);
+    PGX_LADDER_EXACT_EMIT=1 keeps the reference's operation order and pgx_tanh for them.  Same graph, same blocks, two
+    processes (the switch is read once): the two agree to 2e-7 of the peak -- a float32 ulp or two -- for every mode."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PGX_ROOT"])
+import pygmu2_amd as pg
+from pygmu2_amd import look_ahead
+pg.set_sample_rate(48000)
+look_ahead.set_enabled(False)
+outs = []
+for mode in ("lp24", "lp12", "bp12", "hp24", "hp12"):
+    pe = pg.LadderPE(pg.SuperSawPE(110.0, voices=5, seed=3, channels=2), frequency=1500.0, resonance=0.45,
+                     mode=pg.LadderMode(mode), drive=1.3, oversample=2)
+    r = pg.NullRenderer(48000); r.set_source(pe); r.start()
+    outs += [pe.render(i * 96_000, 96_000).data.copy() for i in range(2)]
+    assert pe._settle_frames() > 0
+    r.stop()
+np.save(sys.argv[1], np.concatenate(outs))
+''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for exact in ("0", "1"):
+        out = tmp_path / f"y{exact}.npy"
+        env = dict(os.environ, PGX_ROOT=root, PGX_LADDER_EXACT_EMIT=exact)
+        p = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+        got[exact] = np.load(out)
+    peak = float(np.max(np.abs(got["1"])))
+    err = float(np.max(np.abs(got["0"].astype(np.float64) - got["1"])))
+    assert err <= 2e-7 * peak, (err, peak)
+    assert np.mean(got["0"] != got["1"]) < 0.05
