@@ -592,12 +592,29 @@ int pgx_convolve_fft(float *out, const float *x, int64_t n, int src_channels, co
  *   pgx_allreduce_wait   orders the library stream behind the collective of `ticket` (stream-level wait:
  *                        the host blocks only until that collective has been handed to RCCL -- normally long
  *                        ago), after which `out` may be read and `in` released
- *   pgx_allreduce_scalar_host   synchronous sum (op 0) / max (op 1) of one host double over the ranks */
+ *   pgx_allreduce_scalar_host   synchronous sum (op 0) / max (op 1) of one host double over the ranks
+ *   pgx_comm_fold_check  every rank must issue the same sequence of collectives with the same counts.  The first 8
+ *                        tickets and every 16th after them (PGX_COMM_CHECK_FIRST / _EVERY) are preceded by a 32-byte
+ *                        all-reduce(max) of {n, -n, h, -h}: n this collective's count, h a running hash of every count
+ *                        so far and of every word folded in here (the caller's shared facts: window or block, rows,
+ *                        switches).  Ranks that disagree get PGX_ERR_RUNTIME ("ranks out of step ...") from the
+ *                        next call on the communicator instead of a hang or a corrupted sum; a check that does not
+ *                        complete within PGX_COMM_CHECK_TIMEOUT_MS (60 s) fails the same way.
+ *   pgx_comm_stats       tickets issued, agreement checks completed, current sequence hash (any pointer may be NULL)
+ *   pgx_comm_quiesce     PGX_OK once everything handed to the communicator has completed, PGX_ERR_RUNTIME after
+ *                        `timeout_ms` (a peer that died mid-collective never completes ours).  pgx_comm_destroy /
+ *                        pgx_shutdown use it with PGX_COMM_EXIT_TIMEOUT_MS (10 s): past the deadline the communicator
+ *                        is ABANDONED -- nothing of it is joined, synchronised or destroyed -- both return
+ *                        PGX_ERR_RUNTIME and pgx_comm_abandoned() says 1: the process should exit non-zero. */
 size_t pgx_comm_unique_id_bytes(void);
 int pgx_comm_unique_id(void *id_host, size_t len);
 int pgx_comm_init(int rank, int world, const void *id_host, size_t len);
 int pgx_comm_info(int *rank, int *world);        /* world == 0: no communicator */
 int pgx_comm_destroy(void);
+int pgx_comm_quiesce(int timeout_ms);
+int pgx_comm_abandoned(void);
+int pgx_comm_fold_check(int64_t word);
+int pgx_comm_stats(int64_t *issued, int64_t *checks, int64_t *hash);
 int pgx_allreduce_sum(float *out, const float *in, size_t n, int64_t *ticket);
 int pgx_allreduce_wait(int64_t ticket);
 int pgx_allreduce_scalar_host(double *value_host, int op);

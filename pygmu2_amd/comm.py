@@ -47,7 +47,25 @@ def initialised() -> bool:
 
 
 def destroy() -> None:
-    device.load_library().pgx_comm_destroy()
+    """Tear the communicator down; RuntimeError if collectives were still outstanding at the deadline
+    (PGX_COMM_EXIT_TIMEOUT_MS): the communicator is then abandoned, not destroyed."""
+    device.check(device.load_library().pgx_comm_destroy(), "pgx_comm_destroy")
+
+
+def fold_check(*words) -> None:
+    """Facts every rank must share about the collectives that follow (window or block, rows, switches): folded into
+    the sequence hash that the library's agreement checks compare across the ranks (pgx_comm_fold_check)."""
+    lib = device.load_library()
+    for w in words:
+        lib.pgx_comm_fold_check(int(w) & 0x7FFFFFFFFFFFFFFF)
+
+
+def stats() -> dict:
+    """Tickets issued, agreement checks completed, the current sequence hash."""
+    lib = device.load_library()
+    a, b, h = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    lib.pgx_comm_stats(C.byref(a), C.byref(b), C.byref(h))
+    return {"issued": a.value, "checks": b.value, "hash": h.value}
 
 
 def reduce_scalar(value: float, op: str = "sum") -> float:

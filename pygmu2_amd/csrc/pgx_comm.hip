@@ -18,9 +18,25 @@
 // first makes sure that event has been recorded (normally long ago), then orders the library stream behind it.  Jobs
 // are issued in ticket order, which is the call order -- the same on every rank.  The scalar reductions and
 // pgx_comm_destroy drain the queue first.
+//
+// Ranks out of step (round 4).  Every rank must issue the same sequence of collectives with the same element counts:
+// the callers above decide "one collective per window or per block" from facts every rank shares, but a rank whose
+// caller pulled differently would hang the communicator or corrupt a sum, silently.  So the first kCheckFirst tickets
+// and every kCheckEvery-th after them are preceded by a 32-byte all-reduce(max) of {n, -n, h, -h} -- n the element
+// count, h a running hash of every count and every word the caller folded in (pgx_comm_fold_check: window or block,
+// rows, switches) since the communicator was made.  A fixed-size collective cannot mismatch; max(n) == -max(-n) on
+// every rank exactly when all ranks agree.  The issue thread waits for it (with a deadline) before handing the payload
+// to RCCL; on disagreement or timeout the error is sticky and every later call on the communicator fails with it.
+//
+// Ending.  pgx_comm_quiesce(timeout) waits, with a deadline, until everything handed to the communicator has
+// completed; pgx_comm_destroy gives up after PGX_COMM_EXIT_TIMEOUT_MS (a peer that died mid-collective never
+// completes ours): the communicator is then abandoned -- nothing of it is joined, synchronised or destroyed -- and the
+// call reports it, so that the process can exit non-zero instead of hanging.  The singleton lives on the heap and is
+// never destroyed: an issue thread left behind never touches destroyed members.
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -50,7 +66,18 @@ struct Job {
     float *out;
     size_t n;
     int64_t ticket;
+    bool check;                  // preceded by the cross-rank agreement collective
+    int64_t hash;                // the sequence hash including this job
 };
+
+constexpr int64_t kHashMask = (int64_t(1) << 62) - 1;
+inline int64_t fold(int64_t h, int64_t word) {       // splitmix-style: every earlier word moves every later hash
+    uint64_t x = (uint64_t)h ^ ((uint64_t)word + 0x9e3779b97f4a7c15ull + ((uint64_t)h << 6) + ((uint64_t)h >> 2));
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return (int64_t)(x & (uint64_t)kHashMask);
+}
 
 struct Comm {
     Api api;
@@ -70,28 +97,57 @@ struct Comm {
     int64_t recorded = 0;        // tickets up to here have their completion event recorded
     bool stop = false;
     std::string worker_error;    // first failure of the issue thread (sticky)
+    // ranks-out-of-step check
+    int64_t seq_hash = 0;        // render thread: folded at every pgx_allreduce_sum / pgx_comm_fold_check
+    int check_first = 8, check_every = 16, check_timeout_ms = 60000;
+    int64_t fault_at = 0;        // test hook: this ticket's check contributes a disagreeing count
+    int64_t *chk_dev = nullptr, *chk_host = nullptr;   // 4 device words; 8 pinned words (in, out)
+    hipEvent_t chk_ev = nullptr;
+    int64_t checks_done = 0;
+    bool abandoned = false;      // a destroy that ran into its deadline: nothing of the communicator is touched again
 
-    // (a process that exits without pgx_comm_destroy: an idle thread just ends; one that is inside a collective whose
-    // peers are gone would never come back -- it is left behind instead of joined, and ends with the process)
-    ~Comm() { stop_worker(true); }
-    void stop_worker(bool at_exit = false) {
+    void stop_worker(bool detach = false) {
         if (!worker.joinable()) return;
-        bool busy;
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
-            busy = recorded < issued;
+            if (detach) jobs.clear();
         }
         cv_work.notify_all();
-        if (at_exit && busy) worker.detach();
+        if (detach) worker.detach();
         else worker.join();
         stop = false;
     }
 };
 
+// On the heap and never destroyed: static teardown must not run under an issue thread that was left behind inside a
+// collective whose peers are gone (it would lock a destroyed mutex); a process that ends without pgx_comm_destroy
+// simply ends.
 Comm &cm() {
-    static Comm c;
-    return c;
+    static Comm *c = new Comm;
+    return *c;
+}
+
+bool wait_event_for(hipEvent_t ev, int timeout_ms) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) return false;
+        if (std::chrono::steady_clock::now() >= deadline) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
+bool wait_stream_for(hipStream_t st, int timeout_ms) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) return false;
+        if (std::chrono::steady_clock::now() >= deadline) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 int load_api(Api &a) {
@@ -127,7 +183,33 @@ int load_api(Api &a) {
 // what issuing ticket `job.ticket` means, on whichever thread does it
 std::string issue(Comm &c, const Job &job) {
     const int slot = (int)(job.ticket % kRing);
-    hipError_t e = hipStreamWaitEvent(c.cstream, c.ev_in[slot], 0);
+    hipError_t e;
+    if (job.check) {
+        // do all ranks issue this collective with this count, after the same sequence?  (in front of the wait for
+        // the partial mix: only the collectives before it are in its way)
+        int64_t *in = c.chk_host, *out = c.chk_host + 4;
+        const int64_t n = (int64_t)job.n;
+        in[0] = n; in[1] = job.ticket == c.fault_at ? -(n + 1) : -n; in[2] = job.hash; in[3] = -job.hash;
+        e = hipMemcpyAsync(c.chk_dev, in, 4 * sizeof(int64_t), hipMemcpyHostToDevice, c.cstream);
+        if (e != hipSuccess) return std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
+        const ncclResult_t r = c.api.AllReduce(c.chk_dev, c.chk_dev, 4, ncclInt64, ncclMax, c.comm, c.cstream);
+        if (r != ncclSuccess) return std::string("ncclAllReduce (agreement check): ") + c.api.GetErrorString(r);
+        e = hipMemcpyAsync(out, c.chk_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, c.cstream);
+        if (e != hipSuccess) return std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
+        e = hipEventRecord(c.chk_ev, c.cstream);
+        if (e != hipSuccess) return std::string("hipEventRecord: ") + hipGetErrorString(e);
+        if (!wait_event_for(c.chk_ev, c.check_timeout_ms))
+            return "ranks out of step? the agreement check in front of collective " + std::to_string(job.ticket) +
+                   " did not complete within " + std::to_string(c.check_timeout_ms) + " ms";
+        ++c.checks_done;
+        if (out[0] != -out[1] || out[2] != -out[3])
+            return "ranks out of step at collective " + std::to_string(job.ticket) + ": this rank reduces " +
+                   std::to_string(n) + " floats (sequence hash " + std::to_string(job.hash) + "), the ranks' counts span " +
+                   std::to_string(-out[1]) + " .. " + std::to_string(out[0]) +
+                   (out[0] == -out[1] ? " (same count, different history of pulls)" : "") +
+                   " -- every rank must make the same sequence of pulls";
+    }
+    e = hipStreamWaitEvent(c.cstream, c.ev_in[slot], 0);
     if (e != hipSuccess) return std::string("hipStreamWaitEvent: ") + hipGetErrorString(e);
     if (job.n) {
         const ncclResult_t r = c.api.AllReduce(job.in, job.out, job.n, ncclFloat32, ncclSum, c.comm, c.cstream);
@@ -198,6 +280,8 @@ int pgx_comm_init(int rank, int world, const void *id_host, size_t len) {
     hipEvent_t ev_in[kRing] = {};
     hipEvent_t done[kRing] = {};
     double *scratch = nullptr;
+    int64_t *chk_dev = nullptr, *chk_host = nullptr;
+    hipEvent_t chk_ev = nullptr;
     std::string why;
     auto step = [&](hipError_t e, const char *what) {
         if (e == hipSuccess) return true;
@@ -227,7 +311,13 @@ int pgx_comm_init(int rank, int world, const void *id_host, size_t len) {
     for (int i = 0; ok && i < kRing; ++i) ok = step(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming), "hipEventCreateWithFlags");
     for (int i = 0; ok && i < kRing; ++i) ok = step(hipEventCreateWithFlags(&done[i], hipEventDisableTiming), "hipEventCreateWithFlags");
     ok = ok && step(hipMalloc(&scratch, sizeof(double)), "hipMalloc");
+    ok = ok && step(hipMalloc(&chk_dev, 4 * sizeof(int64_t)), "hipMalloc");
+    ok = ok && step(hipHostMalloc(&chk_host, 8 * sizeof(int64_t), hipHostMallocDefault), "hipHostMalloc");
+    ok = ok && step(hipEventCreateWithFlags(&chk_ev, hipEventDisableTiming), "hipEventCreateWithFlags");
     if (!ok) {
+        if (chk_ev) (void)hipEventDestroy(chk_ev);
+        if (chk_host) (void)hipHostFree(chk_host);
+        if (chk_dev) (void)hipFree(chk_dev);
         if (scratch) (void)hipFree(scratch);
         for (auto &e : done)
             if (e) (void)hipEventDestroy(e);
@@ -241,6 +331,17 @@ int pgx_comm_init(int rank, int world, const void *id_host, size_t len) {
     for (int i = 0; i < kRing; ++i) c.ev_in[i] = ev_in[i];
     for (int i = 0; i < kRing; ++i) c.done[i] = done[i];
     c.scratch = scratch;
+    c.chk_dev = chk_dev;
+    c.chk_host = chk_host;
+    c.chk_ev = chk_ev;
+    c.seq_hash = 0;
+    c.checks_done = 0;
+    c.abandoned = false;
+    auto env_int = [](const char *name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; };
+    c.check_first = env_int("PGX_COMM_CHECK_FIRST", 8);
+    c.check_every = env_int("PGX_COMM_CHECK_EVERY", 16);
+    c.check_timeout_ms = env_int("PGX_COMM_CHECK_TIMEOUT_MS", 60000);
+    c.fault_at = getenv("PGX_COMM_CHECK_FAULT_AT") ? atoll(getenv("PGX_COMM_CHECK_FAULT_AT")) : 0;
     c.rank = rank;
     c.world = world;
     c.issued = 0;
@@ -260,21 +361,82 @@ int pgx_comm_info(int *rank, int *world) {
     return PGX_OK;
 }
 
+// Everything handed to the communicator so far has completed (or `timeout_ms` have passed: PGX_ERR_RUNTIME).  No
+// communicator: PGX_OK.  The atexit hook of the Python layer asks this before it synchronises anything: a rank whose
+// peer died mid-collective then exits non-zero instead of hanging in hipStreamSynchronize.
+int pgx_comm_quiesce(int timeout_ms) {
+    Comm &c = cm();
+    if (!c.comm) return c.abandoned ? pgx::fail(PGX_ERR_RUNTIME, "pgx_comm: the communicator was abandoned") : PGX_OK;
+    if (timeout_ms < 0) timeout_ms = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (c.threaded) {
+        std::unique_lock<std::mutex> lk(c.mu);
+        if (!c.cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return c.recorded >= c.issued; }))
+            return pgx::fail(PGX_ERR_RUNTIME, "pgx_comm_quiesce: " + std::to_string(c.issued - c.recorded) +
+                                                  " collective(s) not handed to RCCL after " +
+                                                  std::to_string(timeout_ms) + " ms");
+    }
+    const int spent = (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (!wait_stream_for(c.cstream, timeout_ms > spent ? timeout_ms - spent : 0))
+        return pgx::fail(PGX_ERR_RUNTIME, "pgx_comm_quiesce: collectives still running after " +
+                                              std::to_string(timeout_ms) + " ms (a peer gone, or ranks out of step?)");
+    return PGX_OK;
+}
+
 int pgx_comm_destroy(void) {
     Comm &c = cm();
     if (!c.comm) return PGX_OK;
-    (void)drain(c);
+    static const int timeout_ms = getenv("PGX_COMM_EXIT_TIMEOUT_MS") ? atoi(getenv("PGX_COMM_EXIT_TIMEOUT_MS")) : 10000;
+    const bool failed = !c.worker_error.empty();
+    if (failed || pgx_comm_quiesce(timeout_ms) != PGX_OK) {
+        // outstanding work that will never complete (or an issue thread that reported a failure: the collective
+        // stream may be stuck behind it).  Joining, synchronising or ncclCommDestroy would hang with it: leave
+        // everything where it is and say so.
+        const std::string why = failed ? "issue thread failed: " + c.worker_error : std::string(pgx_last_error());
+        c.stop_worker(true);
+        c.comm = nullptr;
+        c.world = 0;
+        c.abandoned = true;
+        return pgx::fail(PGX_ERR_RUNTIME, "pgx_comm_destroy: communicator abandoned (" + why + ")");
+    }
     c.stop_worker();
-    (void)hipStreamSynchronize(c.cstream);
     (void)c.api.CommDestroy(c.comm);
     c.comm = nullptr;
     (void)hipStreamDestroy(c.cstream);
     for (auto &e : c.ev_in) (void)hipEventDestroy(e);
     for (auto &e : c.done) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c.chk_ev);
+    (void)hipHostFree(c.chk_host);
+    (void)hipFree(c.chk_dev);
     (void)hipFree(c.scratch);
     c.cstream = nullptr;
     c.scratch = nullptr;
+    c.chk_dev = c.chk_host = nullptr;
+    c.chk_ev = nullptr;
     c.world = 0;
+    return PGX_OK;
+}
+
+// 1 after a pgx_comm_destroy that ran into its deadline (pgx_shutdown then leaves the HIP objects alone too).
+int pgx_comm_abandoned(void) { return cm().abandoned ? 1 : 0; }
+
+// A fact this rank's NEXT collectives depend on and every rank must share (window or block, rows, switches): folded
+// into the sequence hash the agreement checks compare.
+int pgx_comm_fold_check(int64_t word) {
+    Comm &c = cm();
+    c.seq_hash = fold(c.seq_hash, word);
+    return PGX_OK;
+}
+
+// tickets issued, agreement checks completed, the current sequence hash (tests, bench.py)
+int pgx_comm_stats(int64_t *issued, int64_t *checks, int64_t *hash) {
+    Comm &c = cm();
+    if (issued) *issued = c.comm ? c.issued : 0;
+    if (checks) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        *checks = c.checks_done;
+    }
+    if (hash) *hash = c.seq_hash;
     return PGX_OK;
 }
 
@@ -284,7 +446,9 @@ int pgx_allreduce_sum(float *out, const float *in, size_t n, int64_t *ticket) {
     PGX_CHECK_ARG(c.comm != nullptr, "pgx_allreduce_sum: pgx_comm_init has not been called");
     PGX_CHECK_ARG(out != nullptr && in != nullptr && ticket != nullptr, "pgx_allreduce_sum: null argument");
     const int64_t t = c.issued + 1;
-    const Job job{in, out, n, t};
+    c.seq_hash = fold(c.seq_hash, (int64_t)n);
+    const bool check = (t <= c.check_first) || (c.check_every > 0 && t % c.check_every == 0);
+    const Job job{in, out, n, t, check, c.seq_hash};
     if (!c.threaded) {
         PGX_HIP(hipEventRecord(c.ev_in[t % kRing], pgx::stream()));      // the local partial mix is complete here
         const std::string err = issue(c, job);

@@ -154,7 +154,13 @@ int pgx_pool_trim(void) {
 int pgx_shutdown(void) {
     Runtime &r = rt();
     if (!r.ready) return PGX_OK;
-    pgx_comm_destroy();
+    if (pgx_comm_destroy() != PGX_OK || pgx_comm_abandoned()) {
+        // collectives that will never complete sit on the device (a peer died, ranks out of step): freeing, synchronising
+        // or destroying anything could wait for them for ever.  The library is marked down and the process is expected
+        // to end (the Python layer exits non-zero).
+        r.ready = false;
+        return PGX_ERR_RUNTIME;                          // (pgx_last_error() still holds pgx_comm_destroy's message)
+    }
     pgx_pool_trim();
     std::lock_guard<std::mutex> lock(r.mu);
     for (auto &kv : r.live) (void)hipFree(kv.first);   // parked blocks are still listed in `live`

@@ -146,6 +146,10 @@ _SIGNATURES = [
     ("pgx_comm_init", _I, [_I, _I, _P, _Z]),
     ("pgx_comm_info", _I, [C.POINTER(_I), C.POINTER(_I)]),
     ("pgx_comm_destroy", _I, []),
+    ("pgx_comm_quiesce", _I, [_I]),
+    ("pgx_comm_abandoned", _I, []),
+    ("pgx_comm_fold_check", _I, [_L]),
+    ("pgx_comm_stats", _I, [C.POINTER(_L), C.POINTER(_L), C.POINTER(_L)]),
     ("pgx_allreduce_sum", _I, [_P, _P, _Z, C.POINTER(_L)]),
     ("pgx_allreduce_wait", _I, [_L]),
     ("pgx_allreduce_scalar_host", _I, [C.POINTER(_D), _I]),
@@ -196,6 +200,10 @@ class PgxError(RuntimeError):
     pass
 
 
+class PgxOutOfMemory(PgxError, MemoryError):
+    """PGX_ERR_NOMEM: the pool could not get the block from HIP (look_ahead falls back to block-by-block on it)."""
+
+
 def check(code: int, what: str = "") -> None:
     """Map a pgx_status to a Python exception (ValueError for bad arguments, as the
     reference raises from render(); RuntimeError otherwise)."""
@@ -205,6 +213,8 @@ def check(code: int, what: str = "") -> None:
     text = f"{what}: {msg}" if what else msg
     if code == -1:
         raise ValueError(text)
+    if code == -4:
+        raise PgxOutOfMemory(f"{text} (pgx status {code})")
     raise PgxError(f"{text} (pgx status {code})")
 
 
@@ -232,7 +242,7 @@ def ensure_init(device: int | None = None):
         _initialised = True
         global _exit_hook
         if not _exit_hook:
-            atexit.register(shutdown)
+            atexit.register(_shutdown_at_exit)
             _exit_hook = True
     return lib
 
@@ -240,22 +250,47 @@ def ensure_init(device: int | None = None):
 _exit_hook = False
 
 
-def shutdown() -> None:
+def shutdown(at_exit: bool = False) -> None:
     """Orderly end of the library: wait for the streams, then pgx_shutdown() -- communicator, streams, events and
     every pooled device / pinned block are released while the HIP runtime (and a profiler's tool library riding on
     it) is still fully alive.  Registered with atexit by the first ensure_init(): without it the process reached
     C++ static teardown with three streams, 64+ events and the pools still open, and under rocprofv3 that ended in
     a SIGSEGV inside __cxa_finalize after the results were written (gpurun_out/r2o_ss.log, round 2).  Buffers that
     Python still holds are harmless afterwards: pgx_free / pgx_host_free return quietly once the library is down.
-    Safe to call twice; ensure_init() brings the library up again."""
+    Safe to call twice; ensure_init() brings the library up again.
+
+    A rank whose peer died mid-collective (or whose ranks fell out of step) holds collectives that never complete:
+    nothing is synchronised before pgx_comm_quiesce has said, within its deadline, that the communicator is idle.
+    If it is not, the communicator is abandoned; at interpreter exit the process then ends at once with status 70
+    (os._exit: the HIP runtime's own teardown would wait for the stuck queues), otherwise RuntimeError."""
     global _initialised
     if not _initialised or _lib is None:
         return
     _initialised = False
-    try:
-        _lib.pgx_stream_sync()
-    finally:
-        _lib.pgx_shutdown()
+    timeout = int(os.environ.get("PGX_COMM_EXIT_TIMEOUT_MS", "10000"))
+    stuck = _lib.pgx_comm_quiesce(timeout) != 0
+    if not stuck:
+        try:
+            _lib.pgx_stream_sync()
+        finally:
+            stuck = _lib.pgx_shutdown() != 0
+    else:
+        _lib.pgx_shutdown()                            # abandons the communicator, touches nothing else
+    if stuck:
+        msg = _lib.pgx_last_error().decode("utf-8", "replace")
+        if at_exit:
+            import sys
+            try:
+                sys.stderr.write(f"pygmu2_amd: {msg}; exiting with status 70\n")
+                sys.stdout.flush()
+                sys.stderr.flush()
+            finally:
+                os._exit(70)
+        raise PgxError(msg)
+
+
+def _shutdown_at_exit() -> None:
+    shutdown(at_exit=True)
 
 
 def device_available() -> bool:

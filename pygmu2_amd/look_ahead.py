@@ -160,6 +160,32 @@ def restore_snapshot(snap) -> None:
             setattr(pe, name, value)
 
 
+def _flush_pending_backups(snap) -> None:
+    for n, _ in snap:
+        flush = getattr(n, "_flush_backup", None)
+        if flush is not None:
+            flush()
+
+
+def _expected_window_failure(exc) -> bool:
+    """What a window `blocks` times longer than the caller's block may legitimately run into: a PE that declines it,
+    the HBM for the intermediates, a kernel's size limit (PGX_ERR_INVALID -> ValueError)."""
+    return isinstance(exc, (_read_ahead.Declined, MemoryError, ValueError))
+
+
+_noted: set = set()
+
+
+def _note_window_failure(pe, exc) -> None:
+    key = (type(pe).__name__, type(exc).__name__, str(exc)[:80])
+    if key not in _noted:                             # once per kind: a stream would repeat it block after block
+        _noted.add(key)
+        import logging
+        logging.getLogger("pygmu2_amd.look_ahead").warning(
+            "%s: look-ahead window declined (%s: %s); this PE renders block by block from here on",
+            type(pe).__name__, type(exc).__name__, exc)
+
+
 # ------------------------------------------------------------------------------------ windows
 class _Window:
     __slots__ = ("first", "end", "buf", "served", "snap", "nodes", "block")     # block: 0, or the only block size served
@@ -212,22 +238,32 @@ def render(pe, start: int, duration: int):
     blocks = max(2, min(grow, AHEAD_BLOCKS, AHEAD_FRAMES // duration))
     try:
         big = pe._render(start, duration * blocks)
-    except Exception:                                 # noqa: BLE001
+    except BaseException as exc:
         # a render `blocks` times longer can fail where the block itself would not (HBM for the intermediates,
-        # a kernel's size limit): every state goes back to the snapshot, this PE stops opening windows and the
-        # request takes the block-by-block path -- the caller sees what it would have seen without look-ahead
+        # a kernel's size limit, a PE that declines the window): every state goes back to the snapshot, this PE stops
+        # opening windows and the request takes the block-by-block path -- the caller sees what it would have seen
+        # without look-ahead.  Anything else (a HIP runtime error, a bug) is not swallowed: the states are put back
+        # and the exception goes to the caller, so that a fault is diagnosed where it first shows.
         _tls.busy = False
         _tls.period = 0
-        for n, _ in snap:                             # a copy its kernel was to write and never did: made now
-            flush = getattr(n, "_flush_backup", None)
-            if flush is not None:
-                flush()
-        restore_snapshot(snap)
         d["_la_ok"] = False
+        try:
+            _flush_pending_backups(snap)
+            restore_snapshot(snap)
+        except Exception:                             # noqa: BLE001 -- the device is gone: the first error is the story
+            if _expected_window_failure(exc):
+                raise
+        if not _expected_window_failure(exc):
+            raise
+        _note_window_failure(pe, exc)
         return None
     finally:
         _tls.busy = False
         _tls.period = 0
+    # a snapshot copy that the window's own kernel was to write (BiquadPE._la_take_snapshot) and that no render asked
+    # for -- CropPE past its end returns fill without pulling its source -- is made now: the state is unchanged when
+    # the PE was never rendered, so the copy is the state before the window
+    _flush_pending_backups(snap)
     d["_la_grow"] = grow * WINDOW_GROWTH
     STATS["window_frames"] += duration * blocks
     STATS["windows"] += 1

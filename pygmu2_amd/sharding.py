@@ -81,8 +81,17 @@ class RcclReducer:
         self.calls = 0                # collectives issued, floats reduced (bench.py reports them)
         self.floats = 0
         self._parked = []             # (ticket, buffers kept alive) of results dropped unread, oldest first
+        self._comm = comm
 
     PARK_MAX = 8                      # results dropped unread before the library stream is made to wait for them
+
+    def fold(self, *words) -> None:
+        """Facts every rank shares about the collectives that follow: part of the sequence hash the library's
+        agreement checks compare across the ranks (a rank out of step fails instead of hanging the communicator)."""
+        self._comm.fold_check(*words)
+
+    def checks(self) -> int:
+        return self._comm.stats()["checks"]
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         import ctypes as C
@@ -144,6 +153,39 @@ class TorchReducer:
         self.on_device = "nccl" in str(dist.get_backend())
         self._lib_stream = None
         self._comm_stream = None
+        self._hash = 0                # sequence hash: every count and every folded fact so far
+        self._tickets = 0
+        self._checks = 0
+
+    CHECK_FIRST, CHECK_EVERY = 8, 16  # as pgx_comm.hip: the first tickets and every 16th after them are checked
+
+    def fold(self, *words) -> None:
+        for w in words:
+            self._hash = hash((self._hash, int(w))) & ((1 << 62) - 1)      # ints and tuples of ints hash alike everywhere
+
+    def checks(self) -> int:
+        return self._checks
+
+    def _agree(self, n: int) -> None:
+        """The same agreement check pgx_comm.hip makes in front of a collective: all ranks reduce {n, -n, h, -h} with
+        max; they agree exactly when max(n) == -max(-n) and max(h) == -max(-h).  A fixed-size collective cannot
+        mismatch, so a rank out of step raises on every rank instead of hanging the group."""
+        self.fold(n)
+        self._tickets += 1
+        if not (self._tickets <= self.CHECK_FIRST or self._tickets % self.CHECK_EVERY == 0):
+            return
+        torch, dist = self.torch, self.dist
+        t = torch.tensor([n, -n, self._hash, -self._hash], dtype=torch.int64)
+        if self.on_device:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        v = [int(x) for x in t.cpu()]
+        self._checks += 1
+        if v[0] != -v[1] or v[2] != -v[3]:
+            raise RuntimeError(
+                f"ranks out of step at collective {self._tickets}: this rank reduces {n} floats, the ranks' counts span "
+                f"{-v[1]} .. {v[0]}" + (" (same count, different history of pulls)" if v[0] == -v[1] else "")
+                + " -- every rank must make the same sequence of pulls")
 
     def _streams(self):
         if self._lib_stream is None:
@@ -155,6 +197,7 @@ class TorchReducer:
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         torch, dist = self.torch, self.dist
+        self._agree(int(snippet.duration) * int(snippet.channels))
         if self.on_device:
             from . import device as _dev
             src = snippet.dev                           # a host payload (zeros of an idle rank) is uploaded
@@ -216,6 +259,7 @@ class ShardedMixPE(ProcessingElement):
         else:
             self._local = _Silence(self._channels or 1)
         self._reducer = reducer
+        self._folded_config = False
         self._windows = None          # decided once, from what every rank knows (see _whole_windows)
         self._reduced = None          # (local window buffer, its reduced Snippet, that Snippet's buffer)
         if world > 1 and isinstance(self._local, MixPE) and self._whole_windows():
@@ -259,14 +303,31 @@ class ShardedMixPE(ProcessingElement):
                 and all(vb._signature(pe) == sig and vb._collect_ids(pe, seen) for pe in self._all_inputs))
         return self._windows
 
+    def _fold(self, *words) -> None:
+        """Tell the reducer what this rank is about to do and why (facts every rank must share): its agreement checks
+        compare a hash of all of it across the ranks, so a rank that decides differently -- another pull sequence,
+        another environment switch -- fails with "ranks out of step" instead of hanging the communicator."""
+        fold = getattr(self._reducer, "fold", None)
+        if fold is None:
+            return
+        if not self._folded_config:
+            from . import voice_bank as vb
+            self._folded_config = True
+            fold(len(self._all_inputs), self._world, int(WINDOW_COLLECTIVES), int(bool(self._whole_windows())),
+                 int(vb.BANK_WINDOWS), int(vb.BANK_WINDOWS_ANY_ROOT), int(vb.BANK_WINDOW_MAX_VOICES))
+        fold(*words)
+
     def _render(self, start, duration):
         part = self._local.render(start, duration)
         if self._world == 1:
             return part
         if self._reducer is None:
             self._reducer = default_reducer()
-        base = part._base
+        # only rows of a voice bank's window count as a window here (read-ahead / look-ahead rows are reduced block by
+        # block: whether those layers opened a window is a rank-local matter)
+        base = part._base if part._bank_window else None
         if base is None or not self._whole_windows():
+            self._fold(1, start, duration)
             return self._reducer.all_reduce(part)
         # A row of the bank's window of 2, 4 or 8 blocks: the window is reduced whole when its first row is handed
         # out -- one collective of up to 1.5 MB instead of eight of 192 KB, each of which costs the links' latency --
@@ -275,11 +336,13 @@ class ShardedMixPE(ProcessingElement):
         # this one is on the links, and the stream waits for it when the window after it replaces it.
         window, first_row = base
         if first_row == 0:
+            self._fold(2, start, int(window.shape[0]))
             whole = self._reducer.all_reduce(Snippet(start, window))
             self._reduced = (window, whole, whole._dev)       # (the previous window's wait is enqueued here, when it is dropped)
         elif self._reduced is None or self._reduced[0] is not window:
             # a window whose first row did not pass through here (somebody pulled the local mix directly -- on every
             # rank, by the contract): its rows are reduced one by one
+            self._fold(3, start, duration)
             return self._reducer.all_reduce(part)
         _, whole, buf = self._reduced
 

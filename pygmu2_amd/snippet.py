@@ -22,13 +22,14 @@ from .device import DeviceBuffer
 
 
 class Snippet:
-    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready", "_copy", "_base")
+    __slots__ = ("_start", "_host", "_dev", "_shape", "_ready", "_copy", "_base", "_bank_window")
 
     def __init__(self, start: int, data, ready=None):
         self._start = int(start)
         self._ready = ready
         self._copy = None
         self._base = None
+        self._bank_window = False     # a row of a voice bank's mixed window (sharding.py reduces such a window whole)
         if isinstance(data, DeviceBuffer):
             if data.dtype != np.float32 or len(data.shape) != 2:
                 raise ValueError("device payload must be float32 of shape (frames, channels)")
@@ -58,6 +59,7 @@ class Snippet:
         self._host = None
         self._dev = None
         self._base = (window, first_row)
+        self._bank_window = False
         self._shape = (rows, window.shape[1])
         return self
 

@@ -986,7 +986,9 @@ class VoiceBank:
             if start == win[4] and duration == win[2] and start + duration <= win[1]:
                 win[4] = start + duration
                 self.last = (start, duration)
-                return Snippet.window_rows(start, win[3].dev, start - win[0], duration)
+                row = Snippet.window_rows(start, win[3].dev, start - win[0], duration)
+                row._bank_window = True
+                return row
             self._settle_window()
         streaming = self.last == (start - duration, duration)
         self.last = (start, duration)
@@ -1010,7 +1012,9 @@ class VoiceBank:
                 _look_ahead.STATS["window_frames"] += duration * blocks
                 _look_ahead.STATS["windows"] += 1
                 self.win = [start, start + duration * blocks, duration, big, start + duration, snaps]
-                return Snippet.window_rows(start, big.dev, 0, duration)
+                row = Snippet.window_rows(start, big.dev, 0, duration)
+                row._bank_window = True
+                return row
         elif not streaming:
             self.grow = BANK_WINDOW_FIRST
         return self._render_mix_now(start, duration)

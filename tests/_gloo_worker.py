@@ -68,7 +68,24 @@ def run(rank, world, port, n_voices, out_dir):
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
     r.start()
+    out_of_step = os.environ.get("PGX_TEST_OUT_OF_STEP", "")
+    if out_of_step:
+        # rank 1 makes a different pull (another block length, or the same length at another place) at its third
+        # collective: every rank must get "ranks out of step" from the agreement check, nobody may hang
+        try:
+            for i in range(5):
+                n, at = 1000, i * 1000
+                if rank == 1 and i == 2:
+                    n, at = (500, at) if out_of_step == "count" else (1000, at + 7)
+                root.render(at, n).data
+        except RuntimeError as exc:
+            assert "ranks out of step" in str(exc), str(exc)
+            with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+                f.write(str(exc))
+            return                                         # (no barrier: the group is not usable for payloads any more)
+        raise SystemExit("the diverging pull went unnoticed")
     blocks = [root.render(i * 1000, 1000).data for i in range(3)]
+    assert root._reducer.checks() == 3, "the first collectives are each preceded by an agreement check"
     r.stop()
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate(blocks))
     dist.barrier()

@@ -230,3 +230,71 @@ def test_block_sensitive_graphs_need_blocks_passed_through():
     win = comp.__dict__["_la_win"]
     assert win.block == 500 and win.first in (4096, 4596)    # ... and the stream goes on in windows of the new one
     r.stop()
+
+
+def test_window_that_never_pulls_the_fused_filter_keeps_its_state():
+    """CropPE(BiquadPE(SinePE)) streamed past the crop's end.  The window rendered past the end returns fill
+    without pulling the filter, whose snapshot copy was to be written by the filter's own next kernel: look_ahead makes
+    that copy after the window's render, so a seek back into the crop filters from the carried state, not from
+    uninitialised pool memory."""
+    def crop():
+        flt = pg.BiquadPE(pg.SinePE(frequency=440.0), frequency=1000.0, q=0.707)
+        root = pg.CropPE(flt, 0, 20 * 1024)
+        return root, {"filter": flt}
+    steps = ([("r", i * 1024, 1024) for i in range(20)]                  # the crop's own frames (windows of 8, 16)
+             + [("r", (20 + i) * 1024, 1024) for i in range(30)]         # past the end: fill, new windows, no pulls
+             + [("inner", "filter", 20 * 1024, 2048)]                    # mid-window: settle, then the filter itself
+             + [("r", 5 * 1024, 1024), ("r", 6 * 1024, 1024)])           # and a seek back into the crop
+    got, root = run(crop, steps, ahead=True)
+    want, _ = run(crop, steps, ahead=False)
+    assert all(np.all(np.isfinite(g)) for g in got)
+    close(got, want)
+
+
+def test_unexpected_errors_inside_a_window_are_not_swallowed():
+    """A window render may fail for reasons of its size (declined, out of memory, a kernel's size limit): those fall
+    back to block by block.  Anything else reaches the caller."""
+    pg.set_sample_rate(SR)
+    flt, _ = c2()
+    r = pg.NullRenderer(SR)
+    r.set_source(flt)
+    r.start()
+    flt.render(0, 1024)
+    real = flt._render
+    calls = {"n": 0}
+
+    def boom(start, duration):
+        calls["n"] += 1
+        if duration > 1024:
+            raise ZeroDivisionError("a bug, not a size limit")
+        return real(start, duration)
+    flt._render = boom
+    with pytest.raises(ZeroDivisionError):
+        flt.render(1024, 1024)
+    assert flt.__dict__.get("_la_ok") is False
+
+    flt2, _ = c2()
+    r2 = pg.NullRenderer(SR)
+    r2.set_source(flt2)
+    r2.start()
+    flt2.render(0, 1024)
+    real2 = flt2._render
+
+    def too_big(start, duration):
+        if duration > 1024:
+            raise MemoryError("no room for the window")
+        return real2(start, duration)
+    flt2._render = too_big
+    got = flt2.render(1024, 1024).data.copy()                # falls back to the block itself
+    flt2._render = real2
+    ref, _ = c2()
+    r3 = pg.NullRenderer(SR)
+    r3.set_source(ref)
+    r3.start()
+    look_ahead.set_enabled(False)
+    try:
+        ref.render(0, 1024)
+        want = ref.render(1024, 1024).data.copy()
+    finally:
+        look_ahead.set_enabled(True)
+    close([got], [want])

@@ -83,6 +83,8 @@ r = pg.NullRenderer(48000); r.set_source(root); r.start()
 a = [root.render(i * 4096, 4096).data for i in range(3)]
 r.stop()
 assert isinstance(root._reducer, RcclReducer)
+st = comm.stats()
+assert st["issued"] == 3 and st["checks"] == 3 and st["hash"] != 0, st     # the first collectives are each checked
 plain = pg.MixPE(*[c5_voice(pg, i) for i in range(6)])
 r = pg.NullRenderer(48000); r.set_source(plain); r.start()
 b = [plain.render(i * 4096, 4096).data for i in range(3)]
@@ -101,6 +103,9 @@ assert keep._ready is not None       # nothing has forced the last reduce yet
 tail = keep.data
 assert keep._ready is None
 r.stop()
+st = comm.stats()
+assert st["issued"] == 203 and st["checks"] == 8 + (203 // 16 - 0), st      # first 8, then every 16th ticket
+assert device.load_library().pgx_comm_quiesce(5000) == 0
 r = pg.NullRenderer(48000); r.set_source(plain); r.start()
 want = np.concatenate([plain.render(i * 512, 512).data for i in range(200)])[-512:]
 r.stop()
@@ -227,6 +232,42 @@ assert not comm.initialised()
 assert "torch" not in sys.modules
 print("RCCL_ABI_OK")
 '''
+
+
+OUT_OF_STEP_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PGX_ROOT"])
+import pygmu2_amd as pg
+from pygmu2_amd import comm, device
+from pygmu2_amd.sharding import ShardedMixPE, c5_voice
+device.ensure_init()
+comm.init(0, 1, comm.unique_id())
+pg.set_sample_rate(48000)
+root = ShardedMixPE([c5_voice(pg, i) for i in range(6)], 0, 1)
+root._world = 2
+r = pg.NullRenderer(48000); r.set_source(root); r.start()
+try:
+    for i in range(6):                       # PGX_COMM_CHECK_FAULT_AT=3: that ticket's check contributes another count
+        root.render(i * 4096, 4096).data
+except RuntimeError as exc:
+    assert "ranks out of step at collective 3" in str(exc), str(exc)
+    print("OUT_OF_STEP_SEEN", flush=True)
+else:
+    raise SystemExit("the planted disagreement went unnoticed")
+# the interpreter now ends: the communicator has failed, so the exit hook abandons it and ends the process with 70
+'''
+
+
+def test_ranks_out_of_step_fail_loudly_and_the_process_exits_non_zero(tmp_path):
+    """pgx_comm.hip's agreement check (a planted disagreement on a 1-rank communicator) and the exit path of a failed
+    communicator: no join / synchronise / ncclCommDestroy that could hang with it, exit status 70."""
+    env = dict(os.environ, PGX_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", PGX_COMM_CHECK_FAULT_AT="3")
+    script = tmp_path / "w.py"
+    script.write_text(OUT_OF_STEP_WORKER)
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert "OUT_OF_STEP_SEEN" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    assert p.returncode == 70 and "communicator abandoned" in p.stderr, (p.returncode, p.stderr[-2000:])
 
 
 def _worker(tmp_path, text, token, **env_extra):
