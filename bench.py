@@ -767,9 +767,9 @@ def cpu_c3(frames=96_000, budget_s=6.0):
 # ----------------------------------------------------------------------------- sharded mixes (C4, C5, SuperSaw)
 def mix_entry(pg, dist, config, steps, warmup, with_cpu):
     from pygmu2_amd.sharding import bench_voice_mix
-    voices = 64 if config == "c4" else 512
+    voices = 64 if config in ("c4", "c4r06") else 512
     dt, frames, name, info = bench_voice_mix(pg, dist, steps, warmup, voices=voices, config=config)
-    per_voice = {"c4": 7, "c5": 1, "supersaw": 7}[config]
+    per_voice = {"c4": 7, "c4r06": 7, "c5": 1, "supersaw": 7}[config]
     out = {"value": round(frames * steps / dt / 1e6, 3), "unit": "Msamples/s",
            "ms_per_block": round(dt / steps * 1e3, 4), "scaling": "strong", "workload": name,
            "steps": steps, "warmup": warmup, "n_ranks": dist.world if dist.enabled else 1,
@@ -778,6 +778,8 @@ def mix_entry(pg, dist, config, steps, warmup, with_cpu):
            "allreduce_wait_ms": info.get("allreduce_wait_ms"),
            "collectives_in_timed_region": info.get("collectives_in_timed_region"),
            "floats_reduced_in_timed_region": info.get("floats_reduced_in_timed_region"),
+           "sharded_vs_unsharded_max_err_over_peak": info.get("sharded_vs_unsharded_max_err_over_peak"),
+           "agreement_checks": info.get("agreement_checks"),
            "oscillator_msamples_s": round(per_voice * voices * frames * steps / dt / 1e6, 1),
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                         "achieved": round(4.0 * frames * steps / dt / 1e9, 4),
@@ -785,7 +787,7 @@ def mix_entry(pg, dist, config, steps, warmup, with_cpu):
                         "algorithmic_bytes_per_block": 4.0 * frames,
                         "note": "SURVEY 8d: 4C B/frame of final mix; every oscillator / filter is an on-chip "
                                 "intermediate, so this path is compute / latency bound by construction"}}
-    if config == "c4":
+    if config in ("c4", "c4r06"):
         # LadderPE: chains x oversampled steps per second (latency-bound, no bandwidth fraction)
         out["chain_steps_per_s"] = round(voices * 2 * frames * steps / dt, 1)
     if with_cpu:
@@ -809,10 +811,10 @@ def cpu_mix(config, voices, frames, budget_s=5.0, max_picks=96):
                               frequency=2000.0, q=0.707),
                      gain=S("AdsrGatedPE", gate=S("PeriodicGate", frequency=2.0 + 0.01 * i, duty_cycle=0.5),
                             attack_time=0.01, decay_time=0.1, sustain_level=0.7, release_time=0.2))
-        if config == "c4":
+        if config in ("c4", "c4r06"):
             return S("LadderPE", source=S("SuperSawPE", frequency=55.0 * 2 ** (i / 12.0), voices=7,
                                           detune_cents=20.0, seed=i),
-                     frequency=1200.0, resonance=0.3, mode="lp24", drive=1.0, oversample=2)
+                     frequency=1200.0, resonance=0.3 if config == "c4" else 0.6, mode="lp24", drive=1.0, oversample=2)
         return S("SuperSawPE", frequency=55.0 * 2 ** (i / 96.0), voices=7, detune_cents=20.0, seed=i)
 
     order = [int((k * 0.6180339887 % 1.0) * voices) for k in range(max_picks)]      # low-discrepancy spread
@@ -833,7 +835,7 @@ def cpu_mix(config, voices, frames, budget_s=5.0, max_picks=96):
            "sample": f"{len(picks)} of the {voices} voices (indices spread over the range), one {frames}-frame block "
                      f"each = {t_all:.2f} s; whole mix = mean x {voices}; oracle numpy/scipy + oracle/seq_kernels.c "
                      f"(gcc -O2) for the ladder and ADSR loops"}
-    if config == "c4":
+    if config in ("c4", "c4r06"):
         out["chain_steps_per_s"] = round(2 * frames / per_voice, 1)
     out.update(host_info())
     return out
@@ -883,6 +885,19 @@ def north_star_pe_rows(pg, with_cpu):
         ("LadderPE (lp24, 1200 Hz, res 0.3, oversample 2)",
          S("LadderPE", source=S("BlitSawPE", frequency=110.0), frequency=1200.0, resonance=0.3, mode="lp24",
            drive=1.0, oversample=2)),
+        # at and above self-oscillation (k = 4 res 1.8 > 4 from res 0.556): the reference's own example setting
+        # (examples/17_ladder_filter.py:43) and a stronger one over a saw, which locks the saturating loop to itself --
+        # time segments with warm-ups found by trial -- and over a lone sine, which does not: the loop runs free, every
+        # trial fails the device check and the chain stays on the sequential kernel (one lane: below the CPU)
+        ("LadderPE (lp24, 800 Hz, res 0.6, drive 1.5)",
+         S("LadderPE", source=S("BlitSawPE", frequency=110.0), frequency=800.0, resonance=0.6, mode="lp24",
+           drive=1.5, oversample=2)),
+        ("LadderPE (lp24, 800 Hz, res 0.9, drive 1.5)",
+         S("LadderPE", source=S("BlitSawPE", frequency=110.0), frequency=800.0, resonance=0.9, mode="lp24",
+           drive=1.5, oversample=2)),
+        ("LadderPE (res 0.9 over a lone sine: free-running, sequential)",
+         S("LadderPE", source=sine(220.0, 0.5), frequency=800.0, resonance=0.9, mode="lp24", drive=1.5,
+           oversample=2)),
         ("LadderPE (modulated cutoff)",
          S("LadderPE", source=S("BlitSawPE", frequency=110.0), frequency=S("MixPE", inputs=[
              S("ConstantPE", value=1200.0), sine(0.5, 600.0)]), resonance=0.3, mode="lp24", drive=1.0, oversample=2)),
@@ -915,6 +930,87 @@ def north_star_pe_rows(pg, with_cpu):
             "rows": rows, "comb_bank_512": bank}
 
 
+# ----------------------------------------------------------------------------- flat record
+FLAT_MIX_KEYS = ("value", "ms_per_block", "oscillator_msamples_s", "over_cpu", "render_ms", "render_ms_max_over_ranks",
+                 "allreduce_wait_ms", "collectives_in_timed_region", "sharded_vs_unsharded_max_err_over_peak",
+                 "agreement_checks", "voices_on_this_rank", "chain_steps_per_s")
+
+
+def flat_keys(result) -> dict:
+    """Scalar `config` entries (Msamples/s unless the name says otherwise): the sharded mixes with their collective and
+    N-rank parity figures, the other BASELINE configs, the north_star PE rows, the PCIe-inclusive C2 rate and the
+    float64-issue roofline fractions.  `None` where a figure does not exist in this run (N = 1 has no collectives)."""
+    flat = {}
+    cases = result.get("cases", {})
+
+    def mix(prefix, entry):
+        if not isinstance(entry, dict) or "value" not in entry:
+            return
+        for key in FLAT_MIX_KEYS:
+            if entry.get(key) is not None:
+                flat[f"{prefix}_{'msamples_s' if key == 'value' else key}"] = entry[key]
+        if isinstance(entry.get("cpu_baseline"), dict):
+            flat[f"{prefix}_cpu_msamples_s"] = entry["cpu_baseline"].get("value")
+        for name in ("roofline", "roofline_fp64"):
+            if isinstance(entry.get(name), dict) and entry[name].get("frac") is not None:
+                flat[f"{prefix}_{name}_frac"] = entry[name]["frac"]
+
+    if result.get("mix"):                                   # --workload c4 | c5 | supersaw: the primary line itself
+        mix("primary", dict(result["mix"], value=result.get("value")))
+    mix("supersaw", result.get("supersaw_mix"))
+    mix("c5", result.get("voice_mix"))
+    mix("c4", result.get("ladder_mix") or cases.get("c4_supersaw_ladder_mix_64"))
+    mix("c4_res06", cases.get("c4_res06_supersaw_ladder_mix_64"))
+    d2h = result.get("value_with_d2h")
+    if isinstance(d2h, dict):
+        for mode in ("pipelined", "sync"):
+            if mode in d2h:
+                flat[f"c2_with_d2h_{mode}"] = d2h[mode].get("value")
+                if "over_cpu" in d2h[mode]:
+                    flat[f"c2_with_d2h_{mode}_over_cpu"] = d2h[mode]["over_cpu"]
+    for key, short in (("c1_sine_gain_1024_blocks", "c1"), ("c1_hello_sine_example_1024_blocks", "c1_hello_sine"),
+                       ("c3_convolve_64k_taps", "c3_96000"), ("c3_convolve_64k_taps_1440000_whole", "c3_1440000"),
+                       ("c3_convolve_64k_taps_1440000_blocks_65537", "c3_blocks_65537"),
+                       ("autowah_biquad_1024_blocks", "autowah_biquad"), ("autowah_svf_1024_blocks", "autowah_svf")):
+        case = cases.get(key)
+        if isinstance(case, dict):
+            flat[f"{short}_msamples_s"] = case.get("value")
+            if case.get("cpu_oracle_msamples_s") is not None:
+                flat[f"{short}_cpu_msamples_s"] = case["cpu_oracle_msamples_s"]
+            roof = case.get("roofline")
+            if isinstance(roof, dict):
+                flat[f"{short}_roofline_frac"] = roof.get("frac")
+                if roof.get("avg_launch_ms") is not None:
+                    flat[f"{short}_call_us"] = round(roof["avg_launch_ms"] * 1e3, 2)
+                if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
+                    flat[f"{short}_traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 2)
+    rows = (result.get("north_star_pes") or {}).get("rows", {})
+    short_names = {"LadderPE (lp24, 1200 Hz, res 0.3, oversample 2)": "ladder_res03",
+                   "LadderPE (lp24, 800 Hz, res 0.6, drive 1.5)": "ladder_res06",
+                   "LadderPE (lp24, 800 Hz, res 0.9, drive 1.5)": "ladder_res09",
+                   "LadderPE (res 0.9 over a lone sine: free-running, sequential)": "ladder_res09_free_running",
+                   "LadderPE (modulated cutoff)": "ladder_modulated_cutoff",
+                   "CombPE (440 Hz, fb 0.7)": "comb_440", "CombPE (modulated frequency)": "comb_modulated_frequency",
+                   "AdsrGatedPE (PeriodicGate 2 Hz)": "adsr_2hz", "AdsrGatedPE (PeriodicGate 7 Hz)": "adsr_7hz"}
+    for name, row in rows.items():
+        tag = short_names.get(name)
+        if tag:
+            for k in ("sync", "pipelined", "cpu", "pipelined_over_cpu"):
+                if row.get(k) is not None:
+                    flat[f"{tag}_{k}"] = row[k]
+    suite = (result.get("suite") or {}).get("rows", {})
+    for name, tag in (("BiquadPE (lowpass, fixed)", "suite_biquad"), ("SinePE (440 Hz)", "suite_sine"),
+                      ("BlitSawPE (440 Hz, auto M)", "suite_blitsaw"), ("SuperSawPE (7 voices)", "suite_supersaw7")):
+        row = suite.get(name)
+        if row:
+            for k in ("sync", "pipelined", "cpu"):
+                if row.get(k) is not None:
+                    flat[f"{tag}_{k}"] = row[k]
+    if isinstance(result.get("roofline_fp64"), dict):
+        flat["c2_roofline_fp64_frac"] = result["roofline_fp64"].get("frac")
+    return flat
+
+
 # ----------------------------------------------------------------------------- dry run (launch glue on CPU)
 def dry_run(args, dist):
     import pygmu2_amd as pg
@@ -933,7 +1029,11 @@ def dry_run(args, dist):
                           "value": None, "unit": "Msamples/s", "n_gpus": dist.world, "n_ranks_seen": seen,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                           "config": {"workload": args.workload, "voices_on_rank0": owned,
-                                     "voices_on_all_ranks": total_owned}}), flush=True)
+                                     "voices_on_all_ranks": total_owned,
+                                     # the scalar keys a measured line of this world size carries for each sharded mix
+                                     "flat_mix_keys": ",".join(f"{p}_{'msamples_s' if k == 'value' else k}"
+                                                               for p in ("supersaw", "c5", "c4") for k in FLAT_MIX_KEYS)}}),
+              flush=True)
     dist.shutdown()
 
 
@@ -1020,6 +1120,10 @@ def main():
         # 8-block collective, the timed region is six whole windows: 48 blocks rendered for the 48 counted)
         result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 48, 15, with_cpu and dist.rank == 0)
         result["voice_mix"].pop("_dt"), result["supersaw_mix"].pop("_dt")
+        if dist.enabled:
+            # BASELINE config 4 sharded as well (at N = 1 it is `cases.c4_supersaw_ladder_mix_64`)
+            result["ladder_mix"] = mix_entry(pg, dist, "c4", 24, 15, False)
+            result["ladder_mix"].pop("_dt")
 
     if dist.rank == 0 and not args.no_extras and not sharded:
         solo = _Solo()
@@ -1062,6 +1166,9 @@ def main():
             # window's last block; the timed region is three whole windows of 8 -- 24 blocks rendered for the 24 counted)
             cases["c4_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4", 24, 15, with_cpu)
             cases["c4_supersaw_ladder_mix_64"].pop("_dt")
+            # the same bank with the ladders above self-oscillation (resonance 0.6): warm-ups by trial
+            cases["c4_res06_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4r06", 24, 15, with_cpu)
+            cases["c4_res06_supersaw_ladder_mix_64"].pop("_dt")
             cases["autowah_biquad_1024_blocks"] = {"value": autowah_case(pg, "biquad"), "unit": "Msamples/s"}
             cases["autowah_svf_1024_blocks"] = {"value": autowah_case(pg, "svf"), "unit": "Msamples/s"}
             result["north_star_pes"] = north_star_pe_rows(pg, with_cpu)
@@ -1126,6 +1233,11 @@ def main():
             pass
         if hl:
             result["config"]["highlights"] = hl
+
+    if dist.rank == 0:
+        # The driver's record keeps `config` only as far as its values are scalars (nested objects are dropped, the
+        # rest of the line survives as a tail): everything north_star words a target on is repeated there, flat.
+        result["config"].update(flat_keys(result))
 
     if dist.rank == 0:
         print(json.dumps(result), flush=True)

@@ -93,6 +93,7 @@ int pgx_host_malloc(void **hptr, size_t bytes);
 int pgx_host_free(void *hptr);
 int pgx_d2h_begin(void *dst_host, const void *src, size_t bytes, int64_t *ticket);
 int pgx_d2h_wait(int64_t ticket);
+int pgx_d2h_query(int64_t ticket, int *done);   /* *done = 1 once that copy has landed; never blocks */
 int pgx_d2h_fence(int64_t ticket);
 
 int pgx_event_create(void **event);
@@ -441,8 +442,10 @@ int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, in
  * _ladder_process_numba (ladder_pe.py:31-203), the reference's float64 operation order.
  * state[instance][channel] = {z0[4], z1[4], old_input}.
  * settle_frames = 0: one lane per (instance, channel) chain, strictly sequential.
- * settle_frames = W > 0 (host estimate of how many samples the filter needs to forget its state;
- * only meaningful below self-oscillation): the block is cut into segments that each start W samples
+ * settle_frames = W > 0 (host estimate of how many samples the filter needs to forget its state: from the
+ * small-signal loop below self-oscillation, a TRIAL value at and above it -- a driven, saturating ladder usually
+ * locks to its input although the linearised loop does not decay; the caller reads the counters below and moves to
+ * a longer warm-up or to W = 0 when chains fall back): the block is cut into segments that each start W samples
  * early from a zero state; the library verifies every segment against its left neighbour's final
  * state (1e-8 relative) and re-renders a chain sequentially when the check fails, so W affects
  * speed, never results beyond that bound.  accurate_frames = A (0 < A < W): only the last A warm-up samples
@@ -450,7 +453,8 @@ int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, in
  * use the float32 exponential unit (state error ~1e-7, contracted by the accurate tail; 0 or >= W: all of the
  * warm-up is accurate).  Warm-ups run on fused multiply-adds; emitted samples keep the reference's operation
  * order.  workspace: pgx_ladder_workspace_bytes(...) bytes
- * (NULL when 0); the int32 at byte offset (size - 16) counts chains that fell back (zero it to count). */
+ * (NULL when 0).  Its first 16 bytes are counters, cumulative since the caller zeroed them: int32[0] chains that
+ * fell back to the sequential re-render, int32[1] segmented launches (the position does not depend on n). */
 typedef struct {
     double freq;
     double resonance;

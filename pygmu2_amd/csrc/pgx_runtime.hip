@@ -488,6 +488,17 @@ int pgx_d2h_wait(int64_t ticket) {
     return PGX_OK;
 }
 
+// *done = 1 when the copy of `ticket` has landed, 0 while it is on its way: never blocks.
+int pgx_d2h_query(int64_t ticket, int *done) {
+    PGX_REQUIRE_INIT();
+    Runtime &r = rt();
+    PGX_CHECK_ARG(done != nullptr && ticket >= 1 && ticket <= r.copies_issued, "pgx_d2h_query: unknown ticket");
+    const hipError_t e = hipEventQuery(copy_event(r, ticket));
+    if (e != hipSuccess && e != hipErrorNotReady) PGX_HIP(e);
+    *done = e == hipSuccess ? 1 : 0;
+    return PGX_OK;
+}
+
 int pgx_d2h_fence(int64_t ticket) {
     PGX_REQUIRE_INIT();
     Runtime &r = rt();

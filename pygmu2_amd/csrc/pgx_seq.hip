@@ -484,6 +484,7 @@ k_ladder_finish(float *out, int64_t out_stride, const float *in, int64_t in_stri
                 const float *drive, double *state, int64_t settle, int64_t seg_len, int nseg,
                 const double *warm, const double *ends, int *fallbacks) {
     const int chain = blockIdx.x, lane = threadIdx.x;
+    if (lane == 0 && chain == 0 && fallbacks) atomicAdd(fallbacks + 1, 1);
     bool bad = false;
     for (int seg = 1 + lane; seg < nseg; seg += 64) {
         const double *a = warm + ((int64_t)chain * nseg + seg) * 9;
@@ -567,7 +568,7 @@ size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t se
     if (batch <= 0 || n <= 0 || channels <= 0) return 0;
     const LadderPlan p = ladder_plan(batch, n, channels, settle_frames);
     if (!p.segmented) return 0;
-    return ((size_t)batch * channels * p.nseg * 18 + 2) * sizeof(double);
+    return ((size_t)batch * channels * p.nseg * 18 + 2) * sizeof(double);      // 16 bytes of counters first
 }
 
 int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_stride, int batch, int64_t n,
@@ -590,9 +591,12 @@ int pgx_ladder(float *out, int64_t out_stride, const float *in, int64_t in_strid
         return PGX_OK;
     }
     PGX_CHECK_ARG(workspace != nullptr, "pgx_ladder: workspace required for the segmented path");
-    double *warm = (double *)workspace;
+    // The workspace begins with the counters (wherever its owner keeps it, whatever the block length: a caller that
+    // tries warm-up lengths reads them back, ladder_pe.SettleOptimist): [0] chains re-rendered sequentially because a
+    // segment's warm-up had not converged (cumulative since the workspace was zeroed), [1] segmented launches.
+    int *fallbacks = (int *)workspace;
+    double *warm = (double *)workspace + 2;
     double *ends = warm + (size_t)chains * p.nseg * 9;
-    int *fallbacks = (int *)(ends + (size_t)chains * p.nseg * 9);
     const int64_t lanes = (int64_t)chains * p.nseg;
     // (64-thread workgroups, two per CU, and 256-thread ones -- a wave on every SIMD of half the CUs -- measure the
     // same; 64-thread ones with 64 Ki lanes are a third slower: they are not spread over the SIMDs)

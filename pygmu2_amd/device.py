@@ -63,6 +63,7 @@ _SIGNATURES = [
     ("pgx_host_free", _I, [_P]),
     ("pgx_d2h_begin", _I, [_P, _P, _Z, C.POINTER(_L)]),
     ("pgx_d2h_wait", _I, [_L]),
+    ("pgx_d2h_query", _I, [_L, C.POINTER(_I)]),
     ("pgx_d2h_fence", _I, [_L]),
     ("pgx_event_create", _I, [C.POINTER(_P)]),
     ("pgx_event_destroy", _I, [_P]),
@@ -434,6 +435,13 @@ class PinnedBlock:
         except Exception:
             pass
         self.ptr = 0
+
+
+def host_copy_done(ticket: int) -> bool:
+    """Has the asynchronous copy of `ticket` (DeviceBuffer.begin_to_host) landed?  Never blocks."""
+    done = C.c_int(0)
+    check(_lib.pgx_d2h_query(ticket, C.byref(done)), "pgx_d2h_query")
+    return bool(done.value)
 
 
 def wait_to_host(ticket: int) -> None:

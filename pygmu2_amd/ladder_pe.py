@@ -22,6 +22,14 @@ from .snippet import Snippet
 
 
 ACCURATE_TAIL_FACTOR = 4e-4
+# At and above self-oscillation (k = 4 res 1.8 passes the small-signal loop gain of 4 at res 0.556; the reference's own
+# example is there: examples/17_ladder_filter.py:43, res 0.6) and for loops that decay too slowly, ladder_settle_frames has
+# no answer.  The device verifies every time segment against its neighbour and re-renders a chain sequentially when one
+# disagrees, so a warm-up length only has to be TRIED (SettleOptimist): these, in turn.
+OPTIMISTIC_SETTLES = (2048, 8192, 32768)
+OPTIMISTIC_RETRY = 64                 # renders on the sequential kernel after every length failed, then the longest again
+OPTIMISTIC = True
+STATS = {"segmented": 0, "sequential": 0, "fallback_chains": 0, "escalations": 0, "gave_up": 0}
 SEGMENT_STREAM_LADDER = True          # PE-driven cutoff / resonance: time segments too (warm-up from the block's range)
 STREAM_SEGMENT_MIN_FRAMES = 8192      # shorter blocks stay on the sequential kernel (the range costs a read-back)
 
@@ -86,6 +94,79 @@ def ladder_settle_frames(cutoff: float, resonance: float, sample_rate: float, ov
     return frames if frames <= limit else 0
 
 
+class SettleOptimist:
+    """Warm-up lengths by trial, for ladders whose small-signal loop does not decay (or decays too slowly for
+    ladder_settle_frames).  A driven, saturating ladder usually locks to its input: two trajectories under the same
+    input then converge although the linearised loop oscillates (measured on the CPU oracle, experiments/README.md: a
+    110 Hz saw, a SuperSaw, noise or a chord into an 800 Hz ladder at resonance 0.6 ... 1.0 forget a zero start to 1e-8
+    within 2 000 ... 8 000 samples; a lone sine does not at resonance >= 0.7 -- the loop runs free beside it).  The
+    device check (k_ladder_finish: every segment's entry state against its neighbour's exit state, 1e-8) decides; this
+    class only reads its verdict back -- the cumulative fallback counter at the head of the workspace, copied
+    asynchronously -- and moves to the next length, or to the sequential kernel for `OPTIMISTIC_RETRY` renders
+    (doubling, at most 1024) when the longest failed too.  A failed trial costs the sequential re-render of the chain
+    (what the render would have cost without the trial), so the host must not run ahead of the verdicts: a length
+    that has not passed yet is waited for before the next render is planned (one device wait per new length), a
+    length that has passed may have `RUN_AHEAD` verdicts outstanding."""
+
+    RUN_AHEAD = 2
+
+    def __init__(self):
+        self.level = 0
+        self.sleep = 0
+        self.retry = OPTIMISTIC_RETRY
+        self.seen = 0                  # the counter's value so far
+        self.pending = []              # (ticket, pinned view, level, workspace kept alive)
+        self.good = 0                  # verified renders in a row at this level
+
+    def settle(self, frames: int) -> tuple[int, int]:
+        """(settle_frames, accurate_frames) for the next render of `frames` frames; (0, 0): sequential."""
+        self.poll()
+        while len(self.pending) > (self.RUN_AHEAD if self.good > 0 else 0):
+            self.poll(wait=True, only_first=True)
+        if not OPTIMISTIC:
+            return 0, 0
+        if self.sleep > 0:
+            self.sleep -= 1
+            return 0, 0
+        w = OPTIMISTIC_SETTLES[self.level]
+        return w, w // 2               # (the float32-tanh half leaves ~1e-7, the accurate half contracts it)
+
+    def launched(self, workspace, level_settle: int) -> None:
+        """A segmented render with this warm-up has been enqueued: its verdict is read back without waiting."""
+        STATS["segmented"] += 1
+        view, ticket = workspace.rows(0, 8).begin_to_host()
+        self.pending.append((ticket, view, level_settle, workspace))
+
+    def poll(self, wait: bool = False, only_first: bool = False) -> None:
+        first = True
+        while self.pending and (first or not only_first):
+            first = False
+            ticket, view, settle, _ws = self.pending[0]
+            if wait:
+                _dev.wait_to_host(ticket)
+            elif not _dev.host_copy_done(ticket):
+                return
+            self.pending.pop(0)
+            count = int(view.view(np.int32)[0])
+            if count > self.seen:
+                STATS["fallback_chains"] += count - self.seen
+                self.seen = count
+                self.good = 0
+                if self.sleep == 0 and settle == OPTIMISTIC_SETTLES[self.level]:     # (not escalated since)
+                    if self.level + 1 < len(OPTIMISTIC_SETTLES):
+                        self.level += 1
+                        STATS["escalations"] += 1
+                    else:
+                        self.sleep = self.retry
+                        self.retry = min(self.retry * 2, 1024)
+                        STATS["gave_up"] += 1
+            else:
+                self.good += 1
+
+    def reset(self) -> None:
+        self.poll()
+
+
 class LadderPE(ProcessingElement):
     _LOOK_AHEAD_SAFE = True            # look_ahead.py
     _STATE_FIELDS = ("_state", "_state_channels")
@@ -116,6 +197,7 @@ class LadderPE(ProcessingElement):
         self._range_dev: DeviceBuffer | None = None          # (256, 2) float64: min / max pairs of a control stream
         self._stream_settle_cache: dict = {}
         self._stream_accurate = 0
+        self._optimist: SettleOptimist | None = None        # warm-up lengths by trial (no analytic estimate)
 
     source = property(lambda self: self._source)
     frequency = property(lambda self: self._frequency)
@@ -176,16 +258,30 @@ class LadderPE(ProcessingElement):
         _, d_buf = self._control_stream(self._drive, start, duration)
         out = new_output(duration, ch)
         settle = self._settle_frames()
-        if (self._freq_is_pe or self._res_is_pe) and SEGMENT_STREAM_LADDER:
+        streams = self._freq_is_pe or self._res_is_pe
+        if streams and SEGMENT_STREAM_LADDER:
             settle = self._settle_frames_for_streams(f_buf, r_buf, duration)
+        accurate = self._stream_accurate if streams else self._accurate_frames()
+        trial = False
+        if settle == 0 and duration >= STREAM_SEGMENT_MIN_FRAMES and (not streams or SEGMENT_STREAM_LADDER):
+            if self._optimist is None:
+                self._optimist = SettleOptimist()
+            settle, accurate = self._optimist.settle(duration)
+            trial = settle > 0
         L = lib()
         need = L.pgx_ladder_workspace_bytes(1, duration, ch, settle)
         if need and (self._workspace is None or self._workspace.nbytes < need):
+            counters = None if self._workspace is None else self._workspace.rows(0, 16)
             self._workspace = DeviceBuffer((need,), np.uint8, zero=True)
-        accurate = self._stream_accurate if (self._freq_is_pe or self._res_is_pe) else self._accurate_frames()
+            if counters is not None:                 # the counters are cumulative: they move with the workspace
+                check(L.pgx_memcpy_d2d(self._workspace.ptr, counters.ptr, 16), "pgx_memcpy_d2d")
         check(L.pgx_ladder(out.ptr, 0, src.dev.ptr, 0, 1, duration, ch, float(self.sample_rate),
                            self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr, settle,
                            accurate, ptr(self._workspace) if need else None), "pgx_ladder")
+        if trial and need:
+            self._optimist.launched(self._workspace, settle)
+        elif not need:
+            STATS["sequential"] += 1
         return Snippet(start, out)
 
     def _settle_frames(self) -> int:

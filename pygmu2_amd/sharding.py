@@ -369,10 +369,16 @@ def c5_voice(pg, i: int):
         gain=pg.AdsrGatedPE(pg.PeriodicGate(2.0 + 0.01 * i, 0.5), 0.01, 0.1, 0.7, 0.2))
 
 
-def c4_voice(pg, i: int):
+def c4_voice(pg, i: int, resonance: float = 0.3):
     """BASELINE config 4 instance i: 7-voice SuperSaw -> 24 dB ladder low-pass."""
     return pg.LadderPE(pg.SuperSawPE(55.0 * 2 ** (i / 12.0), voices=7, detune_cents=20.0, seed=i),
-                       frequency=1200.0, resonance=0.3, mode=pg.LadderMode.LP24, drive=1.0, oversample=2)
+                       frequency=1200.0, resonance=resonance, mode=pg.LadderMode.LP24, drive=1.0, oversample=2)
+
+
+def c4_res06_voice(pg, i: int):
+    """C4 with the ladders above self-oscillation (resonance 0.6, as examples/17_ladder_filter.py:43): the warm-up of
+    the time segments is found by trial (ladder_pe.SettleOptimist), the device check decides."""
+    return c4_voice(pg, i, resonance=0.6)
 
 
 def supersaw_voice(pg, i: int):
@@ -382,7 +388,8 @@ def supersaw_voice(pg, i: int):
 
 def mix_voice_factory(config: str):
     """(voice constructor, voice count) of the three sharded bench workloads."""
-    return {"c5": (c5_voice, 512), "c4": (c4_voice, 64), "supersaw": (supersaw_voice, 512)}[config]
+    return {"c5": (c5_voice, 512), "c4": (c4_voice, 64), "supersaw": (supersaw_voice, 512),
+            "c4r06": (c4_res06_voice, 64)}[config]
 
 
 def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c5"):
@@ -398,6 +405,29 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     world = dist.world if dist.enabled else 1
     rank = dist.rank if dist.enabled else 0
     make = mix_voice_factory(config)[0]
+    parity = None
+    if world > 1:
+        # N-rank parity, the only kind a record of an N-GPU run can carry (the GPU test tier has one GPU): two blocks of
+        # the sharded mix -- every rank takes part in the collectives -- against the unsharded MixPE of all voices
+        # rendered by rank 0 alone.  Outside the timed region, on instances of their own.
+        chk = ShardedMixPE([make(pg, i) for i in range(voices)], rank, world)
+        rc = pg.NullRenderer(sample_rate=48000)
+        rc.set_source(chk)
+        rc.start()
+        got = [chk.render(i * block, block).data.copy() for i in range(2)]
+        rc.stop()
+        if rank == 0:
+            full = pg.MixPE(*[make(pg, i) for i in range(voices)])
+            rf = pg.NullRenderer(sample_rate=48000)
+            rf.set_source(full)
+            rf.start()
+            want = [full.render(i * block, block).data.copy() for i in range(2)]
+            rf.stop()
+            peak = max(float(np.max(np.abs(w))) for w in want)
+            parity = max(float(np.max(np.abs(g.astype(np.float64) - w))) for g, w in zip(got, want)) / max(peak, 1e-30)
+            del full, want
+        del chk, got
+        dist.barrier()
     root = ShardedMixPE([make(pg, i) for i in range(voices)], rank, world)
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
@@ -423,6 +453,9 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
     if world > 1:                      # (a bank window of 2, 4, 8 blocks is one collective)
         info["collectives_in_timed_region"] = calls1[0] - calls0[0]
         info["floats_reduced_in_timed_region"] = calls1[1] - calls0[1]
+        info["sharded_vs_unsharded_max_err_over_peak"] = parity
+        checks = getattr(root._reducer, "checks", None)
+        info["agreement_checks"] = checks() if checks else None
     probe = max(3, min(20, steps))
     pos = (warmup + steps) * block
     root.local.render(pos, block)
@@ -444,6 +477,6 @@ def bench_voice_mix(pg, dist, steps, warmup, voices=512, block=48_000, config="c
         name = (f"{voices}-voice SuperSaw mix ({voices} x SuperSawPE 7 oscillators)->MixPE, 48 kHz mono, "
                 f"{block}-frame blocks, voices sharded i mod {world}")
     else:
-        name = (f"C4: {voices} x LadderPE(SuperSawPE 7 voices)->MixPE, 48 kHz mono, {block}-frame blocks, "
-                f"instances sharded i mod {world}")
+        name = (f"C4: {voices} x LadderPE(SuperSawPE 7 voices{', resonance 0.6' if config == 'c4r06' else ''})->MixPE, "
+                f"48 kHz mono, {block}-frame blocks, instances sharded i mod {world}")
     return dt, block, name, info

@@ -497,6 +497,10 @@ class _LadderNode(_Node):
         settles = [pe._settle_frames() for pe in pes]
         self.settle = 0 if min(settles) == 0 else max(settles)     # one warm-up length for the batch
         self.accurate = max(pe._accurate_frames() for pe in pes) if self.settle else 0
+        # a voice without an estimate (at or above self-oscillation, a very slow decay): warm-up lengths by trial, the
+        # device check decides (ladder_pe.SettleOptimist) -- an oscillator bank locks a saturating ladder to itself
+        from .ladder_pe import SettleOptimist
+        self.optimist = SettleOptimist() if self.settle == 0 else None
         self.ahead = None          # (start, n, input buffer, (state copy, last_end)) rendered ahead of the caller
         self.is_root = False       # directly under the bank's mix: may hand out rows of a window (VoiceBank.__init__)
         self.win = None            # [first, end, n, buffer, served, (ladder state, oscillator state, last_end)]
@@ -595,14 +599,22 @@ class _LadderNode(_Node):
         if self.state is None:
             self.state = DeviceBuffer((self.k, ch, 9), np.float64, zero=True)
         out = DeviceBuffer((self.k, n, ch), np.float32)
-        need = L.pgx_ladder_workspace_bytes(self.k, n, ch, self.settle)
+        settle, accurate = self.settle, self.accurate
+        if self.optimist is not None and n >= 8192:
+            settle, accurate = self.optimist.settle(n)
+        need = L.pgx_ladder_workspace_bytes(self.k, n, ch, settle)
         if need and (self.ws is None or self.ws.nbytes < need):
+            counters = None if self.ws is None else self.ws.rows(0, 16)
             self.ws = DeviceBuffer((need,), np.uint8, zero=True)
+            if counters is not None:                     # cumulative counters at the head of the workspace
+                check(L.pgx_memcpy_d2d(self.ws.ptr, counters.ptr, 16), "pgx_memcpy_d2d")
 
         def ladder():
             check(L.pgx_ladder(out.ptr, n * ch, x.ptr, n * ch, self.k, n, ch, self.sr, self.params.ptr,
-                               None, None, None, self.state.ptr, self.settle, self.accurate,
+                               None, None, None, self.state.ptr, settle, accurate,
                                ptr(self.ws) if need else None), "pgx_ladder")
+            if self.optimist is not None and need and settle:
+                self.optimist.launched(self.ws, settle)
 
         speculate = (PREFETCH_LADDER_INPUT and isinstance(src, (_SuperSawNode, _BlitSawNode)) and n >= 4096
                      and not L.pgx_stream_is_forked())

@@ -78,3 +78,41 @@ def test_two_ranks_without_a_communicator_fail_unless_told_otherwise():
         assert "error" in d["voice_mix"] and "error" in d["supersaw_mix"]
     else:
         assert d["n_ranks_seen"] == 2 and d["voice_mix"]["n_ranks"] == 2 and d["voice_mix"]["value"] > 0
+
+
+def test_dry_run_names_the_flat_keys_of_a_measured_line():
+    """the driver's record keeps only scalar `config` entries.  The dry run lists the keys a measured
+    line carries per sharded mix; flat_keys() makes them from a line's nested objects."""
+    p = _run(["--gpus", "2", "--workload", "supersaw", "--dry-run"])
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    keys = d["config"]["flat_mix_keys"].split(",")
+    for want in ("supersaw_msamples_s", "supersaw_ms_per_block", "c5_allreduce_wait_ms", "c5_collectives_in_timed_region",
+                 "c4_render_ms_max_over_ranks", "c4_sharded_vs_unsharded_max_err_over_peak", "c5_msamples_s",
+                 "supersaw_agreement_checks"):
+        assert want in keys, want
+
+
+def test_flat_keys_are_scalars_and_cover_the_north_star_numbers():
+    sys.path.insert(0, ROOT)
+    import bench
+    mix = {"value": 100.0, "ms_per_block": 0.5, "render_ms": 0.4, "render_ms_max_over_ranks": 0.45,
+           "allreduce_wait_ms": 0.05, "collectives_in_timed_region": 6, "sharded_vs_unsharded_max_err_over_peak": 3e-8,
+           "agreement_checks": 9, "voices_on_this_rank": 64, "oscillator_msamples_s": 7.0,
+           "cpu_baseline": {"value": 0.006}, "roofline": {"frac": 1e-4}, "roofline_fp64": {"frac": 0.5}}
+    result = {"value": 1.0, "supersaw_mix": dict(mix), "voice_mix": dict(mix), "ladder_mix": dict(mix),
+              "value_with_d2h": {"pipelined": {"value": 10000.0, "over_cpu": 150.0}, "sync": {"value": 8000.0}},
+              "cases": {"c3_convolve_64k_taps": {"value": 5000.0, "cpu_oracle_msamples_s": 22.0,
+                                                 "roofline": {"frac": 0.01, "avg_launch_ms": 0.0156, "traffic": 29e6,
+                                                              "algorithmic_bytes_per_launch": 1.536e6}},
+                        "c4_res06_supersaw_ladder_mix_64": dict(mix)},
+              "north_star_pes": {"rows": {"LadderPE (lp24, 800 Hz, res 0.6, drive 1.5)":
+                                          {"sync": 400.0, "pipelined": 460.0, "cpu": 8.0, "pipelined_over_cpu": 57.0}}},
+              "roofline_fp64": {"frac": 0.6}}
+    flat = bench.flat_keys(result)
+    assert all(isinstance(v, (int, float)) or v is None for v in flat.values()), flat
+    for key in ("supersaw_msamples_s", "supersaw_ms_per_block", "c5_allreduce_wait_ms", "c4_collectives_in_timed_region",
+                "c4_sharded_vs_unsharded_max_err_over_peak", "c2_with_d2h_pipelined", "c3_96000_call_us",
+                "c3_96000_traffic_over_algorithmic", "ladder_res06_pipelined", "ladder_res06_cpu", "c4_res06_msamples_s",
+                "c2_roofline_fp64_frac", "supersaw_roofline_fp64_frac", "c5_cpu_msamples_s"):
+        assert key in flat, key
