@@ -158,6 +158,8 @@ class BiquadPE(ProcessingElement):
         self._sine_chain_memo = None                  # _sine_chain(), evaluated once
         self._sine_supported: dict = {}               # duration -> pgx_biquad_sine_supported
         self._backup_target = None                    # a snapshot buffer the next fused render has to fill
+        self._backup_ring = []                        # three small buffers used in turn as snapshot targets
+        self._backup_turn = 0
         self._settle = 0                              # settle_frames of the constant section
         self._tables: DeviceBuffer | None = None      # its power tables (single-launch path)
         self._params: DeviceBuffer | None = None      # pgx_biquad_var_params (varying path)
@@ -263,8 +265,19 @@ class BiquadPE(ProcessingElement):
         that comes first fills the copy the ordinary way (_flush_backup)."""
         if self._state is None or self._sine_chain() is None or not FUSE_SINE_SOURCE:
             return None
-        self._backup_target = DeviceBuffer(self._state.shape, self._state.dtype)
-        return {"_state": self._backup_target, "_state_channels": self._state_channels}
+        # Three buffers in turn instead of an allocation per window (1.4 us of every opening): a snapshot is used at
+        # most once -- restored, it BECOMES the state -- and only the newest window's can still be restored; with the
+        # live state that makes two buffers busy, the third is free.
+        ring = self._backup_ring
+        if len(ring) < 3 or ring[0].shape != self._state.shape:
+            ring[:] = [DeviceBuffer(self._state.shape, self._state.dtype) for _ in range(3)]
+        for _ in range(3):
+            self._backup_turn = (self._backup_turn + 1) % 3
+            target = ring[self._backup_turn]
+            if target is not self._state:
+                break
+        self._backup_target = target
+        return {"_state": target, "_state_channels": self._state_channels}
 
     def _flush_backup(self) -> None:
         backup, self._backup_target = self._backup_target, None

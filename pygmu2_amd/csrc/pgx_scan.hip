@@ -3620,24 +3620,31 @@ int pgx_biquad_sine(float *out, int64_t start, int64_t n, double sample_rate, do
     // the largest phase of the render has to stay in the bounded sine's range
     const double far = fabs(phase0) + fabs(w) * ((double)(llabs(start) + n) / sample_rate);
     PGX_CHECK_ARG(far < pgx::kSinFastRange, "pgx_biquad_sine: phase beyond the fast sine range");
-    SbSine sine;
-    sine.w = w;
-    sine.amp = amp;
-    sine.phase0 = phase0;
-    sine.sr = sample_rate;
-    sine.inv_sr = 1.0 / sample_rate;
-    const long double d = (long double)w / (long double)sample_rate;
-    sine.cos_d = (double)cosl(d);
-    sine.sin_d = (double)sinl(d);
-    sine.two_cos_d = (fabsl(sinl(d)) >= 1e-3L) ? (double)(2.0L * cosl(d)) : 0.0;
-    {
+    // the tone's constants (five long-double sines and cosines) are made once per (w, sample rate): a stream of windows
+    // asks for the same tone every time, and they were 1 us of every window opening's host time
+    static SbSine cached;
+    static bool have = false;
+    if (!have || cached.w != w || cached.sr != sample_rate) {
+        SbSine c;
+        c.w = w;
+        c.sr = sample_rate;
+        c.inv_sr = 1.0 / sample_rate;
+        const long double d = (long double)w / (long double)sample_rate;
+        c.cos_d = (double)cosl(d);
+        c.sin_d = (double)sinl(d);
+        c.two_cos_d = (fabsl(sinl(d)) >= 1e-3L) ? (double)(2.0L * cosl(d)) : 0.0;
         // a tile's advance, block * 16 frames: the angle reduced in long double before the sine and cosine are taken
         const long double turn = 6.283185307179586476925286766559L;
         long double a = d * (long double)(sine_block() * kBqT);
         a -= turn * floorl(a / turn);
-        sine.tile_cos = (double)cosl(a);
-        sine.tile_sin = (double)sinl(a);
+        c.tile_cos = (double)cosl(a);
+        c.tile_sin = (double)sinl(a);
+        cached = c;
+        have = true;
     }
+    SbSine sine = cached;
+    sine.amp = amp;
+    sine.phase0 = phase0;
     sine.start = start;
     sine.state_backup = state_backup;
     const dim3 grid(sp.groups == 1 ? 1 : (sp.groups + 7) / 8 * 8, 1);

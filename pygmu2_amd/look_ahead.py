@@ -140,16 +140,24 @@ def _copy_value(value):
     return value                      # numbers, None, tuples, enums: immutable
 
 
-def take_snapshot(nodes):
-    snap = []
+def _snapshot_plan(nodes):
+    """[(pe, state field names, pe._la_take_snapshot or None)] of the stateful PEs among `nodes` (graphs are static:
+    made once per window root)."""
+    plan = []
     for pe in nodes:
         fields = getattr(pe, "_STATE_FIELDS", None)
         if fields:
-            own = getattr(pe, "_la_take_snapshot", None)      # a PE whose next kernel can write the copy itself
-            saved = own() if own is not None else None
-            if saved is None:
-                saved = {name: _copy_value(getattr(pe, name)) for name in fields}
-            snap.append((pe, saved))
+            plan.append((pe, fields, getattr(pe, "_la_take_snapshot", None)))     # a PE whose next kernel can write the copy itself
+    return plan
+
+
+def take_snapshot(nodes, plan=None):
+    snap = []
+    for pe, fields, own in (plan if plan is not None else _snapshot_plan(nodes)):
+        saved = own() if own is not None else None
+        if saved is None:
+            saved = {name: _copy_value(getattr(pe, name)) for name in fields}
+        snap.append((pe, saved))
     return snap
 
 
@@ -162,9 +170,8 @@ def restore_snapshot(snap) -> None:
 
 def _flush_pending_backups(snap) -> None:
     for n, _ in snap:
-        flush = getattr(n, "_flush_backup", None)
-        if flush is not None:
-            flush()
+        if getattr(n, "_backup_target", None) is not None:     # (only a PE with the hook has the attribute)
+            n._flush_backup()
 
 
 def _expected_window_failure(exc) -> bool:
@@ -225,10 +232,12 @@ def render(pe, start: int, duration: int):
         nodes = []
         _subtree(pe, set(), nodes)
         d["_la_nodes"] = nodes
-    for n in nodes:                                   # a window below (opened while this PE was pulled one
-        if n is not pe and n.__dict__.get("_la_win") is not None:      # level down) is closed first
+        d["_la_plan"] = _snapshot_plan(nodes)
+        d["_la_below"] = [n for n in nodes if n is not pe]
+    for n in d["_la_below"]:                          # a window below (opened while this PE was pulled one
+        if "_la_win" in n.__dict__:                   # level down) is closed first
             settle(n)
-    snap = take_snapshot(nodes)
+    snap = take_snapshot(nodes, d["_la_plan"])
     block = duration if d.get("_la_sensitive") else 0
     _tls.busy = True
     _tls.period = block
@@ -278,9 +287,8 @@ def render(pe, start: int, duration: int):
     win.first, win.end, win.buf = start, start + big.duration, big.dev
     win.served, win.snap, win.nodes, win.block = start + duration, snap, nodes, block
     d["_la_win"] = win
-    for n in nodes:
-        if n is not pe:
-            n.__dict__["_la_owner"] = pe
+    for n in d["_la_below"]:
+        n.__dict__["_la_owner"] = pe
     return Snippet.window_rows(start, win.buf, 0, duration)
 
 
