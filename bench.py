@@ -48,6 +48,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+F64_PEAK_TSLOTS = 256 * 4 * 16 * 2.4e9 / 1e12   # float64 lane-slots/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T
+                                                # (78.6 TFLOP/s with an FMA counted as two: SURVEY Appendix B)
 SHARDED = ("c4", "c5", "supersaw")
 
 
@@ -408,6 +410,78 @@ def pmc_traffic(entry: str, frames: int):
             return json.load(f).get(entry, {}).get(str(frames))
     except (OSError, ValueError):
         return None
+
+
+_ISA = None
+
+
+def isa_counts():
+    """profiles/r4_isa_counts.json: float64 issue slots per unit of the compute-bound kernels' steady-state loop
+    bodies, counted in the gfx950 ISA by tools/isa_count.py (committed; a CPU test regenerates and compares it)."""
+    global _ISA
+    if _ISA is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r4_isa_counts.json")) as f:
+                _ISA = json.load(f)
+        except (OSError, ValueError):
+            _ISA = {"kernels": {}}
+    return _ISA
+
+
+def fp64_roofline(kernel: str, units_per_launch: float, avg_launch_ms: float):
+    """the FP64-VALU fraction of a kernel that is compute-bound by construction.  achieved = units per launch
+    x float64 issue slots per unit (ISA count of the steady-state body: full-rate float64 instructions and conversions
+    1 slot, v_rcp_f64 4) / the kernel's HIP-event time; peak = 39.3 T lane-slots/s."""
+    k = isa_counts()["kernels"].get(kernel)
+    if not k or "slots_per_unit" not in k or not avg_launch_ms:
+        return None
+    per_s = units_per_launch / (avg_launch_ms * 1e-3)
+    achieved = per_s * k["slots_per_unit"] / 1e12
+    all_valu = per_s * k["slots_per_unit_all_valu"] / 1e12
+    return {"bound": "fp64_valu", "unit": "T lane-slots/s", "peak": round(F64_PEAK_TSLOTS, 2),
+            "achieved": round(achieved, 3), "frac": round(achieved / F64_PEAK_TSLOTS, 4),
+            "frac_with_32bit_valu": round(all_valu / F64_PEAK_TSLOTS, 4),
+            "kernel": kernel, "unit_counted": k["unit"], "slots_per_unit": k["slots_per_unit"],
+            "slots_per_unit_with_32bit_valu": k["slots_per_unit_all_valu"],
+            "units_per_launch": units_per_launch, "avg_launch_ms": round(avg_launch_ms, 6),
+            "giga_units_per_s": round(per_s / 1e9, 2), "peak_tflops_fma_as_two": round(2 * F64_PEAK_TSLOTS, 1),
+            "counts_from": "profiles/r4_isa_counts.json (tools/isa_count.py: gfx950 ISA, steady-state loop body; "
+                           "32-bit VALU instructions count half a slot in frac_with_32bit_valu)"}
+
+
+def bank_kernel_fp64(pg, config: str, launches: int = 20):
+    """The dominant kernel of a bank mix alone, HIP events around back-to-back launches through the bank's own node
+    (states carried from block to block as in the mix): k_supersaw_wide<4> over 512 x 7 oscillators, or
+    k_blitsaw_biquad_wide<4> over C5's 512 oscillator -> filter chains; 48 000-frame blocks."""
+    from pygmu2_amd import voice_bank as vb
+    from pygmu2_amd.sharding import mix_voice_factory
+    pg.set_sample_rate(48000)
+    make, voices = mix_voice_factory(config)
+    mix = pg.MixPE(*[make(pg, i) for i in range(voices)])
+    bank = mix._voice_bank()
+    if not bank:
+        return None
+    n, pos = 48_000, [0]
+    if config == "supersaw":
+        node = bank.root
+        if not (isinstance(node, vb._SuperSawNode) and node.wide()):
+            return None
+        kernel, units = "k_supersaw_wide<4>", voices * node.nv * n
+
+        def launch():
+            node._bank(pos[0], n)
+            pos[0] += n
+    else:
+        node = next((x for x in bank._nodes() if isinstance(x, vb._BiquadNode)), None)
+        if node is None or not node.children["source"].wide():
+            return None
+        kernel, units = "k_blitsaw_biquad_wide<4>", voices * n
+
+        def launch():
+            node.render(pos[0], n)
+            pos[0] += n
+    ms = event_avg_ms(launch, launches)
+    return fp64_roofline(kernel, units, ms)
 
 
 def event_avg_ms(launch, launches, warm=3):
@@ -1141,6 +1215,14 @@ def main():
         # tone): the filter alone is the HBM-streaming kernel, 8 B/frame
         result["roofline_filter_alone"] = biquad_kernel_roofline(pg, 1_000_000 * ahead, 50)
         result["roofline_sine_alone"] = sine_kernel_roofline(pg, 1_000_000 * ahead, 30, far)
+        # SURVEY 8d / VERDICT r3: the kernels that are compute-bound by construction, priced against the float64 issue
+        # peak with instruction counts from the ISA (the HBM fractions above say little about them)
+        result["roofline_fp64"] = fp64_roofline("k_biquad_settled<mono, staged, sine, 256>",
+                                                result["roofline"]["frames_per_launch"],
+                                                result["roofline"]["avg_launch_ms"])
+        for key, config in (("supersaw_mix", "supersaw"), ("voice_mix", "c5")):
+            if isinstance(result.get(key), dict) and "value" in result[key]:
+                result[key]["roofline_fp64"] = bank_kernel_fp64(pg, config)
         cases = {}
         if args.workload == "c2" and n_gpus == 1:
             result["value_with_d2h"] = bench_c2_with_d2h(pg, 40, 5)

@@ -29,6 +29,19 @@ int device_index();
             return pgx::fail(PGX_ERR_NOT_INIT, "pgx_init() has not been called"); \
     } while (0)
 
+// Branch weights for the instruction counts of tools/isa_count.py.  That tool compiles the kernels with
+// -DPGX_COUNT_STEADY and counts the float64 instructions of their loop bodies for the FP64-VALU roofline: under that
+// switch a branch marked PGX_COLD (a workgroup's first tile, the guarded re-run after a singularity, the one thread that
+// captures the carried state, unaligned edges) is compiled out and one marked PGX_HOT is taken unconditionally, so the
+// bodies hold the steady-state path only.  The library itself is never built with the switch: there both are `(cond)`.
+#ifdef PGX_COUNT_STEADY
+#define PGX_COLD(cond) (false)
+#define PGX_HOT(cond) (true)
+#else
+#define PGX_COLD(cond) (cond)
+#define PGX_HOT(cond) (cond)
+#endif
+
 #define PGX_CHECK_ARG(cond, msg)                                     \
     do {                                                             \
         if (!(cond)) return pgx::fail(PGX_ERR_INVALID, (msg));       \

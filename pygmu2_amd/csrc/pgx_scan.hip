@@ -734,7 +734,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             // turned by a tile's advance for every further one (4 operations instead of the division and the sincos, ~35;
             // a workgroup's run is a dozen tiles: ~1e-15).
             double sn, cs;
-            if (hh == anchor_tile + kTileHalves) {
+            if (PGX_HOT(hh == anchor_tile + kTileHalves)) {
                 sn = __builtin_fma(anchor_s, sine.tile_cos, anchor_c * sine.tile_sin);
                 cs = __builtin_fma(anchor_c, sine.tile_cos, -(anchor_s * sine.tile_sin));
             } else {
@@ -744,7 +744,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             anchor_tile = hh;
             anchor_s = sn;
             anchor_c = cs;
-            if (sine.two_cos_d != 0.0) {
+            if (PGX_HOT(sine.two_cos_d != 0.0)) {
                 // three-term recurrence sin(p + (j+1)d) = 2 cos(d) sin(p + jd) - sin(p + (j-1)d): ONE fused multiply-add
                 // per frame instead of the four operations of the rotation (the cosine is not needed).  Its error
                 // after k steps is <= k ulp / d: 15 steps, d >= 1e-3 (the host's condition) -> below 2e-12
@@ -769,7 +769,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
             }
             return;
         }
-        xn_staged = io_aligned && w0 + 64 * kBqT <= emit_to;
+        xn_staged = STAGED && PGX_HOT(io_aligned && w0 + 64 * kBqT <= emit_to);
         if (xn_staged) {
             stage_fetch(ib + w0, lane, xn);
         } else if (f0 < emit_to) {
@@ -870,7 +870,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
 #endif
             carry = run;
 
-            if (f0 >= emit_from && f0 < emit_to) {
+            if (PGX_HOT(f0 >= emit_from && f0 < emit_to)) {
                 const V2 ex = dpp_v2<0x138, 0xf>(e);           // previous lane's inclusive value, 0 for lane 0
                 const V2 zin = mv_add_fma(mlane, cw, ex);
                 V2 z = zin;
@@ -896,11 +896,11 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
                 }
                 }
                 const int64_t w0 = f0 - lane * kBqT;
-                if (STAGED && io_aligned && w0 >= emit_from && w0 + 64 * kBqT <= emit_to)
+                if (STAGED && PGX_HOT(io_aligned && w0 >= emit_from && w0 + 64 * kBqT <= emit_to))
                     stage_store(wlds, ob + w0, lane, yf);
                 else
                     store_frames<kBqT>(ob, f0, n, channels, ch, yf);
-                if (n - 1 - f0 < kBqT) {                         // the chunk holding the last frame: new state
+                if (PGX_COLD(n - 1 - f0 < kBqT)) {               // the chunk holding the last frame: new state
                     z = zin;
                     for (int j = 0; j <= (int)(n - 1 - f0); ++j) {
                         double x = (double)xf[j];
@@ -2161,7 +2161,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 // anchors for): evaluated every tile.
                 double sd, cd, sn, cn;
                 SswAnchor *anc = anchors ? anchors + (v0 + u) * (NW * 64) + tid : nullptr;
-                if (anc == nullptr || base == frame_first) {
+                if (PGX_COLD(anc == nullptr || base == frame_first)) {
                     const double ph = pgx::pgx_mod1(sh.phase0[v0 + u] + (double)(f0 + 1) * inc);
                     const double theta = kPi * ph;
                     pgx::pgx_sincos_bounded(theta, sd, cd);
@@ -2175,7 +2175,8 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                     cn = __builtin_fma(a.cn, tcm, -(a.sn * tsm));
                 }
                 if (anc != nullptr) *anc = SswAnchor{sd, cd, sn, cn};
-                if (saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]))
+                const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]);
+                if (PGX_COLD(met != 0ull))
                     saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]);
                 double f = 0.0;
 #pragma unroll
@@ -2210,7 +2211,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                     // <= 6e-8 of a voice's level each, inside this kernel's tolerance; three operations fewer per frame)
                     acc[j] = __builtin_fma(y, amp2[u], acc[j]);
                 }
-                if (owner) {                                   // (one thread of the block's last tile)
+                if (PGX_COLD(owner)) {                         // (one thread of the block's last tile)
                     const int jn = (int)(n - 1 - f0);
                     double yl = y_in;
 #pragma unroll
@@ -2292,7 +2293,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         // the voice's gain (GainPE(x, gain=<PE>): float32 x float32) for these frames, asked for first
         float gv[GAIN ? T : 1];
         if (GAIN) {
-            if (f0 + T <= n && aligned16(gb + f0)) {
+            if (PGX_HOT(f0 + T <= n && aligned16(gb + f0))) {
 #pragma unroll
                 for (int j = 0; j < T; j += 4) {
                     const float4 q = *reinterpret_cast<const float4 *>(gb + f0 + j);
@@ -2307,7 +2308,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         // The anchor -- sin / cos of theta and M theta at the thread's first frame -- is evaluated for the first tile and
         // turned by a tile's advance (table: angles reduced exactly) for every further one: 8 operations instead of two
         // sincos (~60); a block's 12 tiles add ~1e-15.
-        if (base == 0) {
+        if (PGX_COLD(base == 0)) {
             const double ph = pgx::pgx_mod1(phase0 + (double)(f0 + 1) * inc);
             const double theta = kPi * ph;
             pgx::pgx_sincos_bounded(theta, a_sd, a_cd);
@@ -2322,7 +2323,8 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         }
         const double sd = a_sd, cd = a_cd, sn = a_sn, cn = a_cn;
         double xb[T];
-        if (saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb))
+        const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+        if (PGX_COLD(met != 0ull))
             saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
         double e = 0.0;
 #pragma unroll
@@ -2369,7 +2371,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
             for (int j = 0; j < T; ++j) yf[j] = yf[j] * gv[GAIN ? j : 0];   // gain_pe.py:104-119: the float32 product
         }
         store_frames<T>(ob, f0, n, 1, 0, yf);
-        if (f0 <= n - 1 && n - 1 < f0 + T) {                      // the thread that renders the block's last frame:
+        if (PGX_COLD(f0 <= n - 1 && n - 1 < f0 + T)) {            // the thread that renders the block's last frame:
             const int jn = (int)(n - 1 - f0);                     // the states after it, by the literal recurrences
             double yl = y_in;
             V2 z = zin;

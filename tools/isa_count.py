@@ -7,12 +7,15 @@ HBM-write fraction and FP64-VALU fraction"; bench.py `roofline_fp64`).
     python tools/isa_count.py                 # the kernels of KERNELS -> JSON on stdout (profiles/r4_isa_counts.json)
     python tools/isa_count.py --loops pgx_scan.hip k_supersaw_wideILi4    # every loop of one kernel, to choose from
 
-How.  `hipcc -S --cuda-device-only` with build.py's flags gives the device assembly of a translation unit.  Inside a
-kernel a loop is a branch to an earlier label; loops nest by containment.  For every loop the instructions between its
-head label and its back edge are counted by class:
-    f64        v_fma / v_mul / v_add / v_min / v_max / v_cmp*_f64: full rate, one issue slot per lane
-    f64_slow   v_rcp / v_rsq / v_sqrt / v_rndne / v_floor / v_ceil / v_trunc / v_fract / v_frexp* / v_ldexp /
-               v_div_* / v_trig_preop / v_cvt to or from f64: quarter rate (tools/microbench/f64_rate.hip), four slots
+How.  `hipcc -S --cuda-device-only -DPGX_COUNT_STEADY` with build.py's flags gives the device assembly of a translation
+unit with the kernels' rare branches compiled out (pgx_common.h: PGX_COLD / PGX_HOT -- a workgroup's first tile, the
+guarded re-run after a singularity, the thread that captures the carried state).  LLVM annotates every basic block of
+that assembly with the loop it belongs to ("in Loop: Header=BB31_35 Depth=2"); the instructions of a loop's blocks --
+wherever the block placement put them -- are counted by class, inner loops added to the loops around them:
+    f64        every v_*_f64 instruction and every conversion to or from float64 but the three below: full rate, one issue
+               slot per lane (measured, tools/microbench/f64_rate.hip + experiments/README.md: v_fma / v_mul / v_add /
+               v_rndne / v_floor and the float32 <-> float64 conversions all take 4.8 - 5.4 cycles per wave instruction)
+    f64_slow   v_rcp_f64 / v_rsq_f64 / v_sqrt_f64: quarter rate (v_rcp_f64 measured at 17 cycles), four slots
     valu32     every other v_* instruction (moves, selects, integer, DPP, float32): half a float64 slot each on the
                SIMD-32 (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles, a float64 one over 4)
     salu / lds / vmem / other
@@ -26,18 +29,18 @@ import json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pygmu2_amd", "csrc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result", "-w"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result", "-w",
+         "-DPGX_COUNT_STEADY=1"]
 F64_PEAK_SLOTS = 256 * 4 * 16 * 2.4e9
 
-SLOW = re.compile(r"^v_(rcp|rsq|sqrt|rndne|floor|ceil|trunc|fract|frexp_mant|frexp_exp_i32|ldexp|div_scale|div_fmas|"
-                  r"div_fixup|trig_preop)_f64|^v_cvt_.*f64")
-FULL = re.compile(r"^v_(fma|mul|add|min|max|max_num|min_num|fmac)_f64|^v_cmp[a-z_]*_f64|^v_cmpx[a-z_]*_f64")
+SLOW = re.compile(r"^v_(rcp|rsq|sqrt)_f64")
+FULL = re.compile(r"^v_\w+_f64(_e32|_e64|_dpp|_sdwa)?$|^v_cvt_\w*f64|^v_cmpx?_\w+_f64")
 
 
 def classify(op: str) -> str:
     if SLOW.match(op):
         return "f64_slow"
-    if FULL.match(op) or (op.startswith("v_") and op.endswith("_f64")):
+    if FULL.match(op) or (op.startswith("v_") and "_f64" in op):
         return "f64"
     if op.startswith("v_mfma") or op.startswith("v_smfma"):
         return "mfma"
@@ -63,62 +66,76 @@ def assembly(source: str) -> str:
 
 
 def functions(asm: str):
-    """{mangled name: [(kind, text)]} with kind 'label' or 'inst'."""
-    out, cur = {}, None
-    for line in asm.splitlines():
-        s = line.strip()
-        if not s or s.startswith((";", "//")):
+    """{mangled name: [block]} with block = {"label", "loop" (innermost loop's header label or None), "header" (bool),
+    "depth", "parents" [(label, depth)], "insts" [text]}."""
+    out, cur, block = {}, None, None
+    lines = asm.splitlines()
+    i = 0
+    while i < len(lines):
+        raw = lines[i]
+        s = raw.strip()
+        i += 1
+        if not s:
             continue
         m = re.match(r"^(_Z[\w$.]*):", s)
-        if m and not s.startswith(".L"):
+        if m:
             cur = out.setdefault(m.group(1), [])
+            block = {"label": "entry", "loop": None, "header": False, "depth": 0, "parents": [], "insts": []}
+            cur.append(block)
             continue
         if cur is None:
             continue
         if s.startswith(".Lfunc_end"):
             cur = None
             continue
-        m = re.match(r"^(\.LBB[\w]+):", s)
+        m = re.match(r"^(?:(\.LBB\w+):|; %bb\.(\d+):)\s*(;.*)?$", s)
         if m:
-            cur.append(("label", m.group(1)))
+            label = m.group(1) or f"bb.{m.group(2)}"
+            notes = [m.group(3) or ""]
+            while i < len(lines) and re.match(r"^\s+;", lines[i]):       # the annotation's continuation lines
+                notes.append(lines[i].strip())
+                i += 1
+            text = " ".join(notes)
+            block = {"label": label, "loop": None, "header": False, "depth": 0, "parents": [], "insts": []}
+            h = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", text)
+            if h:
+                block.update(loop=label.replace(".L", ""), header=True, depth=int(h.group(1)))
+                block["parents"] = [(a, int(b)) for a, b in re.findall(r"Parent Loop (BB\w+) Depth=(\d+)", text)]
+            else:
+                h = re.search(r"in Loop: Header=(BB\w+) Depth=(\d+)", text)
+                if h:
+                    block.update(loop=h.group(1), depth=int(h.group(2)))
+            cur.append(block)
             continue
-        if s.startswith("."):
+        if s.startswith((".", ";", "//")):
             continue
-        cur.append(("inst", s.split(";")[0].strip()))
+        block["insts"].append(s.split(";")[0].strip())
     return out
 
 
-def loops(body):
-    """Loops of one function: [{head, start, end, counts, depth, own}] sorted by start; indices are positions in `body`."""
-    pos = {text: i for i, (kind, text) in enumerate(body) if kind == "label"}
+def loops(blocks):
+    """{header: {"depth", "parent", "own" counts, "counts" (with inner loops)}} of one function."""
     found = {}
-    for i, (kind, text) in enumerate(body):
-        if kind != "inst":
+    for b in blocks:
+        if b["loop"] is None:
             continue
-        m = re.match(r"^s_c?branch\w*\s+(\.LBB\w+)", text)
-        if m and m.group(1) in pos and pos[m.group(1)] < i:
-            head = m.group(1)
-            found[head] = max(found.get(head, -1), i)                  # the outermost back edge to this head
-    result = []
-    for head, end in found.items():
-        start = pos[head]
-        counts = {}
-        for kind, text in body[start:end + 1]:
-            if kind == "inst":
-                c = classify(text.split()[0])
-                counts[c] = counts.get(c, 0) + 1
-        result.append({"head": head, "start": start, "end": end, "counts": counts})
-    result.sort(key=lambda l: (l["start"], -l["end"]))
-    for l in result:
-        inside = [m for m in result if m is not l and m["start"] >= l["start"] and m["end"] <= l["end"]]
-        l["depth"] = sum(1 for m in result if m is not l and m["start"] <= l["start"] and m["end"] >= l["end"])
-        own = dict(l["counts"])
-        for m in inside:
-            if not any(k is not m and k is not l and k["start"] <= m["start"] and k["end"] >= m["end"] for k in inside):
-                for c, v in m["counts"].items():                         # direct children only
-                    own[c] = own.get(c, 0) - v
-        l["own"] = own
-    return result
+        l = found.setdefault(b["loop"], {"head": b["loop"], "depth": b["depth"], "parent": None, "own": {}, "counts": {}})
+        if b["header"]:
+            l["depth"] = b["depth"]
+            near = [p for p, d in b["parents"] if d == b["depth"] - 1]
+            l["parent"] = near[-1] if near else None
+        for text in b["insts"]:
+            c = classify(text.split()[0])
+            l["own"][c] = l["own"].get(c, 0) + 1
+    for l in found.values():
+        l["counts"] = dict(l["own"])
+    for l in sorted(found.values(), key=lambda l: -l["depth"]):            # innermost first: add to every ancestor
+        p = l["parent"]
+        while p is not None and p in found:
+            for c, v in l["own"].items():
+                found[p]["counts"][c] = found[p]["counts"].get(c, 0) + v
+            p = found[p]["parent"]
+    return found
 
 
 def slots(counts) -> float:
@@ -127,26 +144,25 @@ def slots(counts) -> float:
 
 # kernel -> (source, substring of the mangled name, how the steady-state body is chosen, units one lane makes per trip)
 # "largest": the loop with the most float64 slots among those of the given nesting depth (0 = outermost).
+# depth: LLVM's loop depth (1 = outermost) of the steady-state body; among the loops of that depth the one with the most
+# float64 slots is taken.
 KERNELS = {
     "k_biquad_settled<mono, staged, sine, 256>": dict(
-        source="pgx_scan.hip", match="k_biquad_settledILb1ELb1ELb1ELi256", depth=0, units=16, unit="frame",
+        source="pgx_scan.hip", match="k_biquad_settledILb1ELb1ELb1ELi256", depth=2, units=16, unit="frame",
         why="the loop over a workgroup's tiles; a lane makes the 16 frames of its slot per tile (sine rotation, "
             "zero-state pass, DPP scan, carry-in pass)"),
     "k_biquad_settled<mono, staged, 512>": dict(
-        source="pgx_scan.hip", match="k_biquad_settledILb1ELb1ELb0ELi512", depth=0, units=16, unit="frame",
+        source="pgx_scan.hip", match="k_biquad_settledILb1ELb1ELb0ELi512", depth=2, units=16, unit="frame",
         why="the loop over a workgroup's tiles; 16 frames per lane and tile"),
     "k_supersaw_wide<4>": dict(
-        source="pgx_scan.hip", match="k_supersaw_wideILi4", depth=1, units=16, unit="oscillator-frame",
+        source="pgx_scan.hip", match="k_supersaw_wideILi4", depth=2, units=16, unit="oscillator-frame",
         why="tiles (outer) x voices (inner): one trip of the voice loop is one voice's 16 frames of a lane"),
     "k_blitsaw_biquad_wide<4, env>": dict(
-        source="pgx_scan.hip", match="k_blitsaw_biquad_wideILi4ELb1", depth=0, units=16, unit="voice-frame",
+        source="pgx_scan.hip", match="k_blitsaw_biquad_wideILi4ELb1", depth=1, units=16, unit="voice-frame",
         why="one voice per workgroup: the loop over its tiles, 16 frames per lane and tile (oscillator + filter)"),
     "k_blitsaw_biquad_wide<4>": dict(
-        source="pgx_scan.hip", match="k_blitsaw_biquad_wideILi4ELb0", depth=0, units=16, unit="voice-frame",
+        source="pgx_scan.hip", match="k_blitsaw_biquad_wideILi4ELb0", depth=1, units=16, unit="voice-frame",
         why="one voice per workgroup: the loop over its tiles, 16 frames per lane and tile (oscillator + filter)"),
-    "k_sine": dict(
-        source="pgx_elementwise.hip", match="k_sine", depth=None, units=4, unit="frame",
-        why="grid-stride body: four frames per lane and trip (no loop: the whole kernel is the body)"),
 }
 
 
@@ -157,18 +173,18 @@ def kernel_report(name, spec, cache):
     names = [n for n in funcs if spec["match"] in n]
     if not names:
         return {"error": f"no function matches {spec['match']}"}
-    body = funcs[names[0]]
+    blocks = funcs[names[0]]
     total = {}
-    for kind, text in body:
-        if kind == "inst":
+    for b in blocks:
+        for text in b["insts"]:
             c = classify(text.split()[0])
             total[c] = total.get(c, 0) + 1
-    ls = loops(body)
-    if spec["depth"] is None or not ls:
-        chosen = {"head": None, "counts": total, "depth": None}
-    else:
-        cands = [l for l in ls if l["depth"] == spec["depth"]] or ls
+    ls = loops(blocks)
+    cands = [l for l in ls.values() if l["depth"] == spec["depth"]] if spec["depth"] else []
+    if cands:
         chosen = max(cands, key=lambda l: slots(l["counts"]))
+    else:
+        chosen = {"head": None, "counts": total, "depth": None}
     c = chosen["counts"]
     units = spec["units"]
     return {"function": names[0], "loop_head": chosen["head"], "loop_depth": chosen["depth"], "unit": spec["unit"],
@@ -185,9 +201,9 @@ def main():
         for n in funcs:
             if sys.argv[3] in n:
                 print(n)
-                for l in loops(funcs[n]):
-                    print("  " * l["depth"], f"{l['head']} [{l['start']}..{l['end']}] slots {slots(l['counts']):.0f}",
-                          json.dumps(l["counts"]), "own", json.dumps(l["own"]))
+                for l in loops(funcs[n]).values():
+                    print("  " * l["depth"], f"{l['head']} depth {l['depth']} parent {l['parent']} slots "
+                          f"{slots(l['counts']):.0f}", json.dumps(l["counts"]), "own", json.dumps(l["own"]))
         return
     cache = {}
     out = {"peak_f64_lane_slots_per_s": F64_PEAK_SLOTS,
