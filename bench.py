@@ -799,13 +799,15 @@ def conv_kernel_roofline(pg, frames, launches):
             "frames_per_launch": frames, "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(ms, 6)}
 
 
-def conv_fft_roofline(pg, frames, launches):
-    """HIP-event timing of pgx_convolve_fft (the path ConvolvePE takes for the 65 536-tap C3 filter)."""
+def conv_fft_roofline(pg, frames, launches, nfft=None):
+    """HIP-event timing of pgx_convolve_fft (the path ConvolvePE takes for the 65 536-tap C3 filter); nfft: the
+    transform size (default: the one ConvolvePE picks for a render of `frames` frames)."""
     from pygmu2_amd import device
+    from pygmu2_amd.convolve_pe import device_fft_size
     lib = device.ensure_init()
     x, h = c3_inputs(frames)
     L = 65536
-    nfft = lib.pgx_convolve_fft_size(L)
+    nfft = nfft or device_fft_size(L, frames)
     xd, hd = device.DeviceBuffer.from_host(x), device.DeviceBuffer.from_host(h.reshape(-1, 1))
     spec = device.DeviceBuffer((lib.pgx_convolve_fft_spectrum_bytes(nfft, 1),), np.uint8)
     device.check(lib.pgx_convolve_fft_prepare(spec.ptr, hd.ptr, L, 1, nfft))

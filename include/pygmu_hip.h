@@ -481,7 +481,12 @@ size_t pgx_ladder_workspace_bytes(int batch, int64_t n, int channels, int64_t se
  *    fb (batch == 1) optionally streams the feedback.  Up to 1024 * delay frames the render is the reference's loop
  *    operation for operation; beyond, time segments run concurrently (carries through a float64 affine fold).
  *  - freq != NULL (batch == 1): the smoothed frequency is carried in state[0] (-1 = unset); delays come from a
- *    time-parallel evaluation of the one-pole (comb_pe.py:61-77), the ring runs in LDS.  ring_rows = buffer_len. */
+ *    time-parallel evaluation of the one-pole (comb_pe.py:61-77), the ring runs in LDS.  ring_rows = buffer_len.
+ *    The delays are index work: a sample whose sr / f lies within 1e-9 of a rounding tie (where the time-parallel
+ *    level and the reference's chain, ~1e-14 apart, could round differently) raises a flag, and the block's delays
+ *    are then made again by the reference's loop itself on one lane -- always the reference's integers.
+ *    state = double[4]: {smoothed frequency, level on entering the last block, tie flag (int32), blocks redone by the
+ *    literal loop (int64)}; the caller sets {-1, 0, 0, 0} at reset. */
 typedef struct {
     double feedback;       /* scalar feedback (clamped to +-0.995 by the kernels, non-finite -> 0) */
     int32_t delay;         /* scalar-frequency delay in frames (unused with a frequency stream) */
@@ -492,7 +497,7 @@ int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride,
              int delay_min, int delay_max, const float *freq, const float *fb /* batch == 1 */,
              double min_frequency, int64_t smoothing_samples,
              double *ring, int64_t ring_rows, int64_t total_frames, int parity,
-             double *state /* [1], frequency stream only */, void *workspace);
+             double *state /* [4], frequency stream only */, void *workspace);
 size_t pgx_comb_workspace_bytes(int batch, int64_t n, int channels, int delay_max, int freq_stream);
 
 /* ------------------------------------------------------------------ envelopes / gates

@@ -34,7 +34,7 @@ class CombPE(ProcessingElement):
         self._freq_is_pe = isinstance(frequency, ProcessingElement)
         self._fb_is_pe = isinstance(feedback, ProcessingElement)
         self._ring: DeviceBuffer | None = None       # (2, buffer_len, C) float64: the half `_parity` is current
-        self._state: DeviceBuffer | None = None      # {smoothed_freq} (frequency PE only)
+        self._state: DeviceBuffer | None = None      # {smoothed_freq, entry level, tie flag, blocks redone} (frequency PE only)
         self._buffer_len = 0
         self._total = 0                              # frames rendered since the reset: write_pos = total % buffer_len
         self._parity = 0
@@ -86,7 +86,7 @@ class CombPE(ProcessingElement):
     def _allocate(self, channels: int) -> None:
         self._buffer_len = self._buffer_rows()
         self._ring = DeviceBuffer((2, self._buffer_len, channels), np.float64, zero=True)
-        self._state = DeviceBuffer.from_host(np.array([-1.0], dtype=np.float64))
+        self._state = DeviceBuffer.from_host(np.array([-1.0, 0.0, 0.0, 0.0], dtype=np.float64))
         self._total = 0
         self._parity = 0
         if self._params is None:

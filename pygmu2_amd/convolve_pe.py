@@ -42,6 +42,24 @@ def _next_pow2(n: int) -> int:
     return p
 
 
+LONG_RENDER_HOPS = int(__import__("os").environ.get("PGX_FFT_LONG_HOPS", "0"))   # 0: never switch (measured: DESIGN section 7)
+
+
+def device_fft_size(fir_len: int, frames: int) -> int:
+    """The transform size of the device's overlap-save for a render of `frames` frames: the smallest power of two >= twice
+    the filter (every block's transform is half history), or -- for renders of at least LONG_RENDER_HOPS of its hops --
+    twice that where the library has the geometry (2^18 points: a 65 536-tap filter then advances 196 609 frames per
+    transform instead of 65 537, a quarter fewer transform points per frame).  The reference's `fft_size` is a speed
+    knob of ITS block loop (convolve_pe.py:185-248) and does not change the linear convolution; neither does this."""
+    base = int(lib().pgx_convolve_fft_size(int(fir_len)))
+    if not base or not LONG_RENDER_HOPS:
+        return base
+    big = base * 2
+    if big <= (1 << 18) and frames >= LONG_RENDER_HOPS * (base - fir_len + 1):
+        return big
+    return base
+
+
 class ConvolvePE(ProcessingElement):
     _LOOK_AHEAD_SAFE = True            # look_ahead.py: overlap history carried sample-exactly
     _STATE_FIELDS = ("_hist", "_last_render_end")
@@ -149,13 +167,20 @@ class ConvolvePE(ProcessingElement):
         # sample; the FFT form a few hundred).  The library picks its own transform size; the reference's
         # fft_size only shapes ITS block loop and does not change the result.
         self._device_fft = 0
+        self._spectra = {}                    # transform size -> filter spectrum (made on first use)
         if length >= FFT_MIN_TAPS:
             self._device_fft = int(lib().pgx_convolve_fft_size(length))
         if self._device_fft:
+            self._spectrum_for(self._device_fft)
+
+    def _spectrum_for(self, fft: int) -> DeviceBuffer:
+        spec = self._spectra.get(fft)
+        if spec is None:
             L = lib()
-            self._spectrum = DeviceBuffer((L.pgx_convolve_fft_spectrum_bytes(self._device_fft, fir_ch),), np.uint8)
-            check(L.pgx_convolve_fft_prepare(self._spectrum.ptr, self._h.ptr, length, fir_ch, self._device_fft),
+            spec = self._spectra[fft] = DeviceBuffer((L.pgx_convolve_fft_spectrum_bytes(fft, self._fir_ch),), np.uint8)
+            check(L.pgx_convolve_fft_prepare(spec.ptr, self._h.ptr, self._fir_len, self._fir_ch, fft),
                   "pgx_convolve_fft_prepare")
+        return spec
 
     def _render(self, start: int, duration: int) -> Snippet:
         self._prepare()
@@ -175,8 +200,9 @@ class ConvolvePE(ProcessingElement):
         if src_ch != 1 and src_ch != out_ch:
             raise ValueError(f"ConvolvePE src channels ({src_ch}) incompatible with output channels ({out_ch})")
         L = lib()
+        fft = device_fft_size(length, duration) if self._device_fft else 0
         if self._device_fft:
-            need = L.pgx_convolve_fft_workspace_bytes(duration, length, out_ch, self._device_fft)
+            need = L.pgx_convolve_fft_workspace_bytes(duration, length, out_ch, fft)
         else:
             need = L.pgx_convolve_workspace_bytes(duration, length, out_ch)
         if self._workspace is None or self._workspace.nbytes < need:
@@ -184,8 +210,8 @@ class ConvolvePE(ProcessingElement):
             self._workspace = DeviceBuffer((need,), np.uint8)
         out = new_output(duration, out_ch)
         if self._device_fft:
-            check(L.pgx_convolve_fft(out.ptr, x.dev.ptr, duration, src_ch, self._spectrum.ptr, length,
-                                     self._fir_ch, out_ch, self._device_fft, self._hist.ptr,
+            check(L.pgx_convolve_fft(out.ptr, x.dev.ptr, duration, src_ch, self._spectrum_for(fft).ptr, length,
+                                     self._fir_ch, out_ch, fft, self._hist.ptr,
                                      self._workspace.ptr, 1 if fresh else 0), "pgx_convolve_fft")
         else:
             check(L.pgx_convolve(out.ptr, x.dev.ptr, duration, src_ch, self._h.ptr, length, self._fir_ch,

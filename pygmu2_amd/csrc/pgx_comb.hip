@@ -286,6 +286,7 @@ k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, dou
             if (PASS == 0) ends[nseg - 1] = c;
             else c = ends[nseg - 1];
         }
+        if (PASS == 1 && seg == 0) state[1] = c;                  // the level on entering the block: k_comb_delays_literal
         if (seg > 0) {
             if (PASS == 0) {
                 c = 0.0;                                          // zero-state response of the segment
@@ -327,12 +328,19 @@ k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, dou
         if (lane == 0) e = 0.0;
         double sm = __builtin_fma(plane, c, e);                   // level on entering this thread's samples
         int dmin = 0x7fffffff, dmax = 0;
+        bool tie = false;
 #pragma unroll
         for (int j = 0; j < kCtlT; ++j) {
             sm = sm + (raw[j] - sm) * alpha;                      // comb_pe.py:68
             if (PASS == 1) {
                 const double f = sm < 1.0 ? 1.0 : sm;
-                int64_t d = (int64_t)rint(sr / f);                // np.round: half to even
+                const double q = sr / f;
+                // The delay is index work and has to be the reference's integer.  This level and the literal chain's both
+                // sit ~1e-14 (relative) from the exact recurrence, so round(q) can differ only where q is within ~1e-10
+                // of a half-integer: such a sample is flagged (1e-9: an order of magnitude of margin) and the block's
+                // delays are then made again by the literal one-lane chain (k_comb_delays_literal).
+                tie = tie || (fabs((q - floor(q)) - 0.5) < 1e-9 && i0 + j < n);
+                int64_t d = (int64_t)rint(q);                     // np.round: half to even
                 d = d < 1 ? 1 : d;
                 d = d >= len ? len - 1 : d;
                 if (i0 + j < n) {
@@ -344,6 +352,7 @@ k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, dou
             }
         }
         if (PASS == 1) {
+            if (__any(tie) && lane == 0) reinterpret_cast<int *>(state + 2)[0] = 1;       // (every writer writes 1)
 #pragma unroll
             for (int s = 1; s < 64 / kCtlT; s <<= 1) {
                 dmin = min(dmin, __shfl_xor(dmin, s));
@@ -361,6 +370,49 @@ k_comb_delays(int64_t n, double sr, const float *freq, double min_frequency, dou
         }
         __syncthreads();
     }
+}
+
+// The reference's loop itself (comb_pe.py:61-85), one lane, for a block in which k_comb_delays met a rounding tie's
+// neighbourhood: the same operations in the same order give the reference's smoothed frequency bit for bit, hence its
+// delays.  Launched after every k_comb_delays<1>; returns at once unless the flag is up (practically always: a sample
+// lands within 1e-9 of a tie once in hours of audio).  8 ns per sample when it runs.  state = {smoothed frequency,
+// level on entering the block, tie flag (int), blocks redone (int64)}.
+__global__ void __launch_bounds__(64)
+k_comb_delays_literal(int64_t n, double sr, const float *freq, double min_frequency, double alpha, int64_t len,
+                      double *state, int32_t *delay, int32_t *gmin, int32_t *gmax) {
+    int *flag = reinterpret_cast<int *>(state + 2);
+    if (*flag == 0) return;
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        double sm = state[1];
+        for (int64_t i = 0; i < n; ++i) {
+            double raw = (double)freq[i];
+            raw = raw < min_frequency ? min_frequency : raw;
+            // k_comb_delays entered the block with sm = state[1]; when the stream had never run that value IS the first
+            // sample's clamped frequency and the first update leaves it unchanged in the reference too (sm = raw)
+            sm = sm + (raw - sm) * alpha;
+            const double f = sm < 1.0 ? 1.0 : sm;
+            int64_t d = (int64_t)rint(sr / f);
+            d = d < 1 ? 1 : d;
+            d = d >= len ? len - 1 : d;
+            delay[i] = (int32_t)d;
+        }
+        state[0] = sm;
+        reinterpret_cast<long long *>(state + 3)[0] += 1;
+    }
+    __syncthreads();
+    __threadfence();
+    for (int64_t g = lane; g < (n + 63) / 64; g += 64) {
+        int lo = 0x7fffffff, hi = 0;
+        for (int64_t i = g * 64; i < n && i < g * 64 + 64; ++i) {
+            const int d = delay[i];
+            lo = min(lo, d);
+            hi = max(hi, d);
+        }
+        gmin[g] = lo;
+        gmax[g] = hi;
+    }
+    if (lane == 0) *flag = 0;
 }
 
 constexpr int kRingThreads = 256, kRingTile = 2048, kRingGroups = kRingTile / 64, kRingPer = kRingTile / kRingThreads;
@@ -764,6 +816,9 @@ int pgx_comb(float *out, int64_t out_stride, const float *in, int64_t in_stride,
                            min_frequency, 1.0 / (double)smoothing_samples, len, state, delay, gmin, gmax, ends,
                            ctl_segs);
         PGX_LAUNCH_CHECK("k_comb_delays");
+        hipLaunchKernelGGL(k_comb_delays_literal, dim3(1), dim3(64), 0, pgx::stream(), n, sample_rate, freq,
+                           min_frequency, 1.0 / (double)smoothing_samples, len, state, delay, gmin, gmax);
+        PGX_LAUNCH_CHECK("k_comb_delays_literal");
         const double *ring_old = ring + (int64_t)parity * ring_rows * channels;
         double *ring_new = ring + (int64_t)(parity ^ 1) * ring_rows * channels;
         const int64_t wp0 = total_frames % len;

@@ -329,13 +329,15 @@ int pgx_malloc(void **dptr, size_t bytes) {
     *dptr = p;
     // The first large block of a process announces a streaming caller (a look-ahead window: 32 MB for 8 blocks of
     // 1 M frames): its next windows are 2, 4, 8 times longer, and a hipMalloc of that size in the middle of a stream
-    // costs more than rendering the window.  Put one block of each of the next classes aside now (480 MB of 288 GB).
+    // costs more than rendering the window.  Put one block of each of the next two classes aside now -- the two
+    // doublings a stream's windows make before they reach their cap (6 x the block just asked for: 192 MB behind a
+    // 32 MB window; every class up to 256 MB, 480 MB, until round 4 -- too much for several ranks sharing a card).
+    // PGX_POOL_RESERVE=0 switches it off.
     static const bool reserve = !(getenv("PGX_POOL_RESERVE") && atoi(getenv("PGX_POOL_RESERVE")) == 0);
     static bool reserved = false;
     if (reserve && !reserved && cls >= ((size_t)16 << 20)) {
         reserved = true;
-        for (size_t c = (size_t)32 << 20; c <= ((size_t)256 << 20); c <<= 1) {
-            if (c == cls) continue;
+        for (size_t c = cls << 1; c <= (cls << 2) && c <= ((size_t)256 << 20); c <<= 1) {
             void *q = nullptr;
             if (hipMalloc(&q, c) != hipSuccess) {
                 (void)hipGetLastError();

@@ -194,7 +194,9 @@ class LadderPE(ProcessingElement):
         self._state: DeviceBuffer | None = None      # [C][9]: z0[4], z1[4], old_input
         self._state_channels = 0
         self._workspace: DeviceBuffer | None = None
-        self._range_dev: DeviceBuffer | None = None          # (256, 2) float64: min / max pairs of a control stream
+        self._range_dev: DeviceBuffer | None = None          # (2, 256, 2) float64: min / max pairs of the two control streams
+        self._range_pending: list = []
+        self._range_seen: list = []
         self._stream_settle_cache: dict = {}
         self._stream_accurate = 0
         self._optimist: SettleOptimist | None = None        # warm-up lengths by trial (no analytic estimate)
@@ -232,6 +234,7 @@ class LadderPE(ProcessingElement):
     def _reset_state(self) -> None:
         if self._state is not None:
             self._state.zero_()
+        self._range_pending, self._range_seen = [], []       # a new stream: its first block waits for its own range
 
     _on_start = _reset_state
     _on_stop = _reset_state
@@ -289,28 +292,56 @@ class LadderPE(ProcessingElement):
             return 0
         return ladder_settle_frames(self._frequency, self._resonance, self.sample_rate, self._oversample)
 
-    def _stream_range(self, buf: DeviceBuffer, duration: int):
-        """(min, max) of a control stream of this block: one small launch and a read-back of a few pairs."""
+    def _stream_ranges(self, f_buf, r_buf, duration: int):
+        """(lowest cutoff, highest resonance) the warm-up is planned for, None where the control is a scalar.
+        The block's own range is asked for (one small launch per control stream, one asynchronous read-back of both)
+        but not waited for: a device wait per block would undo the pipelining of everything queued before it.  The
+        plan uses the ranges that HAVE arrived -- the previous blocks' -- extended by their trend (a sweep keeps
+        moving), and only a stream's first block waits.  A stale estimate cannot hurt the result: the device
+        verifies every segment against its neighbour and re-renders the chain when one disagrees."""
         parts = int(min(256, max(1, duration // 4096)))
-        if self._range_dev is None or self._range_dev.shape[0] < parts:
-            self._range_dev = DeviceBuffer((256, 2), np.float64)
-        check(lib().pgx_stream_range(self._range_dev.ptr, parts, buf.ptr, duration), "pgx_stream_range")
-        pairs = self._range_dev.to_host()[:parts]
-        return float(np.min(pairs[:, 0])), float(np.max(pairs[:, 1]))
+        if self._range_dev is None:
+            self._range_dev = DeviceBuffer((2, 256, 2), np.float64)
+            self._range_pending = []                 # (ticket, host view, parts, has f, has r)
+            self._range_seen = []                    # the last two (lo_f, hi_r) that arrived
+        L = lib()
+        if self._range_pending:                      # the buffer is written again: behind the copy that still reads it
+            _dev.fence_to_host(self._range_pending[-1][0])
+        if f_buf is not None:
+            check(L.pgx_stream_range(self._range_dev.ptr, parts, f_buf.ptr, duration), "pgx_stream_range")
+        if r_buf is not None:
+            check(L.pgx_stream_range(self._range_dev.offset_ptr(512), parts, r_buf.ptr, duration), "pgx_stream_range")
+        view, ticket = self._range_dev.begin_to_host()
+        self._range_pending.append((ticket, view, parts, f_buf is not None, r_buf is not None))
+        while self._range_pending:
+            ticket, view, p, has_f, has_r = self._range_pending[0]
+            if not self._range_seen and len(self._range_pending) == 1:
+                _dev.wait_to_host(ticket)            # the stream's first block: nothing to go by yet
+            elif not _dev.host_copy_done(ticket):
+                break
+            self._range_pending.pop(0)
+            lo_f = float(np.min(view[0, :p, 0])) if has_f else None
+            hi_r = float(np.max(view[1, :p, 1])) if has_r else None
+            self._range_seen = (self._range_seen + [(lo_f, hi_r)])[-2:]
+        last = self._range_seen[-1]
+        prev = self._range_seen[-2] if len(self._range_seen) > 1 else last
+        behind = 1 + len(self._range_pending)        # blocks between the newest range and the block being planned
+        lo_f = hi_r = None
+        if last[0] is not None:
+            lo_f = last[0] - behind * max(0.0, (prev[0] if prev[0] is not None else last[0]) - last[0])
+        if last[1] is not None:
+            hi_r = last[1] + behind * max(0.0, last[1] - (prev[1] if prev[1] is not None else last[1]))
+        return lo_f, hi_r
 
     def _settle_frames_for_streams(self, f_buf, r_buf, duration: int) -> int:
         """Warm-up length of the time segments when cutoff and / or resonance are PEs: the ladder forgets slowest at
         the lowest cutoff and the highest resonance it sees, so the estimate of ladder_settle_frames is taken there
-        (block minimum / maximum from the device, quantised so that a sweep does not recompute it every block, and
-        half as much again for the coefficients moving under the warm-up).  Only an estimate is needed: the device
-        verifies every segment against its neighbour and re-renders the chain sequentially if one disagrees."""
+        (quantised so that a sweep does not recompute it every block, and half as much again for the coefficients
+        moving under the warm-up).  Only an estimate is needed: the device verifies every segment against its
+        neighbour and re-renders the chain sequentially if one disagrees."""
         if duration < STREAM_SEGMENT_MIN_FRAMES:
             return 0
-        lo_f = hi_r = None
-        if f_buf is not None:
-            lo_f, _ = self._stream_range(f_buf, duration)
-        if r_buf is not None:
-            _, hi_r = self._stream_range(r_buf, duration)
+        lo_f, hi_r = self._stream_ranges(f_buf, r_buf, duration)
         cutoff = float(self._frequency) if lo_f is None else lo_f
         res = float(self._resonance) if hi_r is None else hi_r
         if not (np.isfinite(cutoff) and np.isfinite(res)):

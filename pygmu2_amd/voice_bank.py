@@ -47,8 +47,8 @@ BANK_WINDOW_FRAMES = 1 << 20
 BANK_WINDOW_MAX_VOICES = 256  # (a bank that fills the chip gains nothing: its launches are long)
 LADDER_WINDOWS = True         # a ladder bank directly under the mix, streamed in equal blocks: several blocks per launch
 LADDER_WINDOW_FIRST = 2       # ... 2, then 4, then 8 blocks
-LADDER_WINDOW_MAX = 8
-LADDER_WINDOW_FRAMES = 1 << 20   # ... and at most this many frames
+LADDER_WINDOW_MAX = int(os.environ.get("PGX_LADDER_WINDOW_MAX", "8"))
+LADDER_WINDOW_FRAMES = int(os.environ.get("PGX_LADDER_WINDOW_FRAMES", str(1 << 20)))   # ... and at most this many frames
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch

@@ -226,3 +226,98 @@ def test_random_combs_against_the_oracle(seed):
     for i, ((s, n), g, w) in enumerate(zip(blocks, got, want)):
         err = float(np.max(np.abs(g.astype(np.float64) - w)))
         assert err <= tol * peak, (i, s, n, err, peak, sr, ch, kw)
+
+
+# ---------------------------------------------------------------------------- rounding ties in the delays (index work)
+def _literal_levels(raw, alpha, min_f):
+    """comb_pe.py:61-68 in Python floats: the smoothed frequency after every sample."""
+    out = np.empty(len(raw))
+    sm = -1.0
+    for i, v in enumerate(raw):
+        v = float(v)
+        v = v if v >= min_f else min_f
+        sm = v if sm < 0.0 else sm + (v - sm) * alpha
+        out[i] = sm
+    return out
+
+
+def _ulps(raw, lo, hi, k):
+    """raw[lo:hi] moved by k float32 ulps (positive floats: the integer representation is monotonic)."""
+    raw = raw.copy()
+    bits = raw.view(np.int32)
+    bits[lo:hi] += k
+    return raw
+
+
+def plant_a_tie(sr=44100, n=30_000, smoothing=2400, min_f=20.0, tie=220.5):
+    """A float32 frequency stream (a slow ramp through sr / tie) whose smoothed level puts sr / f within ~2e-12 of the
+    rounding tie at one sample: coarse to fine -- a run of samples moved by whole ulps, a shorter run by one ulp, then
+    one ulp up at one sample and one ulp down at another (steps of ~3e-12 in sr / f)."""
+    alpha = 1.0 / smoothing
+    f_tie = sr / tie
+    raw = np.linspace(f_tie - 10.0, f_tie + 10.0, n).astype(np.float32)
+    q = sr / _literal_levels(raw, alpha, min_f)
+    t = int(np.argmax(q < tie))                                   # the first sample below the tie
+    assert 6000 < t < n - 10
+    ulp = float(np.spacing(np.float32(f_tie)))
+
+    def residual(r):
+        sm = _literal_levels(r[:t + 1], alpha, min_f)[t]
+        return sr / sm - tie, sm
+
+    for _ in range(40):
+        r, sm = residual(raw)
+        if abs(r) < 2e-12:
+            break
+        need = r * sm / (sr / sm)                                 # change of the level that cancels r (dq/dsm = -q/sm)
+        if abs(need) > 0.8 * ulp:
+            raw = _ulps(raw, t - 4800, t + 1, int(round(need / (ulp * (1.0 - (1.0 - alpha) ** 4801)))))
+        elif abs(need) > alpha * ulp:
+            length = int(round(np.log(1.0 - abs(need) / ulp) / np.log(1.0 - alpha)))
+            raw = _ulps(raw, t + 1 - max(length, 1), t + 1, 1 if need > 0 else -1)
+        else:
+            # +1 ulp at lag a, -1 ulp at lag b: alpha ulp ((1 - alpha)^a - (1 - alpha)^b)
+            a = int(np.random.default_rng(_).integers(0, 40))
+            target = (1.0 - alpha) ** a - abs(need) / (alpha * ulp)
+            if target <= 0.05:
+                raw = _ulps(raw, t, t + 1, 1 if need > 0 else -1)
+                continue
+            b = int(round(np.log(target) / np.log(1.0 - alpha)))
+            if b <= a:
+                b = a + 1
+            s = 1 if need > 0 else -1
+            raw = _ulps(_ulps(raw, t - a, t - a + 1, s), t - b, t - b + 1, -s)
+    r, _sm = residual(raw)
+    return raw, t, r
+
+
+def test_rounding_ties_in_the_delays_take_the_literal_chain():
+    """delays are index work.  A stream planted so that sr / f sits ~1e-12 from a rounding tie at one
+    sample (closer than the time-parallel level and the reference's chain agree): k_comb_delays flags the block, the
+    literal one-lane chain makes its delays again, and the output is the reference's bit for bit."""
+    import pygmu2_amd as pg
+    from oracle import pe_oracle as O
+    sr, n = 44100, 30_000
+    raw, t, r = plant_a_tie(sr, n)
+    assert abs(r) < 1e-10, r                                      # (2e-12 as a rule; anything below 1e-9 raises the flag)
+    rng = np.random.default_rng(5)
+    x = (0.3 * rng.standard_normal((n, 1))).astype(np.float32)
+    pg.set_sample_rate(sr)
+    pe = pg.CombPE(pg.ArrayPE(x), frequency=pg.ArrayPE(raw.reshape(-1, 1)), feedback=0.7, min_frequency=20.0,
+                   smoothing_samples=2400)
+    rr = pg.NullRenderer(sample_rate=sr)
+    rr.set_source(pe)
+    rr.start()
+    blocks = [(0, t - 3000), (t - 3000, 9000), (t + 6000, n - t - 6000)]           # the tie sits in the second block
+    got = [pe.render(s, m).data.copy() for s, m in blocks]
+    from pygmu2_amd import look_ahead
+    look_ahead.settle(pe)                         # (a window opened at the second pull ran on past the stream's end)
+    state = pe._state.to_host()
+    rr.stop()
+    st = O.comb_state(1, sr, 20.0)
+    want = [O.comb(st, x[s:s + m], raw[s:s + m].astype(np.float64), 0.7, 20.0, 2400, sr) for s, m in blocks]
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), (i, int(np.sum(g != w)))
+    assert int(state[3:4].view(np.int64)[0]) == 1, "exactly the block with the planted tie is redone"
+    assert state[0] == st["sm"], "the carried level is the literal chain's, bit for bit"
+    assert int(state[2:3].view(np.int32)[0]) == 0, "the flag is lowered again"

@@ -188,6 +188,18 @@ def _graph(seed):
             "keep": list(range(len(blocks)))}
 
 
+def _where_the_reference_is_finite(g, w):
+    """EnvelopePE(mode=RMS): scipy's running-sum uniform_filter1d can drift a hair below zero after a loud passage, and
+    the reference then takes sqrt(negative) = NaN (envelope_pe.py:208-225) -- which every stateful PE downstream keeps
+    for the rest of the stream.  The device sums each window afresh and returns the non-negative value (DESIGN section
+    6: a deliberate deviation -- the NaN is an artefact of the running sum, not a value anyone asked for).  Such
+    samples are left out of the comparison; everything the reference does define is compared as usual."""
+    ok = np.isfinite(w)
+    if ok.all():
+        return g, w
+    return g[ok], w[ok]
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_SEEDS", "300"))))
 def test_random_graph_matches_oracle(seed):
     from oracle.graph_eval import run_case as oracle_run
@@ -197,13 +209,8 @@ def test_random_graph_matches_oracle(seed):
     want = oracle_run(case)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == w.shape, (case, i, g.shape, w.shape)
-        if not np.all(np.isfinite(w)):
-            # EnvelopePE(mode=RMS): scipy's running-sum uniform_filter1d can drift a hair below zero after a
-            # loud passage, and the reference then takes sqrt(negative) = NaN (envelope_pe.py:222).  The device
-            # sums each window afresh and returns the non-negative value; nothing to compare in that block.
-            assert np.all(np.isfinite(g))
-            pytest.skip("reference output contains NaN (running-sum RMS underflow)")
         assert np.all(np.isfinite(g)), (case["graph"], i)
+        g, w = _where_the_reference_is_finite(g, w)
         peak = float(np.max(np.abs(w))) if w.size else 0.0
         err = float(np.max(np.abs(g.astype(np.float64) - w.astype(np.float64)))) if w.size else 0.0
         assert err <= REL_TOL * peak + ABS_FLOOR, (case["graph"], case["blocks"], i, err, peak)
@@ -232,10 +239,8 @@ def test_random_graph_long_blocks(seed):
     want = oracle_run(case)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == w.shape, (case, i, g.shape, w.shape)
-        if not np.all(np.isfinite(w)):
-            assert np.all(np.isfinite(g))
-            pytest.skip("reference output contains NaN (running-sum RMS underflow)")
         assert np.all(np.isfinite(g)), (case["graph"], i)
+        g, w = _where_the_reference_is_finite(g, w)
         peak = float(np.max(np.abs(w))) if w.size else 0.0
         err = float(np.max(np.abs(g.astype(np.float64) - w.astype(np.float64)))) if w.size else 0.0
         # 3e-5: resonant stages in cascade multiply what their input is off by (seed 194: a comb with feedback -0.87
@@ -271,10 +276,8 @@ def test_random_graph_streams(seed):
     want = oracle_run(case)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == w.shape, (case, i, g.shape, w.shape)
-        if not np.all(np.isfinite(w)):
-            assert np.all(np.isfinite(g))
-            pytest.skip("reference output contains NaN (running-sum RMS underflow)")
         assert np.all(np.isfinite(g)), (case["graph"], i)
+        g, w = _where_the_reference_is_finite(g, w)
         peak = float(np.max(np.abs(w))) if w.size else 0.0
         err = float(np.max(np.abs(g.astype(np.float64) - w.astype(np.float64)))) if w.size else 0.0
         assert err <= 3 * REL_TOL * peak + ABS_FLOOR, (case["graph"], case["blocks"][max(0, i - 2):i + 1], i, err, peak)
