@@ -42,7 +42,9 @@ def _next_pow2(n: int) -> int:
     return p
 
 
-LONG_RENDER_HOPS = int(__import__("os").environ.get("PGX_FFT_LONG_HOPS", "0"))   # 0: never switch (measured: DESIGN section 7)
+LONG_RENDER_HOPS = int(__import__("os").environ.get("PGX_FFT_LONG_HOPS", "3"))   # 0: never switch.  Measured (tools/
+# c3_fft_sizes.py, 65 536 taps, stereo, us per call at 2^17 / 2^18 points): 196 609 frames 21.4 / 20.7, 393 218 29.5 / 26.3,
+# 786 436 38.4 / 34.2, 1 440 000 58.8 / 53.8, 2 880 000 101.8 / 88.3 -- the larger transform wins from three hops on
 
 
 def device_fft_size(fir_len: int, frames: int) -> int:

@@ -46,9 +46,12 @@ BANK_WINDOW_MAX = 8
 BANK_WINDOW_FRAMES = 1 << 20
 BANK_WINDOW_MAX_VOICES = 256  # (a bank that fills the chip gains nothing: its launches are long)
 LADDER_WINDOWS = True         # a ladder bank directly under the mix, streamed in equal blocks: several blocks per launch
-LADDER_WINDOW_FIRST = 2       # ... 2, then 4, then 8 blocks
-LADDER_WINDOW_MAX = int(os.environ.get("PGX_LADDER_WINDOW_MAX", "8"))
-LADDER_WINDOW_FRAMES = int(os.environ.get("PGX_LADDER_WINDOW_FRAMES", str(1 << 20)))   # ... and at most this many frames
+LADDER_WINDOW_FIRST = 2       # ... 2, then 4, 8, 16, 32 blocks (a lane of k_ladder_segments pays its 1024-sample warm-up once per
+                              # launch: C4 over a stream 0.0675 ms per block with windows up to 8, 0.0591 up to 16, 0.0497 up to 32
+                              # -- tools/c4_windows_probe.py; the same ladders at resonance 0.6, whose warm-up is 2048: 0.226 /
+                              # 0.134 / 0.088; like look-ahead's windows a stream that stops after k blocks has rendered < 2k + 2)
+LADDER_WINDOW_MAX = int(os.environ.get("PGX_LADDER_WINDOW_MAX", "32"))
+LADDER_WINDOW_FRAMES = int(os.environ.get("PGX_LADDER_WINDOW_FRAMES", str(1 << 21)))   # ... and at most this many frames
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
@@ -1012,9 +1015,12 @@ class VoiceBank:
                 and (isinstance(self.root, _SuperSawNode) and not self.root.fused() or BANK_WINDOWS_ANY_ROOT
                      or self.mix_windows)
                 and not lib().pgx_stream_is_forked()):
-            blocks = max(1, min(self.grow, BANK_WINDOW_FRAMES // duration))
+            # (a ladder root -- a rank's share of C4 -- takes the ladder bank's longer windows: its lanes' warm-up does
+            # not shrink with the share, so the fewer instances a rank owns the more of a short window is warm-up)
+            ladder_root = isinstance(self.root, _LadderNode)
+            blocks = max(1, min(self.grow, (LADDER_WINDOW_FRAMES if ladder_root else BANK_WINDOW_FRAMES) // duration))
             if blocks > 1:
-                self.grow = min(self.grow * 2, BANK_WINDOW_MAX)
+                self.grow = min(self.grow * 2, LADDER_WINDOW_MAX if ladder_root else BANK_WINDOW_MAX)
                 nodes = self._nodes()
                 for node in nodes:
                     node.quiesce()

@@ -231,12 +231,12 @@ def test_random_graph_long_blocks(seed):
         blocks.append([pos, n])
         pos += n
     case["blocks"], case["keep"] = blocks, list(range(len(blocks)))
-    if _has_self_oscillating_ladder(case["graph"], case["sr"]):
+    want = oracle_run(case)
+    if _has_self_oscillating_ladder(case["graph"], case["sr"]) and _reference_is_ill_conditioned(case, want):
         # (seed 413: cutoff 4196 Hz at 22 050 Hz, resonance 0.77 -- the REFERENCE's output moves by 0.38 of full scale
         # when its input is scaled by 1 + 1e-7: a chaotic orbit, which only bit-identical tanh could follow for 1e5 samples)
         pytest.skip("a ladder at or above self-oscillation: the reference itself is ill-conditioned over long blocks")
     got = hip_run(case)
-    want = oracle_run(case)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == w.shape, (case, i, g.shape, w.shape)
         assert np.all(np.isfinite(g)), (case["graph"], i)
@@ -270,10 +270,10 @@ def test_random_graph_streams(seed):
         blocks.append([pos, size])
         pos += size
     case["blocks"], case["keep"] = blocks, list(range(len(blocks)))
-    if _has_self_oscillating_ladder(case["graph"], case["sr"]):
+    want = oracle_run(case)
+    if _has_self_oscillating_ladder(case["graph"], case["sr"]) and _reference_is_ill_conditioned(case, want):
         pytest.skip("a ladder at or above self-oscillation: the reference itself is ill-conditioned over long streams")
     got = hip_run(case)
-    want = oracle_run(case)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == w.shape, (case, i, g.shape, w.shape)
         assert np.all(np.isfinite(g)), (case["graph"], i)
@@ -281,6 +281,36 @@ def test_random_graph_streams(seed):
         peak = float(np.max(np.abs(w))) if w.size else 0.0
         err = float(np.max(np.abs(g.astype(np.float64) - w.astype(np.float64)))) if w.size else 0.0
         assert err <= 3 * REL_TOL * peak + ABS_FLOOR, (case["graph"], case["blocks"][max(0, i - 2):i + 1], i, err, peak)
+
+
+def _nudge_ladder_inputs(g):
+    """The same graph with every LadderPE's input scaled by 1 + 1e-7 (a float32 ulp, give or take)."""
+    if isinstance(g, list):
+        return [_nudge_ladder_inputs(x) for x in g]
+    if not isinstance(g, dict):
+        return g
+    out = {k: _nudge_ladder_inputs(v) for k, v in g.items()}
+    if out.get("pe") == "LadderPE":
+        out["source"] = {"pe": "GainPE", "source": out["source"], "gain": 1.0 + 1e-7}
+    return out
+
+
+def _reference_is_ill_conditioned(case, want) -> bool:
+    """A ladder at or above self-oscillation that its input does not entrain follows an orbit of its own: the reference's
+    output then moves by a large fraction of full scale when the input moves by one float32 ulp, and no implementation
+    whose tanh is not bit-identical can follow it.  Measured on the oracle itself: the case is compared only if a 1e-7
+    nudge of the ladders' inputs moves the reference by less than 3e-6 of its peak (a driven, entrained ladder -- which
+    the time segments with warm-ups found by trial render -- moves by ~1e-7)."""
+    from oracle.graph_eval import run_case as oracle_run
+    nudged = oracle_run(dict(case, graph=_nudge_ladder_inputs(case["graph"])))
+    for a, b in zip(want, nudged):
+        ok = np.isfinite(a) & np.isfinite(b)
+        if not ok.any():
+            continue
+        peak = float(np.max(np.abs(a[ok])))
+        if float(np.max(np.abs(a[ok].astype(np.float64) - b[ok]))) > 3e-6 * peak + 1e-9:
+            return True
+    return False
 
 
 def _has_self_oscillating_ladder(g, sr):

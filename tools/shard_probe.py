@@ -6,25 +6,28 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pygmu2_amd as pg
 from pygmu2_amd import device
-from pygmu2_amd.sharding import c5_voice, shard_indices, supersaw_voice
+from pygmu2_amd.sharding import c4_voice, c5_voice, shard_indices, supersaw_voice
 
 pg.set_sample_rate(48000)
 block = 48000
-make = supersaw_voice if sys.argv[1:] == ["supersaw"] else c5_voice
+which = sys.argv[1] if len(sys.argv) > 1 else "c5"
+make, total = {"supersaw": (supersaw_voice, 512), "c5": (c5_voice, 512), "c4": (c4_voice, 64)}[which]
 for world in [int(w) for w in os.environ.get("PGX_WORLDS", "1,2,4,8").split(",")]:
-    voices = [make(pg, i) for i in shard_indices(512, 0, world)]
+    voices = [make(pg, i) for i in shard_indices(total, 0, world)]
     root = pg.MixPE(*voices)
+    if which == "c4" and world > 1:
+        root.__dict__["_mix_windows"] = True      # as ShardedMixPE asks: windows at the level of the mix (one collective each)
     r = pg.NullRenderer(sample_rate=48000)
     r.set_source(root)
     r.start()
     # (15 blocks of warm-up: a small bank's windows of 2, 4, 8 blocks open -- and their buffers are allocated, a hipMalloc
     # of a few hundred MB is milliseconds on some boxes -- before the clock starts; 24 timed blocks = three whole windows)
-    warm = 15
+    warm = 31 if which == "c4" else 15            # (C4's windows grow to 32 blocks)
     for i in range(warm):
         root.render(i * block, block)
     device.synchronize()
     t0 = time.perf_counter()
-    reps = 24
+    reps = 64 if which == "c4" else 24
     for i in range(reps):
         keep = root.render((warm + i) * block, block)
     device.synchronize()
