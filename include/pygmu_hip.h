@@ -398,6 +398,18 @@ int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n
                             double *biquad_state /* [batch][2] */,
                             const float *gain /* NULL, or [batch][gain_stride]: out = float32(voice * gain), GainPE's product */,
                             int64_t gain_stride);
+/* The same chain in concurrent time segments for banks of up to 256 voices (a rank's share of a sharded mix), so that a
+ * few voices fill the chip with ONE launch: workgroup (voice, s) renders the 4096-frame tiles of segment s.  On entering
+ * a segment the oscillator's phase is a product and its integrator level a closed form (the harmonics' steady state plus
+ * the decayed remainder of the carried level); the filter has no closed form but forgets: the segment starts
+ * ceil(settle_frames / 4096) tiles early from a zero filter state and emits nothing there (settle_frames: the caller's
+ * bound for "every entry of A^W below 2^-90", the largest of the bank, > 0).  States are read from the *_in buffers and
+ * written to the *_out buffers (two different buffers each).  <= 1e-6 of peak from pgx_blitsaw_biquad_wide. */
+int pgx_blitsaw_biquad_wide_segments(int batch, int64_t n, int64_t settle_frames);
+int pgx_blitsaw_biquad_wide_seg(float *out, int64_t out_stride, int batch, int64_t n, const double *saw_tables,
+                                const double *saw_state_in, double *saw_state_out, const double *coef,
+                                const double *biquad_tables, const double *biquad_state_in, double *biquad_state_out,
+                                const float *gain, int64_t gain_stride, int64_t settle_frames);
 
 /* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
  * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the

@@ -2249,16 +2249,34 @@ struct SawBqWideShared {
     double aff[2 * NW];
     V2 tot[2][NW];
 };
-template <int NW, bool GAIN>
+// SEG (round 4: a rank's share of C5, banks of up to 256 voices): workgroup (voice, s) renders the tiles of time segment
+// s, so that a few voices fill the chip.  What it needs on entering: the oscillator's phase -- a product, as everywhere in
+// this kernel -- and integrator level -- the closed form of k_supersaw_wide's segments (saw_steady_terms) -- and the
+// filter's state, which has no closed form but is forgotten: the segment starts `warm_tiles` tiles early from a zero filter
+// state (the host's settle_frames: every entry of A^W below 2^-90) and emits nothing there.  States are read from one
+// buffer and written to another (the workgroup of the last segment writes while those of the others may still read).
+template <int NW, bool GAIN, bool SEG = false>
 __global__ void __launch_bounds__(NW * 64)
 k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *saw_tables, double *saw_state,
                       const double *coef, const double *bq_tables, double *bq_state, const float *gain,
-                      int64_t gain_stride) {
+                      int64_t gain_stride, double *saw_state_out = nullptr, double *bq_state_out = nullptr,
+                      int seg_tiles = 0, int warm_tiles = 0) {
     constexpr int T = kSswT, kTile = NW * 64 * T;
     static_assert(kSswT == kBqT, "the filter tables are made for 16 frames per thread");
     __shared__ SawBqWideShared<NW> sh;
+    __shared__ double sh_entry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int inst = blockIdx.x;
+    double *saw_out = SEG ? saw_state_out : saw_state, *bq_out = SEG ? bq_state_out : bq_state;
+    int64_t base_first = 0, emit_from = 0, base_end = n;
+    if (SEG) {
+        const int64_t t0 = (int64_t)blockIdx.y * seg_tiles;
+        emit_from = t0 * kTile;
+        if (emit_from >= n) return;
+        base_first = (t0 > warm_tiles ? t0 - warm_tiles : 0) * kTile;
+        base_end = emit_from + (int64_t)seg_tiles * kTile;
+        if (base_end > n) base_end = n;
+    }
     float *ob = out + (int64_t)inst * out_stride;
     // uniform loads: the voice's constants live in scalar registers
     const double *st = saw_tables + (int64_t)inst * kSswTabDoubles;
@@ -2283,13 +2301,44 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
     const M2 m32 = load_m2(tb + 28 + 4 * ((lane & 31) + 1));
     const double *rows = tb + kBqRowsAt;
     V2 carry_z{bq_state[inst * 2 + 0], bq_state[inst * 2 + 1]};
+    if (SEG && base_first > 0) {
+        // the integrator level on entering the segment (comment above k_supersaw_bank): one wave, the harmonics over
+        // its lanes; the filter starts from rest, `warm_tiles` tiles before the first frame it emits
+        carry_z = V2{0.0, 0.0};
+        if (wave == 0) {
+            const double ph_a = pgx::pgx_mod1(phase0 + (double)base_first * inc);
+            const int K = ((int)m - 1) / 2;
+            double pa, pb;
+            saw_steady_terms(ph_a, phase0, inc, leak, K, lane + 1, 64, pa, pb);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                pa += __shfl_xor(pa, o);
+                pb += __shfl_xor(pb, o);
+            }
+            if (lane == 0) {
+                const double scale = 2.0 * invP;
+                double per_tile = lam_wave;                               // leak^(16 * 64): one wave's frames
+#pragma unroll
+                for (int t = 1; t < NW; t <<= 1) per_tile = per_tile * per_tile;
+                double decay = 1.0;
+                for (int64_t e = base_first / kTile; e > 0; e >>= 1) {
+                    if (e & 1) decay = decay * per_tile;
+                    per_tile = per_tile * per_tile;
+                }
+                sh_entry = __builtin_fma(decay, carry_y - scale * pb, scale * pa);
+            }
+        }
+        __syncthreads();
+        carry_y = sh_entry;
+    }
     const double tile_s = st[20], tile_c = st[21], tile_sm = st[22], tile_cm = st[23];
     double a_sd = 0.0, a_cd = 1.0, a_sn = 0.0, a_cn = 1.0;
     int parity = 0;
     const float *gb = GAIN ? gain + (int64_t)inst * gain_stride : nullptr;     // (GAIN: its own instantiation -- as a run-time
                                                                                 // option it cost the plain kernel 19 VGPRs and 8 %)
-    for (int64_t base = 0; base < n; base += kTile, ++parity) {
+    for (int64_t base = base_first; base < base_end; base += kTile, ++parity) {
         const int64_t f0 = base + (int64_t)tid * T;
+        const bool emit = !SEG || base >= emit_from;               // (a segment's warm-up tiles only move the states)
         // the voice's gain (GainPE(x, gain=<PE>): float32 x float32) for these frames, asked for first
         float gv[GAIN ? T : 1];
         if (GAIN) {
@@ -2308,7 +2357,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         // The anchor -- sin / cos of theta and M theta at the thread's first frame -- is evaluated for the first tile and
         // turned by a tile's advance (table: angles reduced exactly) for every further one: 8 operations instead of two
         // sincos (~60); a block's 12 tiles add ~1e-15.
-        if (PGX_COLD(base == 0)) {
+        if (PGX_COLD(base == base_first)) {
             const double ph = pgx::pgx_mod1(phase0 + (double)(f0 + 1) * inc);
             const double theta = kPi * ph;
             pgx::pgx_sincos_bounded(theta, a_sd, a_cd);
@@ -2362,15 +2411,17 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         carry_z = fold;
         const V2 ex = dpp_v2<0x138, 0xf>(ez);                     // the lane before, 0 for lane 0
         const V2 zin = mv_add_fma(mlane, cw, ex);
-        float yf[T];
+        if (PGX_HOT(emit)) {
+            float yf[T];
 #pragma unroll
-        for (int j = 0; j < T; ++j)
-            yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
-        if (GAIN) {
+            for (int j = 0; j < T; ++j)
+                yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
+            if (GAIN) {
 #pragma unroll
-            for (int j = 0; j < T; ++j) yf[j] = yf[j] * gv[GAIN ? j : 0];   // gain_pe.py:104-119: the float32 product
+                for (int j = 0; j < T; ++j) yf[j] = yf[j] * gv[GAIN ? j : 0];   // gain_pe.py:104-119: the float32 product
+            }
+            store_frames<T>(ob, f0, n, 1, 0, yf);
         }
-        store_frames<T>(ob, f0, n, 1, 0, yf);
         if (PGX_COLD(f0 <= n - 1 && n - 1 < f0 + T)) {            // the thread that renders the block's last frame:
             const int jn = (int)(n - 1 - f0);                     // the states after it, by the literal recurrences
             double yl = y_in;
@@ -2387,13 +2438,13 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
                     z = V2{z0, z1};
                 }
             }
-            saw_state[inst * 2 + 1] = yl;
-            bq_state[inst * 2 + 0] = z.x;
-            bq_state[inst * 2 + 1] = z.y;
+            saw_out[inst * 2 + 1] = yl;
+            bq_out[inst * 2 + 0] = z.x;
+            bq_out[inst * 2 + 1] = z.y;
         }
         (void)ez_own;
     }
-    if (tid == 0) saw_state[inst * 2 + 0] = pgx::pgx_mod1(phase0 + (double)n * inc);
+    if (tid == 0 && (!SEG || base_end == n)) saw_out[inst * 2 + 0] = pgx::pgx_mod1(phase0 + (double)n * inc);
 }
 
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
@@ -3769,6 +3820,63 @@ int pgx_blitsaw_biquad_wide(float *out, int64_t out_stride, int batch, int64_t n
         hipLaunchKernelGGL((k_blitsaw_biquad_wide<4, false>), dim3(batch), dim3(4 * 64), 0, pgx::stream(), out, out_stride,
                            n, saw_tables, saw_state, coef, biquad_tables, biquad_state, gain, gain_stride);
     PGX_LAUNCH_CHECK("k_blitsaw_biquad_wide");
+    return PGX_OK;
+}
+
+// The same chain in concurrent time segments, for banks too small to fill the chip with one workgroup per voice (a
+// rank's share of C5).  settle_frames: the filters' warm-up (biquad_pe.settle_frames: the largest of the bank; > 0).
+// States travel from the *_in buffers to the *_out buffers (two different buffers each).
+static int bbw_segment_tiles(int batch, int64_t n, int64_t settle_frames, int *warm_tiles_out) {
+    constexpr int64_t tile = 4 * 64 * kSswT;
+    const int64_t tiles = pgx::ceil_div(n, tile);
+    const int64_t warm = pgx::ceil_div(settle_frames, tile);
+    if (warm_tiles_out) *warm_tiles_out = (int)warm;
+    if (batch <= 0 || settle_frames <= 0 || batch > 256 || tiles < 3) return (int)tiles;
+    // enough workgroups for one per CU (a 4-wave workgroup alone on its CU renders a tile fastest), segments at
+    // least twice their warm-up; PGX_BBW_WGS: experiments
+    static const int wgs = getenv("PGX_BBW_WGS") ? atoi(getenv("PGX_BBW_WGS")) : pgx::kNumCU;
+    int64_t want = pgx::ceil_div(wgs, batch);
+    if (want < 1) want = 1;
+    int64_t seg = pgx::ceil_div(tiles, want);
+    if (seg < 2 * warm) seg = 2 * warm;
+    if (seg > tiles) seg = tiles;
+    return (int)seg;
+}
+
+int pgx_blitsaw_biquad_wide_segments(int batch, int64_t n, int64_t settle_frames) {
+    if (batch <= 0 || n <= 0) return 1;
+    constexpr int64_t tile = 4 * 64 * kSswT;
+    const int seg = bbw_segment_tiles(batch, n, settle_frames, nullptr);
+    return (int)pgx::ceil_div(pgx::ceil_div(n, tile), seg);
+}
+
+int pgx_blitsaw_biquad_wide_seg(float *out, int64_t out_stride, int batch, int64_t n, const double *saw_tables,
+                                const double *saw_state_in, double *saw_state_out, const double *coef,
+                                const double *biquad_tables, const double *biquad_state_in, double *biquad_state_out,
+                                const float *gain, int64_t gain_stride, int64_t settle_frames) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || batch <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && saw_tables && saw_state_in && saw_state_out && coef && biquad_tables && biquad_state_in &&
+                      biquad_state_out && saw_state_in != saw_state_out && biquad_state_in != biquad_state_out,
+                  "pgx_blitsaw_biquad_wide_seg: bad argument (states are read from one buffer and written to another)");
+    PGX_CHECK_ARG(settle_frames > 0, "pgx_blitsaw_biquad_wide_seg: the filters' settle_frames must be known (> 0)");
+    PGX_CHECK_ARG(batch == 1 || out_stride >= n, "pgx_blitsaw_biquad_wide_seg: out_stride too small");
+    PGX_CHECK_ARG(gain == nullptr || batch == 1 || gain_stride >= n, "pgx_blitsaw_biquad_wide_seg: gain_stride too small");
+    PGX_CHECK_ARG(batch <= 65535, "pgx_blitsaw_biquad_wide_seg: too many voices");
+    constexpr int64_t tile = 4 * 64 * kSswT;
+    int warm = 0;
+    const int seg = bbw_segment_tiles(batch, n, settle_frames, &warm);
+    const int nseg = (int)pgx::ceil_div(pgx::ceil_div(n, tile), seg);
+    double *s_in = const_cast<double *>(saw_state_in), *b_in = const_cast<double *>(biquad_state_in);
+    if (gain != nullptr)
+        hipLaunchKernelGGL((k_blitsaw_biquad_wide<4, true, true>), dim3(batch, nseg), dim3(4 * 64), 0, pgx::stream(), out,
+                           out_stride, n, saw_tables, s_in, coef, biquad_tables, b_in, gain, gain_stride, saw_state_out,
+                           biquad_state_out, seg, warm);
+    else
+        hipLaunchKernelGGL((k_blitsaw_biquad_wide<4, false, true>), dim3(batch, nseg), dim3(4 * 64), 0, pgx::stream(), out,
+                           out_stride, n, saw_tables, s_in, coef, biquad_tables, b_in, gain, gain_stride, saw_state_out,
+                           biquad_state_out, seg, warm);
+    PGX_LAUNCH_CHECK("k_blitsaw_biquad_wide<seg>");
     return PGX_OK;
 }
 

@@ -120,6 +120,8 @@ _SIGNATURES = [
     ("pgx_supersaw_sum", _I, [_P, _L, _I, _I, _L, _I, _P, _P, _P, _L]),
     ("pgx_blitsaw_biquad_bank", _I, [_P, _L, _I, _L, _D, _P, _P, _P, _P]),
     ("pgx_blitsaw_biquad_wide", _I, [_P, _L, _I, _L, _P, _P, _P, _P, _P, _P, _L]),
+    ("pgx_blitsaw_biquad_wide_segments", _I, [_I, _L, _L]),
+    ("pgx_blitsaw_biquad_wide_seg", _I, [_P, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L]),
     ("pgx_supersaw_bank", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P]),
     ("pgx_supersaw_bank_segments", _I, [_I, _L]),
     ("pgx_supersaw_bank_seg", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P, _P, _P]),

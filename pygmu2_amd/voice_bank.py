@@ -55,6 +55,8 @@ LADDER_WINDOW_FRAMES = int(os.environ.get("PGX_LADDER_WINDOW_FRAMES", str(1 << 2
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
+SEGMENTED_CHAIN = True       # ... and smaller banks (4 .. 256 voices: a rank's share of C5) as one launch in concurrent time
+                             # segments (pgx_blitsaw_biquad_wide_seg: closed-form oscillator carries, the filters warm up)
 PIPELINE_FULL_SUPERSAW_BANK = True    # ... and for a bank that fills the chip (512 instances: the 17 us mix beside the next block's bank)
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
 FUSE_GAIN_IN_CHAIN = False   # ... and multiplied into the voices by the oscillator -> filter kernel: measured, no gain (render_mix)
@@ -198,6 +200,7 @@ class _BlitSawNode(_Node):
         self.prepare(start)
         if self.state_alt is None:
             self.state_alt = DeviceBuffer(self.state.shape, self.state.dtype)
+        if self.unit_amp is None:
             self.unit_amp = DeviceBuffer.from_host(np.ones(self.k, dtype=np.float64))
         kind = "wide" if self.wide() else "bank"
         tables = self.tables.get(kind)
@@ -416,6 +419,7 @@ class _BiquadNode(_Node):
         self.settle = 0 if min(settles) == 0 else max(settles)
         self.tables = None           # per-voice powers of A (pgx_biquad_tables), made on first render
         self.state = None
+        self.state_alt = None        # (the time-segmented chain reads one buffer and writes the other)
         self.ws = None
 
     def reset(self):
@@ -426,14 +430,55 @@ class _BiquadNode(_Node):
     def channels(self):
         return self.children["source"].channels()
 
+    def _chain_segments(self, n: int) -> int:
+        """Time segments of the fused oscillator -> filter launch for a small bank, or 0: not that path."""
+        src = self.children["source"]
+        if not (SEGMENTED_CHAIN and isinstance(src, _BlitSawNode) and src.ch == 1 and 4 <= self.k <= 256
+                and src.wide() and src.closed_form_ok and self.settle > 0):
+            return 0
+        segs = lib().pgx_blitsaw_biquad_wide_segments(self.k, n, self.settle)
+        return segs if segs > 1 else 0
+
     def takes_gain(self) -> bool:
         """render(..., gain=<[K][n] float32>) multiplies the voices by it inside the chain's kernel."""
         src = self.children["source"]
         return isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= FUSED_VOICE_MIN and src.wide()
 
+    def _render_chain_segments(self, start, n, gain=None):
+        """A small bank (a rank's share of C5): oscillator -> filter as ONE launch in concurrent time segments instead of
+        the segmented oscillator bank followed by the batched settled biquad (two kernels and the dispatch gap between
+        them on the block's critical chain).  States are read from one buffer and written to another."""
+        L = lib()
+        src = self.children["source"]
+        if self.state is None:
+            self.state = DeviceBuffer((self.k, 1, 2), np.float64, zero=True)
+        if self.state_alt is None:
+            self.state_alt = DeviceBuffer(self.state.shape, np.float64)
+        if src.state_alt is None:
+            src.state_alt = DeviceBuffer(src.state.shape, src.state.dtype)
+        src.prepare(start)
+        saw_tables = src.tables.get("wide")
+        if saw_tables is None:
+            saw_tables = src.tables["wide"] = DeviceBuffer((L.pgx_supersaw_wide_table_bytes(self.k, 1),), np.uint8)
+            check(L.pgx_supersaw_wide_tables(saw_tables.ptr, self.k, 1, self.sr, src.params.ptr),
+                  "pgx_supersaw_wide_tables")
+        if self.tables is None:
+            self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
+            check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
+        out = DeviceBuffer((self.k, n, 1), np.float32)
+        check(L.pgx_blitsaw_biquad_wide_seg(out.ptr, n, self.k, n, saw_tables.ptr, src.state.ptr, src.state_alt.ptr,
+                                            self.coef.ptr, self.tables.ptr, self.state.ptr, self.state_alt.ptr,
+                                            ptr(gain), n, self.settle), "pgx_blitsaw_biquad_wide_seg")
+        src.state, src.state_alt = src.state_alt, src.state
+        self.state, self.state_alt = self.state_alt, self.state
+        src.last_end = start + n
+        return out
+
     def render(self, start, n, gain=None):
         L = lib()
         src = self.children["source"]
+        if self._chain_segments(n):
+            return self._render_chain_segments(start, n, gain)
         if isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= FUSED_VOICE_MIN:
             # oscillator -> filter without the [K][frames] oscillator buffer (pgx_blitsaw_biquad_bank)
             if self.state is None:

@@ -360,3 +360,42 @@ def test_oscillator_filter_chain_random_banks(monkeypatch, seed):
         assert a.shape == b.shape
         err = float(np.max(np.abs(a.astype(np.float64) - b)))
         assert err <= 2e-6 * peak, (s, n, err, peak, mode0)
+
+
+@pytest.mark.parametrize("count", [4, 17, 64, 200, 256])
+def test_small_bank_chain_in_time_segments(monkeypatch, count):
+    """pgx_blitsaw_biquad_wide_seg (round 4: a rank's share of C5): oscillator -> filter of a small bank as ONE launch in
+    concurrent time segments -- the oscillator's integrator level on entering a segment from its closed form, the
+    filter from a warm-up of settle_frames -- against the same bank without it (segmented oscillator bank + batched
+    settled biquad) and against the two-launch bank on k_blitsaw's own samples; states carried over blocks (read from
+    one buffer, written to the other), odd tails, a seek."""
+    from pygmu2_amd import voice_bank
+    from pygmu2_amd.biquad_pe import BiquadMode
+    rng = np.random.default_rng(9100 + count)
+    pg.set_sample_rate(48000)
+    mode = list(BiquadMode)[count % 3]
+    spec = [(float(np.exp(rng.uniform(np.log(25.0), np.log(6000.0)))),
+             float(np.exp(rng.uniform(np.log(300.0), np.log(12000.0)))), float(rng.uniform(0.5, 4.0)))
+            for _ in range(count)]
+
+    def make():
+        return pg.MixPE(*[pg.BiquadPE(pg.BlitSawPE(f), frequency=fc, q=q, mode=mode) for f, fc, q in spec])
+
+    blocks = [(0, 48_000), (48_000, 48_000), (96_000, 20_001), (116_001, 12_289), (400_000, 48_000), (448_000, 48_000)]
+    monkeypatch.setattr(voice_bank, "BANK_WINDOWS", False)
+    seg = make()
+    got = _render_blocks(seg, 48000, blocks)
+    node = seg._bank.root
+    assert isinstance(node, voice_bank._BiquadNode)
+    if count < 256:                                  # (256 voices: one workgroup per CU already -- a single segment)
+        assert node._chain_segments(48_000) > 1, "the segmented chain was expected"
+    monkeypatch.setattr(voice_bank, "SEGMENTED_CHAIN", False)
+    same = _render_blocks(make(), 48000, blocks)
+    monkeypatch.setattr(voice_bank, "FUSED_VOICE_MIN", 10 ** 9)
+    monkeypatch.setattr(voice_bank, "WIDE_SUPERSAW", False)
+    want = _render_blocks(make(), 48000, blocks)
+    peak = max(float(np.max(np.abs(b))) for b in want)
+    for (s, n), a, b, c in zip(blocks, got, same, want):
+        assert a.shape == c.shape
+        assert float(np.max(np.abs(a.astype(np.float64) - b))) <= 1e-6 * peak, (s, n, "against the two-kernel wide path")
+        assert float(np.max(np.abs(a.astype(np.float64) - c))) <= 2e-6 * peak, (s, n, "against the two-launch bank")
