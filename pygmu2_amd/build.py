@@ -65,9 +65,33 @@ def needs_build() -> bool:
     return _stale(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + _deps_common())
 
 
+FAST_SRC = os.path.join(CSRC, "_fast.c")
+FAST_LIB = os.path.join(PKG_DIR, "_fast.so")
+
+
+def build_fast(force: bool = False, verbose: bool = True) -> str | None:
+    """pygmu2_amd/_fast.so: the hot host paths (render()'s window exits, Snippet.__del__) as a CPython extension, built
+    with the C compiler against this interpreter's headers.  Host glue: the package runs without it."""
+    import sysconfig
+    if not force and not _stale(FAST_LIB, [FAST_SRC, os.path.abspath(__file__)]):
+        return FAST_LIB
+    include = sysconfig.get_paths()["include"]
+    if not os.path.exists(os.path.join(include, "Python.h")):
+        if verbose:
+            print("[pygmu2_amd.build] no Python.h: _fast.so not built (the Python paths are used)", flush=True)
+        return None
+    cc = os.environ.get("CC") or "gcc"
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-I" + include, FAST_SRC, "-o", FAST_LIB]
+    if verbose:
+        print("[pygmu2_amd.build]", " ".join(cmd[-3:]), flush=True)
+    subprocess.check_call(cmd)
+    return FAST_LIB
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source (one object per translation unit, in parallel, only the stale ones) and
     link pygmu2_amd/libpygmu_hip.so; returns its path."""
+    build_fast(force, verbose)
     if not force and not needs_build():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor

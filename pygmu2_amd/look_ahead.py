@@ -35,9 +35,10 @@ from . import read_ahead as _read_ahead
 
 SMALL_BLOCK = 1 << 20       # pulls up to this many frames are served from a look-ahead window
 FIRST_WINDOW_BLOCKS = 8     # the first window of a stream; every further one is WINDOW_GROWTH times longer, up to
-WINDOW_GROWTH = 2           # (8, 16, 32, 64: a stream that stops after k blocks has rendered < 2k + 8; with x8 a
+WINDOW_GROWTH = 2           # (8, 16, 32, 64, 128, 256: a stream that stops after k blocks has rendered < 2k + 8; with x8 a
                             # 20-block stream rendered 8 + 33 blocks)
-AHEAD_BLOCKS = 64           # ... at most this many blocks per window ...
+AHEAD_BLOCKS = int(os.environ.get("PGX_LOOK_AHEAD_BLOCKS", "256"))   # ... at most this many blocks per window (64 until round 4: the autowah
+                            # graphs in 1024-frame blocks 519 / 544 Msamples/s at 64, 548 / 568 at 128, 581 / 592 at 256) ...
 AHEAD_FRAMES = 1 << 25      # ... and about this many frames (1 M-frame pulls: 32 blocks per window, 128 MB per
                             # channel of every PE in it: C2 3.8 us per step at 2^24, 3.5 at 2^25, 3.3 at 2^26)
 

@@ -225,3 +225,25 @@ class ProcessingElement(ABC):
         if allow_multichannel:
             return np.full((duration, channels if channels is not None else 1), value, dtype=dtype)
         return np.full((duration,), value, dtype=dtype)
+
+
+# ---------------------------------------------------------------------------------------------- hot paths in C
+def _install_fast_paths() -> bool:
+    """ProcessingElement.render's two hot exits (the next block of a stream served from a resident window) and
+    Snippet.__del__ as C method descriptors (csrc/_fast.c, built by pygmu2_amd.build): the same semantics at a third of
+    the interpreter time per small block.  Everything else still runs the Python functions above, and so does every
+    pull when the module has not been built (PYGMU_FAST=0 switches it off)."""
+    import os
+    if os.environ.get("PYGMU_FAST", "1").strip().lower() in ("0", "false", "no", "off"):
+        return False
+    try:
+        from . import _fast
+    except ImportError:
+        return False
+    from . import snippet as _snippet
+    _fast.install(ProcessingElement, Snippet, _look_ahead._Window, ProcessingElement.__dict__["render"],
+                  _snippet.Snippet.__dict__["__del__"], vars(_diag))
+    return True
+
+
+FAST_PATHS = _install_fast_paths()

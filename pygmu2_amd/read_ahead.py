@@ -25,7 +25,9 @@ import threading
 SMALL_BLOCK = 1 << 20       # requests up to this many frames are served from a resident window
 FIRST_WINDOW_BLOCKS = 8     # the first refill of a stream; every further one is WINDOW_GROWTH times longer, up to
 WINDOW_GROWTH = 8
-AHEAD_BLOCKS = 64           # ... at most this many blocks per refill ...
+AHEAD_BLOCKS = int(os.environ.get("PGX_READ_AHEAD_BLOCKS", "4096"))   # ... at most this many blocks per refill (8, 64, 512, 4096: with a
+                            # served block at 0.1 - 0.2 us of host time -- csrc/_fast.c -- a refill per 64 blocks was half of
+                            # what a 1024-frame block of C1 cost; a pure window costs HBM-rate rendering and its memory) ...
 AHEAD_FRAMES = 1 << 25      # ... and about this many frames (128 MB per channel: a 44 100-frame pull refills 64
                             # blocks at a time, a 1 M-frame pull 32: launches of that size leave the ~4 us floor
                             # of a launch behind and stream at HBM rate)

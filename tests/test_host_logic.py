@@ -413,12 +413,12 @@ def test_comb_scalar_delay_follows_the_reference_expression():
 
 def test_look_ahead_windows_double():
     from pygmu2_amd import look_ahead
-    assert look_ahead.FIRST_WINDOW_BLOCKS == 8 and look_ahead.WINDOW_GROWTH == 2 and look_ahead.AHEAD_BLOCKS == 64
+    assert look_ahead.FIRST_WINDOW_BLOCKS == 8 and look_ahead.WINDOW_GROWTH == 2 and look_ahead.AHEAD_BLOCKS == 256
     sizes, grow = [], look_ahead.FIRST_WINDOW_BLOCKS
-    for _ in range(5):
+    for _ in range(7):
         sizes.append(min(grow, look_ahead.AHEAD_BLOCKS))
         grow *= look_ahead.WINDOW_GROWTH
-    assert sizes == [8, 16, 32, 64, 64]
+    assert sizes == [8, 16, 32, 64, 128, 256, 256]
     # a 20-block stream (the driver's bench run): one plain block, then windows of 8 and 16 -> 25 rendered, not 42
     assert 1 + sizes[0] + sizes[1] == 25
 
