@@ -459,14 +459,16 @@ int pgx_supersaw_wide(float *out, int64_t out_stride, int batch, int nvoices, in
  * locks to its input although the linearised loop does not decay; the caller reads the counters below and moves to
  * a longer warm-up or to W = 0 when chains fall back): the block is cut into segments that each start W samples
  * early from a zero state; the library verifies every segment against its left neighbour's final
- * state (1e-8 relative) and re-renders a chain sequentially when the check fails, so W affects
- * speed, never results beyond that bound.  accurate_frames = A (0 < A < W): only the last A warm-up samples
+ * state (1e-8 relative) and REPAIRS what disagrees -- the segment behind a bad boundary is rendered again from its
+ * neighbour's exit state, sample by sample in the reference's operation order, and so are its successors until the
+ * repaired trajectory meets a segment's own entry state again (a chain that disagrees from its first boundary on is
+ * the sequential render, bit for bit) -- so W affects speed, never results beyond that bound.  accurate_frames = A (0 < A < W): only the last A warm-up samples
  * of a segment evaluate tanh in float64; the W - A before them, which merely have to forget the zero start,
  * use the float32 exponential unit (state error ~1e-7, contracted by the accurate tail; 0 or >= W: all of the
  * warm-up is accurate).  Warm-ups run on fused multiply-adds; emitted samples keep the reference's operation
  * order.  workspace: pgx_ladder_workspace_bytes(...) bytes
- * (NULL when 0).  Its first 16 bytes are counters, cumulative since the caller zeroed them: int32[0] chains that
- * fell back to the sequential re-render, int32[1] segmented launches (the position does not depend on n). */
+ * (NULL when 0).  Its first 16 bytes are counters, cumulative since the caller zeroed them: int32[0] chains with a
+ * repair, int32[1] segmented launches, int64[1] samples repaired (the position does not depend on n). */
 typedef struct {
     double freq;
     double resonance;

@@ -476,8 +476,17 @@ k_ladder_segments(float *out, int64_t out_stride, const float *in, int64_t in_st
     ladder_store(ends + ((int64_t)chain * nseg + seg) * 9, s);
 }
 
-// One wave per chain: check every warm-started segment against its left neighbour; commit the new
-// state, or re-render the chain sequentially from the carried state.
+// One wave per chain: check every warm-started segment against its left neighbour and REPAIR what disagrees.
+// A segment whose entry state (from its warm-up) is not the state its left neighbour ended in is rendered again from
+// that true state, sample by sample in the reference's operation order, and so is every segment after it until the
+// repaired trajectory meets a segment's own entry state again (the ladder re-synchronised: everything that segment and
+// its successors emitted stands).  Until round 4 ONE bad boundary re-rendered the whole chain from the block start:
+// right, but a look-ahead window of 2.8 M frames has 48 000 boundaries, and with a warm-up found by trial (resonance at
+// and above self-oscillation, a beating input) one of them fails now and then -- 1.5 s of one lane for 60 samples'
+// worth of disagreement.  The repair costs what it repairs.  A ladder that runs free beside its input fails every
+// boundary and is repaired from the first to the last: the sequential render, as before, bit for bit k_ladder.
+// counters: [0] chains with a repair (int32), [1] segmented launches (int32), [2..3] samples repaired (int64): all
+// cumulative since the workspace was zeroed (ladder_pe.SettleOptimist reads them).
 __global__ void __launch_bounds__(64)
 k_ladder_finish(float *out, int64_t out_stride, const float *in, int64_t in_stride, int64_t n, int channels,
                 double sr, const pgx_ladder_params *params, const float *freq, const float *resonance,
@@ -485,32 +494,75 @@ k_ladder_finish(float *out, int64_t out_stride, const float *in, int64_t in_stri
                 const double *warm, const double *ends, int *fallbacks) {
     const int chain = blockIdx.x, lane = threadIdx.x;
     if (lane == 0 && chain == 0 && fallbacks) atomicAdd(fallbacks + 1, 1);
-    bool bad = false;
-    for (int seg = 1 + lane; seg < nseg; seg += 64) {
-        const double *a = warm + ((int64_t)chain * nseg + seg) * 9;
-        const double *b = ends + ((int64_t)chain * nseg + seg - 1) * 9;
+    const double *cw = warm + (int64_t)chain * nseg * 9, *ce = ends + (int64_t)chain * nseg * 9;
+    auto differs = [](const double *a, const double *b) {
+        bool bad = false;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const double d = fabs(a[j] - b[j]);
             const double m = fmax(fabs(a[j]), fabs(b[j]));
             if (!(d <= 1e-10 + 1e-8 * m)) bad = true;            // also catches NaN
         }
+        return bad;
+    };
+    const int inst = chain / channels, ch = chain - inst * channels;
+    const LadderConsts c = ladder_consts(params[inst], sr, channels, ch, in + (int64_t)inst * in_stride,
+                                         out + (int64_t)inst * out_stride, freq, resonance, drive);
+    LadderState cur{};                                           // lane 0: the true state while a repair is under way
+    int repairing = 0;
+    long long repaired = 0;
+    for (int base = 1; base < nseg; base += 64) {
+        const int seg = base + lane;
+        const bool bad = seg < nseg && differs(cw + (int64_t)seg * 9, ce + (int64_t)(seg - 1) * 9);
+        const unsigned long long mask = __ballot(bad);
+        if (mask == 0ull && !repairing) continue;                // (wave-uniform)
+        if (lane == 0) {
+            for (int b = 0; b < 64 && base + b < nseg; ++b) {
+                const int sg = base + b;
+                if (repairing) {
+                    double now[9];
+                    ladder_store(now, cur);
+                    if (!differs(now, cw + (int64_t)sg * 9)) {   // re-synchronised: segment sg's own samples stand
+                        repairing = 0;
+                        continue;
+                    }
+                } else if ((mask >> b) & 1ull) {
+                    if (sg == 1) {
+                        // the very first boundary: segment 0 is rendered again too, from the carried state, so that a
+                        // chain that fails throughout (a free-running ladder) is the sequential render from its first
+                        // sample on, bit for bit (a segment's own samples are on the fused arithmetic otherwise)
+                        cur = ladder_load(state + (int64_t)chain * 9);
+                        const int64_t e0 = seg_len < n ? seg_len : n;
+                        ladder_advance(c, cur, 0, 0, e0);
+                        repaired += e0;
+                    } else {
+                        cur = ladder_load(ce + (int64_t)(sg - 1) * 9);   // its left neighbour's exit: the true trajectory
+                    }
+                    repairing = 1;
+                } else {
+                    continue;
+                }
+                const int64_t sb = (int64_t)sg * seg_len;
+                int64_t se = sb + seg_len;
+                if (se > n) se = n;
+                ladder_advance(c, cur, sb, sb, se);               // the reference's operation order, samples rewritten
+                repaired += se - sb;
+            }
+        }
+        repairing = __shfl(repairing, 0);
     }
-    bad = __any(bad);
     double *st = state + (int64_t)chain * 9;
-    if (!bad) {
-        if (lane < 9) st[lane] = ends[((int64_t)chain * nseg + nseg - 1) * 9 + lane];
-        return;
-    }
     if (lane == 0) {
-        const int inst = chain / channels, ch = chain - inst * channels;
-        const LadderConsts c = ladder_consts(params[inst], sr, channels, ch, in + (int64_t)inst * in_stride,
-                                             out + (int64_t)inst * out_stride, freq, resonance, drive);
-        LadderState s = ladder_load(st);
-        ladder_advance(c, s, 0, 0, n);
-        ladder_store(st, s);
-        if (fallbacks) atomicAdd(fallbacks, 1);
+        if (repairing) ladder_store(st, cur);                    // repaired through the last segment
+        if (repaired) {
+            if (fallbacks) {
+                atomicAdd(fallbacks, 1);
+                atomicAdd(reinterpret_cast<unsigned long long *>(fallbacks) + 1, (unsigned long long)repaired);
+            }
+        }
     }
+    repairing = __shfl(repairing, 0);
+    if (!repairing && lane < 9) st[lane] = ce[(int64_t)(nseg - 1) * 9 + lane];
 }
 
 }  // namespace

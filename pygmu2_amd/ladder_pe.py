@@ -26,10 +26,10 @@ ACCURATE_TAIL_FACTOR = 4e-4
 # example is there: examples/17_ladder_filter.py:43, res 0.6) and for loops that decay too slowly, ladder_settle_frames has
 # no answer.  The device verifies every time segment against its neighbour and re-renders a chain sequentially when one
 # disagrees, so a warm-up length only has to be TRIED (SettleOptimist): these, in turn.
-OPTIMISTIC_SETTLES = (2048, 8192, 32768)
+OPTIMISTIC_SETTLES = (2048, 4096, 8192, 16384, 32768)
 OPTIMISTIC_RETRY = 64                 # renders on the sequential kernel after every length failed, then the longest again
 OPTIMISTIC = True
-STATS = {"segmented": 0, "sequential": 0, "fallback_chains": 0, "escalations": 0, "gave_up": 0}
+STATS = {"segmented": 0, "sequential": 0, "fallback_chains": 0, "repaired_samples": 0, "escalations": 0, "gave_up": 0}
 SEGMENT_STREAM_LADDER = True          # PE-driven cutoff / resonance: time segments too (warm-up from the block's range)
 STREAM_SEGMENT_MIN_FRAMES = 8192      # shorter blocks stay on the sequential kernel (the range costs a read-back)
 
@@ -114,7 +114,8 @@ class SettleOptimist:
         self.level = 0
         self.sleep = 0
         self.retry = OPTIMISTIC_RETRY
-        self.seen = 0                  # the counter's value so far
+        self.seen = 0                  # the counters' values so far: chains with a repair, samples repaired
+        self.seen_repaired = 0
         self.pending = []              # (ticket, pinned view, level, workspace kept alive)
         self.good = 0                  # verified renders in a row at this level
 
@@ -131,32 +132,41 @@ class SettleOptimist:
         w = OPTIMISTIC_SETTLES[self.level]
         return w, w // 2               # (the float32-tanh half leaves ~1e-7, the accurate half contracts it)
 
-    def launched(self, workspace, level_settle: int) -> None:
+    def launched(self, workspace, level_settle: int, frames: int = 0, chains: int = 1) -> None:
         """A segmented render with this warm-up has been enqueued: its verdict is read back without waiting."""
         STATS["segmented"] += 1
-        view, ticket = workspace.rows(0, 8).begin_to_host()
-        self.pending.append((ticket, view, level_settle, workspace))
+        view, ticket = workspace.rows(0, 16).begin_to_host()
+        self.pending.append((ticket, view, level_settle, workspace, int(frames), max(1, int(chains))))
 
     def poll(self, wait: bool = False, only_first: bool = False) -> None:
         first = True
         while self.pending and (first or not only_first):
             first = False
-            ticket, view, settle, _ws = self.pending[0]
+            ticket, view, settle, _ws, frames, chains = self.pending[0]
             if wait:
                 _dev.wait_to_host(ticket)
             elif not _dev.host_copy_done(ticket):
                 return
             self.pending.pop(0)
             count = int(view.view(np.int32)[0])
+            repaired = int(view.view(np.int64)[1])
             if count > self.seen:
                 STATS["fallback_chains"] += count - self.seen
                 self.seen = count
+            redone, self.seen_repaired = repaired - self.seen_repaired, repaired
+            STATS["repaired_samples"] += redone
+            # The device repairs what disagrees (k_ladder_finish: from the first bad boundary until the trajectory
+            # meets a segment's own entry state again), one lane per chain at ~0.5 us per sample; a lane's warm-up is
+            # ~0.18 us per sample.  A longer warm-up pays when the repairs of a launch cost more than the warm-up does.
+            if redone * 3 > settle * max(1, chains // 4):
                 self.good = 0
                 if self.sleep == 0 and settle == OPTIMISTIC_SETTLES[self.level]:     # (not escalated since)
                     if self.level + 1 < len(OPTIMISTIC_SETTLES):
                         self.level += 1
                         STATS["escalations"] += 1
-                    else:
+                    elif frames and redone * 2 > frames * chains:
+                        # the longest warm-up, and still most of the render was repaired: a ladder that runs free
+                        # beside its input.  The sequential kernel for a while, then the longest length again.
                         self.sleep = self.retry
                         self.retry = min(self.retry * 2, 1024)
                         STATS["gave_up"] += 1
@@ -282,7 +292,7 @@ class LadderPE(ProcessingElement):
                            self._params.ptr, ptr(f_buf), ptr(r_buf), ptr(d_buf), self._state.ptr, settle,
                            accurate, ptr(self._workspace) if need else None), "pgx_ladder")
         if trial and need:
-            self._optimist.launched(self._workspace, settle)
+            self._optimist.launched(self._workspace, settle, duration, ch)
         elif not need:
             STATS["sequential"] += 1
         return Snippet(start, out)

@@ -662,7 +662,7 @@ class _LadderNode(_Node):
                                None, None, None, self.state.ptr, settle, accurate,
                                ptr(self.ws) if need else None), "pgx_ladder")
             if self.optimist is not None and need and settle:
-                self.optimist.launched(self.ws, settle)
+                self.optimist.launched(self.ws, settle, n, self.k * ch)
 
         speculate = (PREFETCH_LADDER_INPUT and isinstance(src, (_SuperSawNode, _BlitSawNode)) and n >= 4096
                      and not L.pgx_stream_is_forked())
