@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Markdown tables for DESIGN.md section 7 from the committed bench line (profiles/r3_bench.json) and the round-2
-line beside it: python tools/design_tables_r3.py > /tmp/tables.md"""
+"""Markdown tables for DESIGN.md section 7 from a committed bench line and the previous round's beside it:
+python tools/design_tables_r3.py [profiles/r4_bench.json [profiles/r3_bench.json]] > /tmp/tables.md"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.load(open(os.path.join(ROOT, "profiles", "r3_bench.json")))
-o = json.load(open(os.path.join(ROOT, "profiles", "r2_bench.json")))
+new = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r3_bench.json")
+old = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r2_bench.json" if "r3" in new else "r3_bench.json")
+d = json.load(open(new))
+o = json.load(open(old))
 
 
 def n(v, digits=0):
@@ -12,7 +14,7 @@ def n(v, digits=0):
 
 
 print("### benchmark_pes.py suite (44 100-frame renders, 5 + 50): Msamples/s\n")
-print("| config | sync | pipelined | block by block | CPU oracle | pipelined / CPU | round 2 pipelined |")
+print("| config | sync | pipelined | block by block | CPU oracle | pipelined / CPU | previous round, pipelined |")
 print("|---|---|---|---|---|---|---|")
 for name, row in d["suite"]["rows"].items():
     old = o["suite"]["rows"].get(name, {})

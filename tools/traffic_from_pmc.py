@@ -88,6 +88,8 @@ md.append("")
 f, w = table("c3_FETCH_SIZE"), table("c3_WRITE_SIZE")
 shapes = [("96 000 frames, stereo (2 packed transforms)", 96000, 65536), ("65 537 frames, stereo (one shared transform)", 65537, 32768),
           ("1 440 000 frames (22 packed transforms)", 1440000, 720896)]
+if tag >= "r4":        # renders of three hops and more take the 2^18-point transform (convolve_pe.device_fft_size)
+    shapes[2] = ("1 440 000 frames (8 blocks of 196 609 frames, N = 262 144: 4 packed transforms)", 1440000, 262144)
 md += ["## C3: `pgx_convolve_fft`, 65 536 taps, N = 131 072 (three launches per call)", "",
        "| shape | FETCH_SIZE KiB (three kernels, raw) | WRITE_SIZE KiB | traffic MB (reads x2: upper bound) | algorithmic MB (16 B/frame) | ratio |",
        "|---|---|---|---|---|---|"]
