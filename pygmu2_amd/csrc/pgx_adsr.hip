@@ -60,8 +60,8 @@ constexpr int kEdgeRun = 24;          // consecutive chunks of one voice per wav
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_adsr_edges(unsigned long long *masks, unsigned long long *group_bits, float *last_gate, const float *ctl,
-             int64_t ctl_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
-             const pgx_gate_params *gates, const double *state) {
+             int64_t ctl_stride, int batch, int64_t start_arg, int64_t n, int64_t nchunks, int64_t gwords,
+             const pgx_gate_params *gates, const double *state, int64_t start_stride = 0) {
     const int lane = threadIdx.x & 63;
     // one wave = kEdgeRun consecutive chunks of one voice: the voice's parameters are loaded once and
     // the gate value at the end of a chunk is the "previous sample" of the next one
@@ -73,7 +73,10 @@ k_adsr_edges(unsigned long long *masks, unsigned long long *group_bits, float *l
     const int64_t c1 = (c0 + kEdgeRun < nchunks) ? c0 + kEdgeRun : nchunks;
     const float *g = (MODE == 2) ? nullptr : ctl + (int64_t)inst * ctl_stride;
     pgx_gate_params gp{0.0, 0.0, 0.0};
-    if (MODE == 2) gp = gates[inst];
+    // start_stride != 0: the batch is ONE envelope's consecutive chunks (adsr_run_chunks): instance i is the stretch
+    // that starts i * start_stride frames into the render, and all instances share the first gate's parameters
+    if (MODE == 2) gp = gates[start_stride ? 0 : inst];
+    const int64_t start = start_arg + (int64_t)inst * start_stride;
     // A periodic gate whose high and low phases both last 65 samples or more changes at most once inside
     // a 64-sample chunk, so "value before the chunk == value at its last sample" means the chunk has no
     // edge: one evaluation per chunk instead of 64 (the common case by a wide margin).
@@ -137,15 +140,16 @@ k_adsr_edges(unsigned long long *masks, unsigned long long *group_bits, float *l
 // that is not sparse has its 64 chunks expanded in turn.
 __global__ void __launch_bounds__(256)
 k_adsr_edges_sparse(unsigned long long *masks, unsigned long long *group_bits, float *last_gate, int batch,
-                    int64_t start, int64_t n, int64_t nchunks, int64_t gwords, const pgx_gate_params *gates,
-                    const double *state) {
+                    int64_t start_arg, int64_t n, int64_t nchunks, int64_t gwords, const pgx_gate_params *gates,
+                    const double *state, int64_t start_stride = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t groups_per_voice = (nchunks + 63) / 64;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (int64_t)batch * groups_per_voice) return;
     const int inst = (int)(w / groups_per_voice);
     const int64_t c0 = (w - (int64_t)inst * groups_per_voice) * 64;
-    const pgx_gate_params gp = gates[inst];
+    const pgx_gate_params gp = gates[start_stride ? 0 : inst];      // (start_stride: see k_adsr_edges)
+    const int64_t start = start_arg + (int64_t)inst * start_stride;
     // A wave's 64 chunks are 8 groups of kGroupChunks = one BYTE of the voice's group bitmap, which the wave alone
     // writes: a plain store, no atomics, and the bitmap needs no clearing launch in front of this kernel (4.7 us + a
     // dispatch gap on C5's envelope chain).  The voice's last wave clears the padding bytes of the last word.
@@ -513,7 +517,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_t n, int64_t nchunks, int64_t gwords,
                 const pgx_adsr_params *params, const unsigned long long *masks,
                 const unsigned long long *group_bits, const float *last_gate, const double *state,
-                double *state_out) {
+                double *state_out, int shared_params = 0, const int *skip_if_zero = nullptr) {
+    if (skip_if_zero && *skip_if_zero == 0) return;              // (adsr_run_chunks: a round nobody needs any more)
     __shared__ int e_pos[WAVES][kParMaxGroups + 2];
     __shared__ unsigned char e_att[WAVES][kParMaxGroups + 2];
     const int lane = threadIdx.x & 63;
@@ -522,7 +527,7 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
     if (state_out == state) __builtin_amdgcn_s_setprio(3);
     const int j = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int inst = blockIdx.x;
-    const pgx_adsr_params p = params[inst];
+    const pgx_adsr_params p = params[shared_params ? 0 : inst];  // (the batch is one envelope's chunks: adsr_run_chunks)
     float *o = out + (int64_t)inst * out_stride;
     const double *st = state + (int64_t)inst * 3;
     double *sto = state_out + (int64_t)inst * 3;
@@ -913,7 +918,10 @@ AdsrWs adsr_ws(void *workspace, int batch, int64_t n) {
 template <int MODE>
 int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_stride, int batch, int64_t start,
                 int64_t n, const pgx_gate_params *gates, const pgx_adsr_params *params, double *state,
-                void *workspace, bool detach_walk = false, double *state_out = nullptr) {
+                void *workspace, bool detach_walk = false, double *state_out = nullptr, int64_t chunk_stride = 0,
+                const int *skip_if_zero = nullptr) {
+    // chunk_stride != 0 (adsr_run_chunks): the `batch` instances are consecutive chunks of ONE envelope -- instance i
+    // starts i * chunk_stride frames into the render, all share gates[0] / params[0]; walk_par only
     if (state_out == nullptr) state_out = state;                // in place
     AdsrWs w = adsr_ws(workspace, batch, n);
     if (MODE != 2)                                              // (k_adsr_edges_sparse writes every byte of the bitmap itself)
@@ -922,13 +930,13 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
         const int64_t edge_waves = (int64_t)batch * pgx::ceil_div(w.nchunks, 64);
         hipLaunchKernelGGL(k_adsr_edges_sparse, dim3((unsigned)pgx::ceil_div(edge_waves, 4)), dim3(256), 0,
                            pgx::stream(), w.masks, w.group_bits, w.last_gate, batch, start, n, w.nchunks, w.gwords,
-                           gates, (const double *)state);
+                           gates, (const double *)state, chunk_stride);
         PGX_LAUNCH_CHECK("k_adsr_edges_sparse");
     } else {
         const int64_t edge_waves = (int64_t)batch * pgx::ceil_div(w.nchunks, kEdgeRun);
         hipLaunchKernelGGL(k_adsr_edges<MODE>, dim3((unsigned)pgx::ceil_div(edge_waves, 4)), dim3(256), 0,
                            pgx::stream(), w.masks, w.group_bits, w.last_gate, ctl, ctl_stride, batch, start, n,
-                           w.nchunks, w.gwords, gates, (const double *)state);
+                           w.nchunks, w.gwords, gates, (const double *)state, chunk_stride);
         PGX_LAUNCH_CHECK("k_adsr_edges");
     }
     if (detach_walk) {
@@ -943,11 +951,13 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
     // with that kernel at 80 us the walk is the critical path: 0.172 -> 0.142 ms.  256 envelopes -- a rank's share at two
     // ranks -- 146 -> 122 us; a rank's 64: walk 100 -> 60 us)
     static const int par_max_batch = getenv("PGX_ADSR_PAR_MAX_BATCH") ? atoi(getenv("PGX_ADSR_PAR_MAX_BATCH")) : kParWalkBatch;
-    if (MODE != 1 && par_on && batch <= par_max_batch && pgx::ceil_div(w.nchunks, kGroupChunks) <= kParMaxGroups)
+    if (MODE != 1 && (par_on || chunk_stride) && batch <= par_max_batch &&
+        pgx::ceil_div(w.nchunks, kGroupChunks) <= kParMaxGroups)
         hipLaunchKernelGGL(k_adsr_walk_par<kParWaves>, dim3(batch), dim3(kParWaves * 64), 0, pgx::stream(), out,
                            out_stride, batch, start, n, w.nchunks, w.gwords, params,
                            (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
-                           (const float *)w.last_gate, (const double *)state, state_out);
+                           (const float *)w.last_gate, (const double *)state, state_out, chunk_stride ? 1 : 0,
+                           skip_if_zero);
     else if (batch <= kWideWalkBatch)
         hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 4>), dim3(batch), dim3(256), 0, pgx::stream(), out, out_stride,
                            batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
@@ -966,16 +976,137 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
 // Blocks longer than the 65 536 frames k_adsr_walk_par covers (look-ahead windows of a lone envelope: up to 64 x 44 100
 // frames) are walked chunk after chunk by it -- the result does not depend on the partition -- instead of in one piece by
 // k_adsr_walk's single chain: a 2.8 M-frame window 1.6 ms -> 43 chunks.  PGX_ADSR_CHUNK=0: one piece.
+// ---- a lone envelope over a window of many chunks: all chunks at once (round 4) ----
+// Walked chunk after chunk a 64-block look-ahead window of a lone AdsrGatedPE is 43 x (edge search + walk) one behind the
+// other: 1.4 ms, and the stand-alone envelope rows sat at 10 - 14x the CPU however long the window.  But an envelope
+// forgets: every completed attack pins (DECAY, 1.0), so the state a chunk ENDS in does not depend on the state it began in
+// as soon as it holds one completed attack.  The chunks are therefore walked as a batch -- instance c = chunk c, the same
+// kernels -- in rounds: round 0 starts every chunk from the carried state (wrong for all but chunk 0, yet its exit states
+// are right wherever a chunk holds a pin), round 1 starts chunk c from chunk c - 1's exit of round 0.  If the exits of
+// round 1 equal those of round 0 bit for bit the entries used were the true ones (a fixed point of the chain is the
+// chain: entry 0 is exact, entry c + 1 is chunk c's exit from entry c) and every sample written in round 1 is the
+// sequential walk's; else a third round, then the verdict is read on the host (one 4-byte read-back per window) and a
+// render that has not settled takes the chunk-after-chunk loop from the untouched carried state.  entries[r][c]: (C + 1) x 3
+// doubles per round parity, entries[.][0] = the carried state, a round's walk writes its exits at entries[next] + 3.
+__global__ void __launch_bounds__(64)
+k_adsr_chunk_entries(double *a0, double *a1, const double *carried, int chunks) {
+    for (int i = threadIdx.x; i < (chunks + 1) * 3; i += 64) a0[i] = carried[i % 3];
+    if (threadIdx.x < 3) a1[threadIdx.x] = carried[threadIdx.x];
+}
+
+// flag = 1 when the exits of two rounds differ anywhere (bitwise), else 0
+__global__ void __launch_bounds__(64)
+k_adsr_chunk_verify(const double *x, const double *y, int chunks, int *flag) {
+    bool differ = false;
+    for (int i = threadIdx.x; i < chunks * 3; i += 64)
+        differ = differ || __double_as_longlong(x[3 + i]) != __double_as_longlong(y[3 + i]);
+    const bool any = __any(differ);
+    if (threadIdx.x == 0) *flag = any ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(64)
+k_adsr_chunk_commit(double *state_out, const double *exits_last, const int *flag) {
+    if (*flag == 0 && threadIdx.x < 3) state_out[threadIdx.x] = exits_last[threadIdx.x];
+}
+
+struct AdsrChunkWs {
+    double *a0, *a1;
+    int *flag;
+};
+
+size_t adsr_chunk_ws_bytes(int64_t chunks, int64_t chunk_frames) {
+    const int64_t nchunks = pgx::ceil_div(chunk_frames, 64);
+    const int64_t gwords = pgx::ceil_div(pgx::ceil_div(nchunks, kGroupChunks), 64);
+    return (size_t)chunks * (nchunks * 2 + gwords) * sizeof(unsigned long long) + (size_t)chunks * sizeof(float) + 64 +
+           (size_t)2 * (chunks + 1) * 3 * sizeof(double) + 64;
+}
+
+AdsrChunkWs adsr_chunk_ws(void *workspace, int64_t chunks, int64_t chunk_frames) {
+    const AdsrWs w = adsr_ws(workspace, (int)chunks, chunk_frames);
+    uintptr_t p = (uintptr_t)(w.last_gate + chunks);
+    p = (p + 15) & ~(uintptr_t)15;
+    AdsrChunkWs c;
+    c.a0 = (double *)p;
+    c.a1 = c.a0 + (chunks + 1) * 3;
+    c.flag = (int *)(c.a1 + (chunks + 1) * 3);
+    return c;
+}
+
+template <int MODE>
+int adsr_run_chunks(float *out, const float *ctl, int64_t start, int64_t n, const pgx_gate_params *gates,
+                    const pgx_adsr_params *params, double *state, void *workspace, double *state_out, bool *settled) {
+    constexpr int64_t kParFrames = (int64_t)kParMaxGroups * kGroupChunks * 64;
+    const int64_t chunks = n / kParFrames;                     // (full chunks; the caller walks what is left)
+    const AdsrChunkWs c = adsr_chunk_ws(workspace, chunks, kParFrames);
+    hipLaunchKernelGGL(k_adsr_chunk_entries, dim3(1), dim3(64), 0, pgx::stream(), c.a0, c.a1, (const double *)state,
+                       (int)chunks);
+    PGX_LAUNCH_CHECK("k_adsr_chunk_entries");
+    double *in = c.a0, *nxt = c.a1;
+    for (int round = 0; round < 3; ++round) {
+        // (round 2 runs only if the exits of rounds 0 and 1 differ: its kernels look at the flag first)
+        if (int rc = adsr_launch<MODE>(out, kParFrames, ctl, kParFrames, (int)chunks, start, kParFrames, gates, params, in,
+                                       workspace, false, nxt + 3, kParFrames, round == 2 ? c.flag : nullptr))
+            return rc;
+        if (round >= 1) {
+            // exits of this round (in nxt) against the previous round's (in `in`); after round 2 a second verdict
+            if (round == 1) {
+                hipLaunchKernelGGL(k_adsr_chunk_verify, dim3(1), dim3(64), 0, pgx::stream(), (const double *)nxt,
+                                   (const double *)in, (int)chunks, c.flag);
+                PGX_LAUNCH_CHECK("k_adsr_chunk_verify");
+            }
+        }
+        double *t = in;
+        in = nxt;
+        nxt = t;
+    }
+    // after the loop: `in` holds round 2's exits if it ran, else it was skipped and `nxt` (round 1's) are the last valid
+    // ones.  Host verdict: round 1 settled (flag 0) -> exits of round 1; else compare rounds 2 and 1 on the host side
+    // of the same read-back.
+    int flag_host = 1;
+    PGX_HIP(hipMemcpyAsync(&flag_host, c.flag, sizeof(int), hipMemcpyDeviceToHost, pgx::stream()));
+    PGX_HIP(hipStreamSynchronize(pgx::stream()));
+    double *exits = nxt;                                       // round 1's exits (the buffer round 2 read its entries from)
+    if (flag_host != 0) {
+        // round 2 ran: settled if its exits equal round 1's
+        hipLaunchKernelGGL(k_adsr_chunk_verify, dim3(1), dim3(64), 0, pgx::stream(), (const double *)in,
+                           (const double *)nxt, (int)chunks, c.flag);
+        PGX_LAUNCH_CHECK("k_adsr_chunk_verify");
+        PGX_HIP(hipMemcpyAsync(&flag_host, c.flag, sizeof(int), hipMemcpyDeviceToHost, pgx::stream()));
+        PGX_HIP(hipStreamSynchronize(pgx::stream()));
+        exits = in;
+    }
+    *settled = flag_host == 0;
+    if (*settled) PGX_HIP(hipMemcpyAsync(state_out, exits + chunks * 3, 3 * sizeof(double), hipMemcpyDeviceToDevice,
+                                         pgx::stream()));
+    return PGX_OK;
+}
+
+// Blocks longer than the 65 536 frames k_adsr_walk_par covers (look-ahead windows of a lone envelope: up to 256 x 44 100
+// frames) are walked chunk by chunk by it -- the result does not depend on the partition -- instead of in one piece by
+// k_adsr_walk's single chain: all chunks at once for a lone envelope (adsr_run_chunks, which waits for its verdict: one
+// device wait per window), else one after the other.  PGX_ADSR_CHUNK=0: one piece; PGX_ADSR_CHUNK_PAR=0: one after the other.
 template <int MODE>
 int adsr_run(float *out, int64_t out_stride, const float *ctl, int64_t ctl_stride, int batch, int64_t start, int64_t n,
              const pgx_gate_params *gates, const pgx_adsr_params *params, double *state, void *workspace,
              bool detach_walk = false, double *state_out = nullptr) {
     constexpr int64_t kParFrames = (int64_t)kParMaxGroups * kGroupChunks * 64;
     static const bool chunk_on = !(getenv("PGX_ADSR_CHUNK") && atoi(getenv("PGX_ADSR_CHUNK")) == 0);
+    static const bool chunk_par = !(getenv("PGX_ADSR_CHUNK_PAR") && atoi(getenv("PGX_ADSR_CHUNK_PAR")) == 0);
     if (MODE == 1 || !chunk_on || batch > kParWalkBatch || n <= kParFrames)
         return adsr_launch<MODE>(out, out_stride, ctl, ctl_stride, batch, start, n, gates, params, state, workspace,
                                  detach_walk, state_out);
     double *carried = state_out ? state_out : state;
+    if (MODE != 1 && chunk_par && batch == 1 && !detach_walk && n >= 3 * kParFrames) {
+        bool settled = false;
+        if (int rc = adsr_run_chunks<MODE>(out, ctl, start, n, gates, params, state, workspace, carried, &settled)) return rc;
+        if (settled) {
+            const int64_t done = (n / kParFrames) * kParFrames;
+            if (done == n) return PGX_OK;
+            return adsr_launch<MODE>(out + done, out_stride, ctl ? ctl + done : nullptr, ctl_stride, 1, start + done,
+                                     n - done, gates, params, carried, workspace, false, carried);
+        }
+        // (not settled after three rounds: chunks without a completed attack in a row -- the loop below, from `state`)
+    }
     if (detach_walk) {
         // the caller joins: every chunk's edge search and walk go to the side stream (the edge search of a chunk needs the
         // state its predecessor's walk leaves, so it cannot stay on the main stream as it does for a single piece)
@@ -999,7 +1130,13 @@ size_t pgx_adsr_workspace_bytes(int batch, int64_t n) {
     if (batch <= 0 || n <= 0) return 0;
     size_t nchunks = (size_t)pgx::ceil_div(n, 64);
     size_t gwords = (size_t)pgx::ceil_div(pgx::ceil_div((int64_t)nchunks, kGroupChunks), 64);
-    return (size_t)batch * (nchunks * 2 + gwords) * sizeof(unsigned long long) + (size_t)batch * sizeof(float) + 64;
+    size_t bytes = (size_t)batch * (nchunks * 2 + gwords) * sizeof(unsigned long long) + (size_t)batch * sizeof(float) + 64;
+    constexpr int64_t kParFrames = (int64_t)kParMaxGroups * kGroupChunks * 64;
+    if (batch == 1 && n >= 3 * kParFrames) {                    // a lone envelope's chunks as a batch (adsr_run_chunks)
+        const size_t alt = adsr_chunk_ws_bytes(n / kParFrames, kParFrames);
+        if (alt > bytes) bytes = alt;
+    }
+    return bytes;
 }
 
 int pgx_adsr_gated(float *out, int64_t out_stride, const float *gate, int64_t gate_stride, int batch, int64_t n,

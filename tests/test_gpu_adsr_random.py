@@ -198,3 +198,42 @@ def test_fused_periodic_gate_matches_rendered_gate(k):
                                    f"gate {gates[bad[0][0]]}")
         assert np.array_equal(st_fused.to_host(), st_ref.to_host()) and np.array_equal(st_a.to_host(), st_ref.to_host())
         pos += b
+
+
+@pytest.mark.parametrize("gate_hz,times", [(2.0, (0.01, 0.1, 0.7, 0.2)), (7.0, (0.01, 0.02, 0.7, 0.03)),
+                                           (5.3, (0.3, 0.05, 0.4, 0.6)),       # attacks that never complete: no pins
+                                           (0.11, (0.01, 0.1, 0.7, 0.2)),      # a gate cycle of nine seconds: chunks without an edge
+                                           (311.7, (0.0005, 0.001, 0.5, 0.001))])
+def test_lone_envelope_over_many_chunks_at_once(gate_hz, times):
+    """adsr_run_chunks (round 4): a lone envelope over a window of many 65 536-frame chunks -- a look-ahead window of a
+    stand-alone AdsrGatedPE -- is walked with all chunks as one batch, in rounds (every chunk from the carried state,
+    then from its left neighbour's exit), settled when two rounds' exits agree bit for bit; what has not settled after
+    three rounds takes the chunk-after-chunk loop.  Fused PeriodicGate and a gate stream from memory, against the
+    oracle's literal loop: bit-exact, states included; a second block continues from the carried state."""
+    lib = device.ensure_init()
+    at, dt, sl, rt = times
+    a, d, r = O.adsr_slopes(at, dt, sl, rt, SR)
+    rec = np.zeros(1, dtype=device.ADSR_PARAMS)
+    rec[0] = (a, d, r, sl, 0)
+    gates = np.zeros(1, dtype=device.GATE_PARAMS)
+    gates[0] = (gate_hz / SR, 0.25, 0.5)
+    gp, params = device.DeviceBuffer.from_host(gates), device.DeviceBuffer.from_host(rec)
+    blocks = [700_001, 65_536 * 3, 1_000_000]
+    st_f = device.DeviceBuffer((1, 3), np.float64, zero=True)
+    st_m = device.DeviceBuffer((1, 3), np.float64, zero=True)
+    ostate = O.adsr_state()
+    pos = 123
+    for b in blocks:
+        ws = device.DeviceBuffer((lib.pgx_adsr_workspace_bytes(1, b),), np.uint8)
+        g = device.DeviceBuffer((1, b), np.float32)
+        device.check(lib.pgx_periodic_gate(g.ptr, b, 1, pos, b, gp.ptr))
+        want = O.adsr_gated(ostate, g.to_host()[0], at, dt, sl, rt, SR)
+        fused = device.DeviceBuffer((1, b), np.float32)
+        device.check(lib.pgx_adsr_gated_periodic(fused.ptr, b, 1, pos, b, gp.ptr, params.ptr, st_f.ptr, ws.ptr, 0))
+        mem = device.DeviceBuffer((1, b), np.float32)
+        device.check(lib.pgx_adsr_gated(mem.ptr, b, g.ptr, b, 1, b, params.ptr, st_m.ptr, ws.ptr))
+        for name, got in (("fused gate", fused.to_host()[0]), ("gate from memory", mem.to_host()[0])):
+            bad = np.flatnonzero(got != np.asarray(want).reshape(-1))
+            assert bad.size == 0, (name, b, pos, len(bad), int(bad[0]), float(got[bad[0]]))
+        assert np.array_equal(st_f.to_host(), st_m.to_host())
+        pos += b
