@@ -537,7 +537,12 @@ int pgx_gate_stateful(float *out, int64_t n, double sample_rate, double freq, do
 /* AdsrGatedPE._render (adsr_pe.py:124-196) / AdsrTriggeredPE._render (adsr_pe.py:279-335):
  * the reference's sequential float64 accumulation reproduced bit for bit (binade-linear runs, see
  * pgx_adsr.hip).  state[instance] = {state enum, env, prev_gate | sustain_ends_at}.
- * workspace: >= pgx_adsr_workspace_bytes(batch, n) bytes of device scratch (edge masks). */
+ * workspace: >= pgx_adsr_workspace_bytes(batch, n) bytes of device scratch (edge masks).
+ * A lone gated envelope (batch == 1) over 196 608 frames or more -- a look-ahead window -- is walked with its 65 536-frame
+ * chunks as one batch, in rounds (every chunk from the carried state, then from its left neighbour's exit; settled when
+ * two rounds' exits agree bit for bit -- every completed attack pins the state, so two rounds settle any envelope
+ * whose chunks each hold one); this one case WAITS for the device once per call to read the verdict, and a render
+ * that has not settled after three rounds is walked chunk after chunk.  Same samples either way. */
 typedef struct {
     double attack_dvdt;
     double decay_dvdt;
