@@ -3831,7 +3831,8 @@ static int bbw_segment_tiles(int batch, int64_t n, int64_t settle_frames, int *w
     const int64_t tiles = pgx::ceil_div(n, tile);
     const int64_t warm = pgx::ceil_div(settle_frames, tile);
     if (warm_tiles_out) *warm_tiles_out = (int)warm;
-    if (batch <= 0 || settle_frames <= 0 || batch > 256 || tiles < 3) return (int)tiles;
+    static const int max_batch = getenv("PGX_BBW_MAX_BATCH") ? atoi(getenv("PGX_BBW_MAX_BATCH")) : 256;
+    if (batch <= 0 || settle_frames <= 0 || batch > max_batch || tiles < 3) return (int)tiles;
     // enough workgroups for one per CU (a 4-wave workgroup alone on its CU renders a tile fastest), segments at
     // least twice their warm-up; PGX_BBW_WGS: experiments
     static const int wgs = getenv("PGX_BBW_WGS") ? atoi(getenv("PGX_BBW_WGS")) : pgx::kNumCU;

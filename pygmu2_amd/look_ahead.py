@@ -39,7 +39,7 @@ WINDOW_GROWTH = 2           # (8, 16, 32, 64, 128, 256: a stream that stops afte
                             # 20-block stream rendered 8 + 33 blocks)
 AHEAD_BLOCKS = int(os.environ.get("PGX_LOOK_AHEAD_BLOCKS", "256"))   # ... at most this many blocks per window (64 until round 4: the autowah
                             # graphs in 1024-frame blocks 519 / 544 Msamples/s at 64, 548 / 568 at 128, 581 / 592 at 256) ...
-AHEAD_FRAMES = 1 << 25      # ... and about this many frames (1 M-frame pulls: 32 blocks per window, 128 MB per
+AHEAD_FRAMES = int(os.environ.get("PGX_LOOK_AHEAD_FRAMES", str(1 << 25)))      # ... and about this many frames (1 M-frame pulls: 32 blocks per window, 128 MB per
                             # channel of every PE in it: C2 3.8 us per step at 2^24, 3.5 at 2^25, 3.3 at 2^26)
 
 STATS = {"window_frames": 0, "windows": 0}     # frames rendered into windows since the process started (bench.py reports

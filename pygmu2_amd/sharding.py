@@ -156,6 +156,8 @@ class TorchReducer:
         self._hash = 0                # sequence hash: every count and every folded fact so far
         self._tickets = 0
         self._checks = 0
+        self.calls = 0                # collectives issued, floats reduced (as RcclReducer: bench.py reports them)
+        self.floats = 0
 
     CHECK_FIRST, CHECK_EVERY = 8, 16  # as pgx_comm.hip: the first tickets and every 16th after them are checked
 
@@ -197,6 +199,8 @@ class TorchReducer:
 
     def all_reduce(self, snippet: Snippet) -> Snippet:
         torch, dist = self.torch, self.dist
+        self.calls += 1
+        self.floats += int(snippet.duration) * int(snippet.channels)
         self._agree(int(snippet.duration) * int(snippet.channels))
         if self.on_device:
             from . import device as _dev

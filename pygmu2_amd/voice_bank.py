@@ -55,6 +55,7 @@ LADDER_WINDOW_FRAMES = int(os.environ.get("PGX_LADDER_WINDOW_FRAMES", str(1 << 2
 PREFETCH_LADDER_INPUT = True
 PREFETCH_SUPERSAW_VOICES = True   # small SuperSaw banks under the mix: oscillators one block ahead (VoiceBank._supersaw_pipelined)  # _LadderNode: next block's oscillators beside this block's ladder
 FUSED_VOICE_MIN = 128        # voices (one workgroup each) from which BlitSaw -> Biquad runs as one launch
+SEGMENTED_CHAIN_MAX = int(os.environ.get("PGX_BBW_MAX_BATCH", "256"))
 SEGMENTED_CHAIN = True       # ... and smaller banks (4 .. 256 voices: a rank's share of C5) as one launch in concurrent time
                              # segments (pgx_blitsaw_biquad_wide_seg: closed-form oscillator carries, the filters warm up)
 PIPELINE_FULL_SUPERSAW_BANK = True    # ... and for a bank that fills the chip (512 instances: the 17 us mix beside the next block's bank)
@@ -433,7 +434,7 @@ class _BiquadNode(_Node):
     def _chain_segments(self, n: int) -> int:
         """Time segments of the fused oscillator -> filter launch for a small bank, or 0: not that path."""
         src = self.children["source"]
-        if not (SEGMENTED_CHAIN and isinstance(src, _BlitSawNode) and src.ch == 1 and 4 <= self.k <= 256
+        if not (SEGMENTED_CHAIN and isinstance(src, _BlitSawNode) and src.ch == 1 and 4 <= self.k <= SEGMENTED_CHAIN_MAX
                 and src.wide() and src.closed_form_ok and self.settle > 0):
             return 0
         segs = lib().pgx_blitsaw_biquad_wide_segments(self.k, n, self.settle)

@@ -123,3 +123,66 @@ def test_every_rank_gets_the_full_mix(tmp_path, world, kind, total, seed):
         assert int(sizes0.max()) >= 4 * n, sizes0                                    # windows were reduced whole
     else:
         assert len(sizes0) >= len(pulls) - 1 and int(sizes0.max()) <= max(m for _, m in pulls)
+
+
+BENCH_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["PGX_ROOT"])
+rank, world, kind, voices, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+import torch.distributed as dist
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+import torch
+import pygmu2_amd as pg
+from pygmu2_amd.sharding import bench_voice_mix
+
+class Dist:                      # what bench.py's Dist offers a workload, carried by the gloo group
+    enabled = True
+    def __init__(self): self.world, self.rank = world, rank
+    def barrier(self): dist.barrier()
+    def max_over_ranks(self, v):
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+dt, frames, name, info = bench_voice_mix(pg, Dist(), 6, 3, voices=voices, block=12_288, config=kind)
+with open(os.path.join(out_dir, f"info{rank}.json"), "w") as f:
+    json.dump({"dt": dt, "frames": frames, "name": name, "info": info}, f)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_OK")
+'''
+
+
+@pytest.mark.parametrize("kind,voices", [("supersaw", 24), ("c5", 16), ("c4", 8)])
+def test_the_bench_workload_with_two_real_ranks(tmp_path, kind, voices):
+    """bench.py's sharded workload (sharding.bench_voice_mix) with two real rank processes on one card over gloo: the
+    N > 1 parts of it that a one-GPU bench run never executes -- the sharded-against-unsharded parity figure measured
+    inside the run (rank 0 renders the full mix as well), the collective counts, the per-rank render time."""
+    import json
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "w.py"
+    script.write_text(BENCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGX_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), kind, str(voices), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=600)
+            outs.append(out.decode()[-3000:])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in out, out
+    infos = [json.load(open(tmp_path / f"info{r}.json")) for r in range(world)]
+    i0 = infos[0]["info"]
+    assert i0["owned"] == voices // 2 and infos[1]["info"]["owned"] == voices - voices // 2
+    assert i0["sharded_vs_unsharded_max_err_over_peak"] is not None and i0["sharded_vs_unsharded_max_err_over_peak"] <= 1e-6
+    assert infos[1]["info"]["sharded_vs_unsharded_max_err_over_peak"] is None       # rank 0 alone renders the full mix
+    assert i0["collectives_in_timed_region"] == infos[1]["info"]["collectives_in_timed_region"] >= 1
+    assert i0["agreement_checks"] >= 1 and i0["render_ms"] > 0 and infos[0]["dt"] == infos[1]["dt"] > 0
