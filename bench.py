@@ -1198,7 +1198,7 @@ def main():
         result["voice_mix"].pop("_dt"), result["supersaw_mix"].pop("_dt")
         if dist.enabled:
             # BASELINE config 4 sharded as well (at N = 1 it is `cases.c4_supersaw_ladder_mix_64`)
-            result["ladder_mix"] = mix_entry(pg, dist, "c4", 64, 31, False)
+            result["ladder_mix"] = mix_entry(pg, dist, "c4", 64, 63, False)
             result["ladder_mix"].pop("_dt")
 
     if dist.rank == 0 and not args.no_extras and not sharded:
@@ -1246,12 +1246,13 @@ def main():
             cases["c3_convolve_64k_taps_1440000_blocks_65537"] = {
                 "value": round(fb * 3 / dtb / 1e6, 3), "unit": "Msamples/s",
                 "roofline": conv_fft_roofline(pg, 65_537, 20)}
-            # (64 blocks after 31: the ladder bank's windows of 2, 4, 8, 16 blocks open during the warm-up, which ends on a
-            # window's last block; the timed region is two whole windows of 32 -- 64 blocks rendered for the 64 counted)
-            cases["c4_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4", 64, 31, with_cpu)
+            # (64 blocks after 63: the ladder bank's windows of 2, 4, 8, 16 blocks and the first one of 32 -- whose 2 x 393 MB
+            # of buffers are allocated then -- open during the warm-up, which ends on a window's last block; the timed
+            # region is two whole windows of 32 -- 64 blocks rendered for the 64 counted)
+            cases["c4_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4", 64, 63, with_cpu)
             cases["c4_supersaw_ladder_mix_64"].pop("_dt")
             # the same bank with the ladders above self-oscillation (resonance 0.6): warm-ups by trial
-            cases["c4_res06_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4r06", 64, 31, with_cpu)
+            cases["c4_res06_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4r06", 64, 63, with_cpu)
             cases["c4_res06_supersaw_ladder_mix_64"].pop("_dt")
             cases["autowah_biquad_1024_blocks"] = {"value": autowah_case(pg, "biquad"), "unit": "Msamples/s"}
             cases["autowah_svf_1024_blocks"] = {"value": autowah_case(pg, "svf"), "unit": "Msamples/s"}

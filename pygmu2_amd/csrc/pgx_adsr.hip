@@ -640,10 +640,12 @@ k_adsr_walk_par(float *out, int64_t out_stride, int batch, int64_t start, int64_
                 const int cnt = adsr_run_length(c, false, now, room + 1);
                 const int take = cnt < room ? cnt : room;
                 const double env = c.env, dq = c.dq;
+#ifndef PGX_ADSR_NO_EMIT            /* experiments/README.md: what the walk costs without its stores (wrong output) */
                 if (emit) {
                     float *dst = o + pos;
                     for (int t = lane; t < take; t += 64) dst[t] = (float)(env + (double)t * dq);
                 }
+#endif
                 c.env = env + (double)take * dq;
                 pos += take;
                 if (cnt <= room) {
