@@ -116,6 +116,10 @@ int pgx_fill(float *out, int64_t n_elems, float value);
 /* IdentityPE: out[i, :] = first + float(i) * delta in float32, where the host passes
  * first = float32(start), delta = float32(start + 1) - first (numpy's arange fill rule). */
 int pgx_ramp(float *out, float first, float delta, int64_t n, int channels);
+/* IdentityPE over a window of consecutive blocks of `period` frames (n frames from `start`): every block is the
+ * reference's np.arange(block start, ..., dtype=float32) -- first and delta taken at the block's own start, which is
+ * what the fill depends on beyond 2^24 (identity_pe.py:54). */
+int pgx_ramp_blocks(float *out, int64_t start, int64_t n, int channels, int64_t period);
 int pgx_dirac(float *out, int64_t start, int64_t n, int channels);
 /* out[f, :] = src[start + f - src_start, :] where start+f lies in [src_start, src_start+src_len),
  * else src[0] if (before && hold_first), src[src_len-1] if (after && hold_last), else 0. */

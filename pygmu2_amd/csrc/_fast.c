@@ -129,10 +129,14 @@ static PyObject *fast_render(PyObject *self, PyObject *const *args, Py_ssize_t n
                 } else {
                     /* ... or from a read-ahead window of a pure sub-graph: (first, end, buffer) (read_ahead.py) */
                     win = PyDict_GetItem(dict, s_ra_win);
-                    if (win && PyTuple_CheckExact(win) && PyTuple_GET_SIZE(win) == 3) {
-                        long long first, end;
-                        if (as_ll(PyTuple_GET_ITEM(win, 0), &first) && as_ll(PyTuple_GET_ITEM(win, 1), &end) &&
-                            first <= s && s + d <= end) {
+                    if (win && PyTuple_CheckExact(win) && (PyTuple_GET_SIZE(win) == 3 || PyTuple_GET_SIZE(win) == 4)) {
+                        /* (first, end, buffer[, period]): a window cut for one block length -- IdentityPE beyond
+                         * 2^24 -- serves only the blocks of its grid */
+                        long long first, end, period = 0;
+                        const int on_grid = PyTuple_GET_SIZE(win) == 3 ||
+                                            (as_ll(PyTuple_GET_ITEM(win, 3), &period) && period > 0 && d == period);
+                        if (on_grid && as_ll(PyTuple_GET_ITEM(win, 0), &first) && as_ll(PyTuple_GET_ITEM(win, 1), &end) &&
+                            first <= s && s + d <= end && (period == 0 || (s - first) % period == 0)) {
                             PyObject *now = PyLong_FromLongLong(s + d);
                             if (!now) return NULL;
                             const int rc = PyDict_SetItem(dict, s_ra_last, now);

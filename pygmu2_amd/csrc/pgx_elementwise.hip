@@ -84,6 +84,23 @@ __global__ void __launch_bounds__(kBlock) k_index_source(float *out, int64_t sta
     }
 }
 
+// The same fill for a WINDOW of consecutive blocks of `period` frames each (read_ahead.py): every block is the
+// reference's own np.arange of that block -- first and delta from the block's start -- so that beyond 2^24, where
+// the fill depends on where a block begins, a window hands out exactly the blocks the caller would have rendered.
+__global__ void __launch_bounds__(kBlock) k_index_blocks(float *out, int64_t start, int64_t n, int channels,
+                                                         int64_t period) {
+    const int64_t n_elems = n * channels;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_elems; e += stride) {
+        const int64_t i = e / channels;
+        const int64_t b = i / period;
+        const int64_t sb = start + b * period;
+        const float first = (float)sb;                              // round to nearest even, as numpy's cast
+        const float delta = (float)(sb + 1) - first;
+        out[e] = first + (float)(i - b * period) * delta;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_window_copy(float *out, int64_t start, int64_t n, int channels,
                                                         const float *src, int64_t src_start, int64_t src_len,
                                                         int hold_first, int hold_last) {
@@ -454,6 +471,16 @@ int pgx_ramp(float *out, float first, float delta, int64_t n, int channels) {
                        dim3(kBlock), 0, pgx::stream(), out, (int64_t)0, n, channels, 0, first, delta,
                        is_aligned16(out));
     PGX_LAUNCH_CHECK("k_index_source");
+    return PGX_OK;
+}
+
+int pgx_ramp_blocks(float *out, int64_t start, int64_t n, int channels, int64_t period) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out != nullptr && channels >= 1 && period >= 1, "pgx_ramp_blocks: bad argument");
+    hipLaunchKernelGGL(k_index_blocks, dim3(pgx::grid_for(n * channels, kBlock)), dim3(kBlock), 0, pgx::stream(), out,
+                       start, n, channels, period);
+    PGX_LAUNCH_CHECK("k_index_blocks");
     return PGX_OK;
 }
 

@@ -73,6 +73,7 @@ _SIGNATURES = [
     ("pgx_selftest_tanh", _I, [_P, _P, _L]),
     ("pgx_fill", _I, [_P, _L, _F]),
     ("pgx_ramp", _I, [_P, _F, _F, _L, _I]),
+    ("pgx_ramp_blocks", _I, [_P, _L, _L, _I, _L]),
     ("pgx_dirac", _I, [_P, _L, _L, _I]),
     ("pgx_window_copy", _I, [_P, _L, _L, _I, _P, _L, _L, _I, _I]),
     ("pgx_extract_channel", _I, [_P, _P, _L, _I, _I]),

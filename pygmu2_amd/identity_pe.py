@@ -13,12 +13,20 @@ class IdentityPE(SourcePE):
     def __init__(self, channels: int = 1):
         self._channels = channels
 
-    # read_ahead.py / look_ahead.py: below 2^24 every index is a float32, whatever block it is rendered in
+    # read_ahead.py / look_ahead.py: below 2^24 every index is a float32, whatever block it is rendered in; beyond, the
+    # fill depends on the block's start: a read-ahead window of equal blocks is filled block by block (pgx_ramp_blocks)
     _READ_AHEAD_SAFE = True
+    _READ_AHEAD_PERIOD_SENSITIVE = True
 
     def _render(self, start: int, duration: int) -> Snippet:
+        from . import look_ahead, read_ahead
+        if read_ahead.busy() and not look_ahead._busy():
+            period = read_ahead.current_period()
+            if period and duration % period == 0:
+                out = new_output(duration, self._channels)
+                check(lib().pgx_ramp_blocks(out.ptr, start, duration, self._channels, period), "pgx_ramp_blocks")
+                return Snippet(start, out)
         if max(abs(start), abs(start + duration)) >= 1 << 24:
-            from . import look_ahead, read_ahead
             if read_ahead.busy() or look_ahead._busy():
                 raise read_ahead.Declined("IdentityPE beyond 2^24: the arange fill depends on the block start")
         out = new_output(duration, self._channels)

@@ -82,8 +82,9 @@ class ProcessingElement(ABC):
                     win.served = d["_la_last"] = end
                     return Snippet.window_rows(start, win.buf, start - win.first, duration)
             else:
-                win = d.get("_ra_win")                   # read-ahead window of a pure sub-graph: (first, end, buffer)
-                if win is not None and win[0] <= start and start + duration <= win[1]:
+                win = d.get("_ra_win")                   # read-ahead window of a pure sub-graph: (first, end, buffer[, period])
+                if (win is not None and win[0] <= start and start + duration <= win[1]
+                        and (len(win) == 3 or (duration == win[3] and (start - win[0]) % win[3] == 0))):
                     d["_ra_last"] = start + duration
                     return Snippet.window_rows(start, win[2], start - win[0], duration)
         diag = is_enabled() if _diag._ACTIVE else False
@@ -104,7 +105,8 @@ class ProcessingElement(ABC):
         if duration <= _RA_LIMIT:
             d = self.__dict__
             win = d.get("_ra_win")
-            if win is not None and win[0] <= start and start + duration <= win[1]:
+            if (win is not None and win[0] <= start and start + duration <= win[1]
+                    and (len(win) == 3 or (duration == win[3] and (start - win[0]) % win[3] == 0))):
                 d["_ra_last"] = start + duration
                 return Snippet.window_rows(start, win[2], start - win[0], duration)
             if d.get("_ra_ok", True):

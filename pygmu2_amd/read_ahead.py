@@ -46,6 +46,32 @@ def busy() -> bool:
     return getattr(_tls, "busy", False)
 
 
+def current_period() -> int:
+    """Frames per caller block while a window is being rendered for a sub-graph that holds a PE whose samples depend on
+    where a block begins (IdentityPE beyond 2^24), else 0.  Such a window is (first, end, buffer, period) and serves
+    only the blocks it was cut for."""
+    return getattr(_tls, "period", 0)
+
+
+def _period_sensitive(pe) -> bool:
+    """Does the sub-graph hold a period-sensitive PE, with nothing above it that changes (start, duration) on the way
+    down?  (cached; a sensitive PE below something that re-addresses its pulls keeps declining such windows)"""
+    cached = pe.__dict__.get("_ra_sensitive")
+    if cached is None:
+        def scan(node):
+            own = bool(getattr(node, "_READ_AHEAD_PERIOD_SENSITIVE", False))
+            below, ok = False, True
+            for child in node.inputs():
+                b, o = scan(child)
+                below, ok = below or b, ok and o
+            if below and not getattr(node, "_PASSES_BLOCKS", False):
+                ok = False
+            return own or below, ok
+        has, ok = scan(pe)
+        cached = pe.__dict__["_ra_sensitive"] = bool(has and ok)
+    return cached
+
+
 def enabled() -> bool:
     return _ENABLED
 
@@ -84,7 +110,8 @@ def render(pe, start: int, duration: int):
     from .snippet import Snippet
     d = pe.__dict__
     win = d.get("_ra_win")
-    if win is not None and win[0] <= start and start + duration <= win[1]:
+    if (win is not None and win[0] <= start and start + duration <= win[1]
+            and (len(win) == 3 or (duration == win[3] and (start - win[0]) % win[3] == 0))):
         d["_ra_last"] = start + duration
         return Snippet.window_rows(start, win[2], start - win[0], duration)
     sequential = d.get("_ra_last") == start
@@ -94,7 +121,9 @@ def render(pe, start: int, duration: int):
         return None             # first pull / random access: render normally, remember where it ended
     grow = d.get("_ra_grow", FIRST_WINDOW_BLOCKS)      # slow start: 8, then 64 blocks (see look_ahead.py)
     d["_ra_grow"] = grow * WINDOW_GROWTH
+    period = duration if _period_sensitive(pe) else 0
     _tls.busy = True
+    _tls.period = period
     try:
         big = pe._render(start, duration * max(2, min(grow, ahead_blocks(duration))))
     except Declined:
@@ -103,10 +132,11 @@ def render(pe, start: int, duration: int):
         return None
     finally:
         _tls.busy = False
+        _tls.period = 0
     if not big.on_device:
         d.pop("_ra_win", None)
         return Snippet(start, big.data[:duration])
-    d["_ra_win"] = (start, start + big.duration, big.dev)
+    d["_ra_win"] = (start, start + big.duration, big.dev, period) if period else (start, start + big.duration, big.dev)
     return Snippet.window_rows(start, big.dev, 0, duration)
 
 

@@ -101,3 +101,17 @@ def test_snippet_finalizer_hooks_still_run():
     assert fired == ["ready", "dropped"]
     s = Snippet.window_rows(0, _Window(16, 1), 0, 4)          # nothing pending: the C exit
     del s
+
+
+def test_read_ahead_window_cut_for_one_block_length():
+    """(first, end, buffer, period): only the blocks of the window's grid are served from it."""
+    pg.set_sample_rate(48000)
+    pe = _Source()
+    pe.__dict__["_ra_ok"] = pe.__dict__["_la_ok"] = False
+    win = _Window(64 * 100, 2)
+    pe.__dict__["_ra_win"] = (1000, 1000 + 64 * 100, win, 100)
+    s = pe.render(1300, 100)
+    assert not pe.calls and s._base == (win, 300)
+    pe.render(1350, 100)                                      # off the grid
+    pe.render(1400, 50)                                       # another length
+    assert pe.calls == [(1350, 100), (1400, 50)]

@@ -94,10 +94,12 @@ def test_mix_with_bounded_inputs_is_not_read_ahead():
         assert np.array_equal(out, g.render(s, n)), (s, n)
 
 
-def test_identity_pe_streams_through_windows_below_2_24_and_declines_beyond():
+def test_identity_pe_streams_through_windows_below_and_beyond_2_24():
     """np.arange(start, start + n, dtype=float32) is filled as first + i * delta in float32: every index below 2^24 is a
-    float32 whatever block it is rendered in (read-ahead windows), beyond that the samples depend on the block start --
-    IdentityPE declines the window that would cross the line and the stream goes on block by block, same samples."""
+    float32 whatever block it is rendered in, beyond that the samples depend on where a block begins.  A read-ahead window
+    over IdentityPE is therefore cut for the caller's block length (round 4: pgx_ramp_blocks fills it block by block,
+    each block the reference's own arange) and serves only pulls on that grid; anything else -- another length, a start
+    off the grid -- is rendered for itself."""
     pg.set_sample_rate(44100)
 
     def want(start, n):
@@ -118,5 +120,13 @@ def test_identity_pe_streams_through_windows_below_2_24_and_declines_beyond():
     for i in range(60):
         got = pe.render(base + i * 1024, 1024).data
         assert np.array_equal(got, 2.0 * want(base + i * 1024, 1024)), i
-    assert not read_ahead.eligible(pe)                     # declined once: block by block from there on
+    win = pe.__dict__.get("_ra_win")
+    assert read_ahead.eligible(pe) and win is not None and len(win) == 4 and win[3] == 1024     # still in windows
+    # off the window's grid, or another length: rendered for itself, the reference's arange of THAT block
+    at = base + 60 * 1024
+    for start, n in ((at + 512, 1024), (at + 1024, 777), (at + 2048, 2048), (at + 4096, 1024), (at + 5120, 1024)):
+        assert np.array_equal(pe.render(start, n).data, 2.0 * want(start, n)), (start, n)
+    far = (1 << 30) + 12345                                 # far beyond: the fill steps by 128
+    for i in range(30):
+        assert np.array_equal(pe.render(far + i * 4096, 4096).data, 2.0 * want(far + i * 4096, 4096)), i
     r.stop()
