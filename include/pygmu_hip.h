@@ -100,6 +100,9 @@ int pgx_event_create(void **event);
 int pgx_event_destroy(void *event);
 int pgx_event_record(void *event);              /* on the library stream */
 int pgx_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+/* What is enqueued from here on -- on the side stream while forked, else on the library stream -- starts after `event`
+ * (recorded with pgx_event_record) has completed: side work that reads ONE thing the main stream produced. */
+int pgx_stream_wait_event(void *event);
 
 /* Diagnostics: evaluate the library's float64 sine / cosine (the routine every oscillator and
  * coefficient kernel uses in place of np.sin / np.cos) on n device doubles. */
@@ -414,6 +417,38 @@ int pgx_blitsaw_biquad_wide_seg(float *out, int64_t out_stride, int batch, int64
                                 const double *saw_state_in, double *saw_state_out, const double *coef,
                                 const double *biquad_tables, const double *biquad_state_in, double *biquad_state_out,
                                 const float *gain, int64_t gain_stride, int64_t settle_frames);
+
+/* MixPE over a bank of such voices -- MixPE(*[GainPE(BiquadPE(BlitSawPE), gain=<envelope>)]) or without the GainPE
+ * (mix_pe.py:91-94 over gain_pe.py:104-119, biquad_pe.py:383-404, blit_saw_pe.py:150-264) -- MIXED ON CHIP: out[n] is the
+ * mix's block, the [voices][frames] layer between the voices and the mix is never written.  The work is cut into
+ * independent (voice, 4096-frame tile) pairs: a workgroup renders a group of voices over the same tile and adds them in a
+ * float64 accumulator per frame; the groups' rows of partial sums are then added in group order (a fixed order).  A pair
+ * enters with the oscillator's phase (a product), its integrator level (closed form, as pgx_blitsaw_biquad_wide_seg) and a
+ * filter started from rest warm_frames before the first frame it emits (warm_frames: a multiple of 16 with every entry of
+ * A^warm_frames below 2^-90 for every voice, <= pgx_voice_tiles_max_warm()).  tables: pgx_voice_tiles_tables packs each
+ * voice's constants (saw_tables / coef / biquad_tables as for pgx_blitsaw_biquad_wide, plus the per-thread turns of the
+ * oscillator's anchor) into one 12 KB block that a workgroup brings into LDS by LDS-DMA, one voice ahead of its use
+ * (pgx_voice_tiles_table_bytes(nvoices) bytes).  States are read from the *_in buffers and written to the *_out buffers.
+ * The oscillator's sample enters the filter unrounded (BlitSawPE's float32 rounding: 6e-8 of a voice's level); each voice's
+ * float32 sample and its float32 product with the gain are the two-PE chain's; the sum is taken in float64 and rounded once (the reference adds float32 in voice
+ * order): <= 1e-6 of peak from pgx_blitsaw_biquad_wide + pgx_gain_mix_batch. */
+int64_t pgx_voice_tiles_max_warm(void);
+size_t pgx_voice_tiles_table_bytes(int nvoices);
+int pgx_voice_tiles_tables(double *tables, const double *saw_tables, const double *coef /* [nvoices][5] */,
+                           const double *biquad_tables, int nvoices);
+size_t pgx_voice_tiles_workspace_bytes(int nvoices, int64_t n, int64_t warm_frames);
+/* What the tiles of a block enter with (integrator levels' closed-form terms, first anchors) depends on the oscillators'
+ * phases only: pgx_voice_tiles_entries makes it for the block that begins advance_frames after the block saw_state is the
+ * start of -- 0: that block itself; n: the next block of a stream, while this one is still being rendered (another
+ * stream) -- into set `slot` (0 / 1) of the workspace; pgx_voice_tiles then takes entries_slot = that set, or -1 to make
+ * them itself first. */
+int pgx_voice_tiles_entries(void *workspace, int slot, int nvoices, int64_t n, const double *tables,
+                            const double *saw_state /* [nvoices][2] */, int64_t advance_frames, int64_t warm_frames);
+int pgx_voice_tiles(float *out /* [n] */, int nvoices, int64_t n, const double *tables,
+                    const double *saw_state_in, double *saw_state_out /* [nvoices][2] */,
+                    const double *biquad_state_in, double *biquad_state_out /* [nvoices][2] */,
+                    const float *gain /* NULL, or [nvoices][gain_stride] */, int64_t gain_stride, int64_t warm_frames,
+                    void *workspace /* pgx_voice_tiles_workspace_bytes(nvoices, n, warm_frames) */, int entries_slot);
 
 /* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
  * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the

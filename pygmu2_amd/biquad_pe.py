@@ -119,6 +119,27 @@ def settle_frames(a1: float, a2: float, limit: int = 1 << 16) -> int:
     return 0
 
 
+def settle_frames_fine(a1: float, a2: float, step: int = 16, limit: int = 2048) -> int:
+    """
+    Smallest multiple of `step` W <= limit for which every entry of A^W (settle_frames' matrix) is below 2^-90; 0 when
+    there is none.  settle_frames rounds up to a power of two (its callers warm up by whole tiles); the on-chip mix
+    (pgx_voice_tiles) warms a filter up INSIDE a 4096-frame tile, where every 16 frames saved are frames emitted.
+    """
+    a = np.array([[-a1, 1.0], [-a2, 0.0]], dtype=np.float64)
+    with np.errstate(over="ignore", invalid="ignore"):
+        ps = np.linalg.matrix_power(a, step)
+        p = ps.copy()
+        w = step
+        while w <= limit:
+            if not np.all(np.isfinite(p)):
+                return 0
+            if np.all(np.abs(p) < 2.0 ** -90):
+                return w
+            p = p @ ps
+            w += step
+    return 0
+
+
 def _passes_more_signal_than_rounding(coef, omega: float, horizon: int) -> bool:
     """The fused chain's sine samples are the separate SinePE's to within the rounding noise of the reference's own
     phase, but not always the same float32: a sample that rounds the other way is an impulse of one float32 ulp

@@ -2463,6 +2463,373 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
     if (tid == 0 && (!SEG || base_end == n)) saw_out[inst * 2 + 0] = pgx::pgx_mod1(phase0 + (double)n * inc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// A bank of BlitSawPE -> BiquadPE [-> GainPE(gain=<envelope>)] voices under a MixPE, MIXED ON CHIP (round 4): the
+// [voices][frames] layer between the voices and the mix (mix_pe.py:91-94 over gain_pe.py:104-119) does not exist.
+//
+// The unit of work is a (voice, tile) pair that depends on no other pair: workgroup (tile t, group g) renders the group's
+// voices one after the other over the SAME 4096 frames -- k_blitsaw_biquad_wide's body: oscillator, integrator scan,
+// float32 rounding, filter, float32 product with the envelope -- and adds each to a float64 accumulator its threads keep
+// for their 16 frames; the tile leaves the chip once, as one row of partial sums per group, and k_mix_partials adds the
+// rows in group order (a fixed order: the result does not depend on the launch).  What a pair needs on entering:
+//   * the oscillator's phase: a product, as everywhere in these kernels; the threads' anchors sincos(theta), sincos(M theta)
+//     are the tile's first anchor (k_voice_tile_entries) turned by the thread's offset (a per-voice table of 256 angles
+//     reduced exactly: k_voice_tile_pack) -- 12 operations where two sincos take ~120;
+//   * the integrator's level: saw_steady_terms' closed form from the level the block began with (k_voice_tile_entries:
+//     one wave per pair, ahead of the tiles);
+//   * the filter's state: forgotten.  Tile t starts `warm` frames (a multiple of 16: whole threads) before the first frame it
+//     emits, from rest; `warm` is the bank's settle horizon (every entry of A^warm below 2^-90), a few hundred frames
+//     where k_blitsaw_biquad_wide<SEG> spends whole tiles.  Tile 0 starts at the block's first frame from the carried state.
+// Tiles advance by emit = 4096 - warm frames.  The thread that renders the block's last frame writes the carried states
+// (to the *_out buffers: other workgroups still read the *_in ones).  <= 1e-6 of peak against k_blitsaw_biquad_wide
+// followed by k_gain_mix_batch, like every closed-form entry in this file.
+// ------------------------------------------------------------------------------------------------
+constexpr int kVtEntryDoubles = 8;       // per (voice, tile): (2/P) sum_a, leak^frames, the first thread's anchor (4), (2/P) sum_b, spare
+// One voice's constants, packed (k_voice_tile_pack) so that a workgroup brings them into LDS with three 4 KB LDS-DMA
+// instructions per thread-row: [0] the 24 scalars of pgx_supersaw_wide_tables, [24] b0 b1 b2 a1 a2, [32] the first 28 doubles
+// of pgx_biquad_tables (A^(16 2^k), A^(16 64)), [64] leak^(16 k) for k = 0..63 (the scans' per-lane powers are entries
+// lane, (lane & 15) + 1 and (lane & 31) + 1 of it), [128] the first rows of A^j, j = 0..15, [256] A^(16 j) for j = 0..63,
+// [512] per thread l: sincos(pi 16 l inc), sincos(M pi 16 l inc) -- the turn from the tile's first anchor to thread l's.
+constexpr int kVtPack = 1536;            // doubles per voice: 12 KB
+constexpr int kVtLds = kVtPack + kVtEntryDoubles;
+
+__global__ void __launch_bounds__(256)
+k_voice_tile_pack(double *pack, const double *saw_tables, const double *coef, const double *bq_tables) {
+    const int inst = blockIdx.x, l = threadIdx.x;
+    const double *st = saw_tables + (int64_t)inst * kSswTabDoubles;
+    const double *tb = bq_tables + (int64_t)inst * kBqTableDoubles;
+    double *dst = pack + (int64_t)inst * kVtPack;
+    if (l < 24) dst[l] = st[l];
+    if (l < 8) dst[24 + l] = l < 5 ? coef[inst * 5 + l] : 0.0;
+    if (l < 32) dst[32 + l] = l < 28 ? tb[l] : 0.0;
+    if (l < 64) dst[64 + l] = st[kSswLanePw + l];
+    if (l < 32) dst[128 + l] = tb[kBqRowsAt + l];
+    if (l >= 160) dst[l] = 0.0;
+    dst[256 + l] = tb[28 + l];
+    const double inc = st[0], m = st[1];
+    // 16 l inc and M 16 l inc as (product, its rounding error); whole half-turns are dropped with their sign
+    const double k1 = 16.0 * (double)l, km = m * k1;                    // integers: exact
+    double out4[4];
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+        const double k = i ? km : k1;
+        const double p = k * inc, e = __builtin_fma(k, inc, -p);
+        const double fl = floor(p);
+        double sn, cs;
+        pgx::pgx_sincos_bounded(kPi * ((p - fl) + e), sn, cs);
+        const bool odd = fmod(fl, 2.0) != 0.0;
+        out4[2 * i] = odd ? -sn : sn;
+        out4[2 * i + 1] = odd ? -cs : cs;
+    }
+    double *r = dst + 512 + 4 * l;
+    r[0] = out4[0]; r[1] = out4[1]; r[2] = out4[2]; r[3] = out4[3];
+}
+
+// One workgroup per voice, all tiles of the block: the harmonics over the threads (saw_steady_terms' sum; the unit
+// vectors of consecutive tiles by a fixed turn -- a tile's advance, reduced exactly), then one thread per tile for the
+// anchors.  advance: the block begins that many frames after the one `saw_state` is the start of (its phase by the same
+// expression k_voice_tiles leaves it with: the entries of the NEXT block can be made while this one is rendered).
+__global__ void __launch_bounds__(256)
+k_voice_tile_entries(double *entries, const double *pack, const double *saw_state, int64_t advance, int ntiles,
+                     int emit_frames, int warm) {
+    constexpr int TT = 15;                                  // tiles per pass (+ the sum at the block's start: 16 rows)
+    __shared__ double part[TT + 1][256];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const double *st = pack + (int64_t)v * kVtPack;
+    const double inc = st[0], m = st[1], invP = st[3], leak = st[5];
+    double phase0 = saw_state[v * 2 + 0];
+    if (advance > 0) phase0 = pgx::pgx_mod1(phase0 + (double)advance * inc);
+    const int K = ((int)m - 1) / 2;
+    const double scale = 2.0 * invP;
+    double *dst = entries + (int64_t)v * ntiles * kVtEntryDoubles;
+    // a tile's advance in phase: emit_frames * inc as (product, rounding error), whole turns dropped
+    const double ef = (double)emit_frames;
+    const double adv_p = ef * inc, adv_e = __builtin_fma(ef, inc, -adv_p);
+    const double adv = (adv_p - floor(adv_p)) + adv_e;
+    for (int t0 = 1; t0 < ntiles; t0 += TT) {               // tiles t0 .. t0 + TT - 1 (tile 0 enters with the carried level)
+        const int64_t base0 = (int64_t)t0 * emit_frames - warm;
+        const double ph_a = pgx::pgx_mod1(phase0 + (double)base0 * inc);
+        double sum_a[TT], sum_b = 0.0;
+#pragma unroll
+        for (int u = 0; u < TT; ++u) sum_a[u] = 0.0;
+        for (int k = tid + 1; k <= K; k += 256) {
+            const double kk = (double)k;
+            double arg[4] = {kk * inc, kk * ph_a, kk * phase0, kk * adv}, sn[4], cs[4];
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) pgx::pgx_sincos_bounded((2.0 * kPi) * (arg[i] - floor(arg[i])), sn[i], cs[i]);
+            const double dr = 1.0 - leak * cs[0], di = leak * sn[0];      // 1 - leak e^(-ja) = dr + j di
+            const double inv = 1.0 / (dr * dr + di * di);
+            const double gr = dr * inv, gi = di * inv;
+            sum_b += cs[2] * gr + sn[2] * gi;
+            double c1 = cs[1], s1 = sn[1];
+#pragma unroll
+            for (int u = 0; u < TT; ++u) {
+                sum_a[u] += c1 * gr + s1 * gi;
+                const double t2 = __builtin_fma(s1, cs[3], c1 * sn[3]);
+                c1 = __builtin_fma(c1, cs[3], -(s1 * sn[3]));
+                s1 = t2;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TT; ++u) part[u][tid] = sum_a[u];
+        part[TT][tid] = sum_b;
+        __syncthreads();
+        // thread (row, piece): 16 of the row's 256 terms, then the 16 pieces of a row over their 16 lanes
+        const int row = tid >> 4, piece = tid & 15;
+        double x = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x += part[row][piece * 16 + i];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+        __syncthreads();
+        if (piece == 0) part[0][row] = x;
+        __syncthreads();
+        const int t = t0 + tid;
+        if (tid < TT && t < ntiles) {
+            const int64_t base = (int64_t)t * emit_frames - warm;
+            double decay = 1.0, q = leak;
+            for (int64_t e = base; e > 0; e >>= 1) {
+                if (e & 1) decay = decay * q;
+                q = q * q;
+            }
+            double *d = dst + (int64_t)t * kVtEntryDoubles;
+            d[0] = scale * part[0][tid]; d[1] = decay; d[6] = scale * part[0][TT]; d[7] = 0.0;
+        }
+        __syncthreads();
+    }
+    // the first thread's anchor of every tile: k_blitsaw_biquad_wide's first-tile evaluation for the frame base + 1
+    for (int t = tid; t < ntiles; t += 256) {
+        const int64_t base = t == 0 ? 0 : (int64_t)t * emit_frames - warm;
+        const double ph = pgx::pgx_mod1(phase0 + (double)(base + 1) * inc);
+        const double theta = kPi * ph;
+        double sd, cd, sn, cn;
+        pgx::pgx_sincos_bounded(theta, sd, cd);
+        pgx::pgx_sincos_bounded(m * theta, sn, cn);
+        double *d = dst + (int64_t)t * kVtEntryDoubles;
+        d[2] = sd; d[3] = cd; d[4] = sn; d[5] = cn;
+        if (t == 0) { d[0] = 0.0; d[1] = 1.0; d[6] = 0.0; d[7] = 0.0; }
+    }
+}
+
+#ifndef PGX_VT_WAVES
+#define PGX_VT_WAVES 3                  // waves per SIMD the kernel is compiled for
+#endif
+typedef __attribute__((address_space(1))) const void *vt_global_ptr;
+typedef __attribute__((address_space(3))) void *vt_lds_ptr;
+
+__device__ __forceinline__ double vt_uniform(double x) {          // a value every lane holds -> scalar registers
+    const unsigned long long b = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <int NW, bool GAIN>
+__global__ void __launch_bounds__(NW * 64, PGX_VT_WAVES)
+k_voice_tiles(double *__restrict__ partial, int64_t partial_stride, int64_t n, int nvoices, int groups, int ntiles,
+              int emit_frames, int warm, const double *__restrict__ pack, const double *__restrict__ saw_state,
+              double *__restrict__ saw_out, const double *__restrict__ bq_state, double *__restrict__ bq_out,
+              const double *__restrict__ entries, const float *__restrict__ gain, int64_t gain_stride) {
+    constexpr int T = kSswT;
+    static_assert(NW * 64 == 256, "the packed tables hold one turn per thread of a 256-thread workgroup");
+    __shared__ __attribute__((aligned(16))) double cbuf[2][kVtLds];
+    __shared__ SawBqWideShared<NW> sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup -> (group, tile).  Consecutive workgroups go to consecutive XCDs: with the groups a multiple of 8 the
+    // workgroups of one group -- the only readers of its voices' tables -- all land on XCD (group mod 8), whose L2 then
+    // holds an eighth of the bank's tables
+    int g, t;
+    if ((groups & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = groups >> 3;
+        g = (slot % per) * 8 + xcd;
+        t = slot / per;
+    } else {
+        g = blockIdx.x % groups;
+        t = blockIdx.x / groups;
+    }
+    const int64_t base = t == 0 ? 0 : (int64_t)t * emit_frames - warm;
+    const int64_t f0 = base + (int64_t)tid * T;
+    const int64_t emit_lo = (int64_t)t * emit_frames;
+    const int64_t emit_hi = emit_lo + emit_frames < n ? emit_lo + emit_frames : n;
+    const bool owner = emit_lo <= n - 1 && n - 1 < emit_hi && f0 <= n - 1 && n - 1 < f0 + T;
+    double acc[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[j] = 0.0;
+    const int v_first = (int)((int64_t)g * nvoices / groups), v_end = (int)((int64_t)(g + 1) * nvoices / groups);
+    // a voice's constants: global memory -> LDS without passing through registers, one voice ahead of their use
+    auto stage = [&](int v, int which) {
+        const char *src = reinterpret_cast<const char *>(pack + (int64_t)v * kVtPack) + tid * 16;
+        double *dst = cbuf[which] + wave * 128;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            __builtin_amdgcn_global_load_lds((vt_global_ptr)(src + q * 4096), (vt_lds_ptr)(dst + q * 512), 16, 0, 0);
+        if (tid < 4)
+            __builtin_amdgcn_global_load_lds(
+                (vt_global_ptr)(reinterpret_cast<const char *>(entries + ((int64_t)v * ntiles + t) * kVtEntryDoubles) + tid * 16),
+                (vt_lds_ptr)(cbuf[which] + kVtPack), 16, 0, 0);
+    };
+    if (v_first < v_end) stage(v_first, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int parity = 0;
+#pragma unroll 1
+    for (int v = v_first; v < v_end; ++v, ++parity) {
+        const double *cb = cbuf[parity & 1];
+        const double level0 = saw_state[v * 2 + 1];
+        // ---- the oscillator: the tile's first anchor turned by this thread's offset
+        const double *en = cb + kVtPack;
+        const double *rt = cb + 512 + 4 * tid;
+        const double r_s = rt[0], r_c = rt[1], r_sm = rt[2], r_cm = rt[3];
+        const double sd = __builtin_fma(en[2], r_c, en[3] * r_s), cd = __builtin_fma(en[3], r_c, -(en[2] * r_s));
+        const double sn = __builtin_fma(en[4], r_cm, en[5] * r_sm), cn = __builtin_fma(en[5], r_cm, -(en[4] * r_sm));
+        const double inc = cb[0], invP = vt_uniform(cb[3]), m_over_p = cb[4], leak = vt_uniform(cb[5]), amp2 = cb[6];
+        const double rsd = vt_uniform(cb[8]), rcd = vt_uniform(cb[9]), rsm = cb[10], rcm = cb[11], two_cm = vt_uniform(cb[19]);
+        double xb[T];
+        const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+        if (PGX_COLD(met != 0ull))
+            saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) e = __builtin_fma(leak, e, xb[j]);           // feeds the scan only
+        double lamp[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lamp[k] = cb[12 + k];
+        const double lam_wave = cb[18];
+        const LanePowers lane_pw{cb[64 + lane], cb[64 + (lane & 15) + 1], cb[64 + (lane & 31) + 1]};
+        double carry_y = t == 0 ? level0 : __builtin_fma(en[1], level0 - en[6], en[0]);
+        double y = block_scan_scalar_affine_wide1<NW>(e, lamp, lam_wave, lane_pw, sh.aff, parity, carry_y);
+        const double y_in = y;
+        // ---- behind the first barrier every wave has left the voice before: its buffer takes the next voice's constants;
+        // this voice's gains (GainPE(x, gain=<PE>): float32 x float32) are asked for, a zero-state pass ahead of their use
+        if (v + 1 < v_end) stage(v + 1, (parity + 1) & 1);
+        float gv[GAIN ? T : 1];
+        if (GAIN) {
+            const float *gb = gain + (int64_t)v * gain_stride;
+            if (PGX_HOT(f0 + T <= n && aligned16(gb + f0))) {
+#pragma unroll
+                for (int j = 0; j < T; j += 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(gb + f0 + j);
+                    gv[j] = q.x; gv[j + 1] = q.y; gv[j + 2] = q.z; gv[j + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) gv[j] = f0 + j < n ? gb[f0 + j] : 0.0f;
+            }
+        }
+        // ---- the filter's zero-state pass over the 16 frames.  The oscillator's sample (y * 2) * amp goes in unrounded
+        // (BlitSawPE rounds it to float32, 6e-8 of the voice's level: three operations per frame; k_supersaw_wide does the
+        // same), so its scale folds into b0, b1, b2
+        const double b0 = vt_uniform(cb[24] * amp2), b1 = vt_uniform(cb[25] * amp2), b2 = vt_uniform(cb[26] * amp2);
+        const double na1 = vt_uniform(-cb[27]), na2 = vt_uniform(-cb[28]);
+        V2 ez{0.0, 0.0};
+        double yz[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            y = __builtin_fma(leak, y, xb[j]);
+            const double yy = __builtin_fma(b0, y, ez.x);
+            ez.x = __builtin_fma(na1, yy, __builtin_fma(b1, y, ez.y));
+            ez.y = __builtin_fma(na2, yy, b2 * y);
+            yz[j] = yy;
+        }
+        // (the scan's matrices are asked for here, not at the top of the zero-state pass: 56 registers the pass has no room for)
+        __builtin_amdgcn_sched_barrier(0);
+        const double *tb = cb + 32;
+        ez = mv_add_fma(load_m2(tb + 0), dpp_v2<0x111, 0xf>(ez), ez);
+        ez = mv_add_fma(load_m2(tb + 4), dpp_v2<0x112, 0xf>(ez), ez);
+        ez = mv_add_fma(load_m2(tb + 8), dpp_v2<0x114, 0xf>(ez), ez);
+        ez = mv_add_fma(load_m2(tb + 12), dpp_v2<0x118, 0xf>(ez), ez);
+        ez = mv_add_fma(load_m2(cb + 256 + 4 * ((lane & 15) + 1)), dpp_v2<0x142, 0xa>(ez), ez);
+        ez = mv_add_fma(load_m2(cb + 256 + 4 * ((lane & 31) + 1)), dpp_v2<0x143, 0xc>(ez), ez);
+        V2 *tot = sh.tot[parity & 1];
+        if (lane == 63) tot[wave] = ez;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the next voice's constants have landed: LDS-DMA counts as a load)
+        __syncthreads();
+        const V2 carry_z = t == 0 ? V2{bq_state[v * 2 + 0], bq_state[v * 2 + 1]} : V2{0.0, 0.0};
+        const M2 pwave = load_m2(tb + 24);
+        V2 cw = carry_z, fold = carry_z;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            fold = mv_add_fma(pwave, fold, tot[w]);
+            if (w + 1 == wave) cw = fold;                         // this wave's carry-in
+        }
+        const V2 ex = dpp_v2<0x138, 0xf>(ez);                     // the lane before, 0 for lane 0
+        const V2 zin = mv_add_fma(load_m2(cb + 256 + 4 * lane), cw, ex);
+        // the carried state's contribution (A^j z).x by its own two-operation recurrence (the rows of A^j from LDS, two
+        // fused multiply-adds per frame, are an operation less -- and 32 more values in flight: measured with spills)
+        V2 hz = zin;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            float yf = (float)(yz[j] + hz.x);
+            const double hx = __builtin_fma(na1, hz.x, hz.y);
+            hz.y = na2 * hz.x;
+            hz.x = hx;
+            if (GAIN) yf = yf * gv[GAIN ? j : 0];                 // gain_pe.py:104-119: the float32 product
+            acc[j] += (double)yf;                                 // mix_pe.py:91-94, in float64 until the rows are added
+        }
+        if (PGX_COLD(owner)) {                                    // the thread that renders the block's last frame:
+            const int jn = (int)(n - 1 - f0);                     // the states after it, by the literal recurrences
+            double yl = y_in;
+            V2 z = zin;
+            double xo[T];                                         // (the oscillator's frames again, from the anchors again:
+            const double o_sd = __builtin_fma(en[2], rt[1], en[3] * rt[0]), o_cd = __builtin_fma(en[3], rt[1], -(en[2] * rt[0]));   // kept until
+            const double o_sn = __builtin_fma(en[4], rt[3], en[5] * rt[2]), o_cn = __builtin_fma(en[5], rt[3], -(en[4] * rt[2]));   // here they cost
+            saw_rot_frames<T, true>(o_sd, o_cd, o_sn, o_cn, cb[3], cb[4], cb[8], cb[9], cb[10], cb[11], cb[19], xo);               // every thread 40 registers)
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const double yn = __builtin_fma(leak, yl, xo[j]);
+                const double yy = z.x + b0 * yn;
+                const double z0 = (z.y + b1 * yn) + na1 * yy;
+                const double z1 = b2 * yn + na2 * yy;
+                if (j <= jn) {
+                    yl = yn;
+                    z = V2{z0, z1};
+                }
+            }
+            saw_out[v * 2 + 1] = yl;
+            bq_out[v * 2 + 0] = z.x;
+            bq_out[v * 2 + 1] = z.y;
+        }
+        if (PGX_COLD(t == 0 && tid == 0)) saw_out[v * 2 + 0] = pgx::pgx_mod1(saw_state[v * 2 + 0] + (double)n * inc);
+    }
+    // the group's row of partial sums: this thread's 16 frames are all inside the tile's emitted range or all outside
+    // (emit_frames and warm are multiples of 16)
+    if (f0 >= emit_lo && f0 < emit_hi) {
+        double *row = partial + (int64_t)g * partial_stride + f0;
+        if (PGX_HOT(f0 + T <= n)) {
+#pragma unroll
+            for (int j = 0; j < T; j += 2) *reinterpret_cast<double2 *>(row + j) = double2{acc[j], acc[j + 1]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                if (f0 + j < n) row[j] = acc[j];
+        }
+    }
+}
+
+// out[f] = float32(sum over the groups' rows, in group order)
+__global__ void __launch_bounds__(256)
+k_mix_partials(float *out, const double *partial, int64_t partial_stride, int groups, int64_t n) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    constexpr int U = 16;
+    double acc = 0.0;
+    int g = 0;
+    for (; g + U <= groups; g += U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = partial[(int64_t)(g + u) * partial_stride + f];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    if (g < groups) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = g + u < groups ? partial[(int64_t)(g + u) * partial_stride + f] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    out[f] = (float)acc;
+}
+
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
 struct SawPlan {
     int nseg, tiles_per_seg;
@@ -3894,6 +4261,107 @@ int pgx_blitsaw_biquad_wide_seg(float *out, int64_t out_stride, int batch, int64
                            out_stride, n, saw_tables, s_in, coef, biquad_tables, b_in, gain, gain_stride, saw_state_out,
                            biquad_state_out, seg, warm);
     PGX_LAUNCH_CHECK("k_blitsaw_biquad_wide<seg>");
+    return PGX_OK;
+}
+
+// The same voices mixed on chip (k_voice_tiles): out[n] is the MixPE's block, no [voices][frames] layer in between.
+struct VoiceTilesPlan {
+    int emit, tiles, groups;
+    int64_t stride;                       // doubles per row of partial sums
+    size_t entries_bytes, bytes;
+};
+static VoiceTilesPlan voice_tiles_plan(int nvoices, int64_t n, int64_t warm) {
+    constexpr int64_t tile = 4 * 64 * kSswT;
+    VoiceTilesPlan p{};
+    p.emit = (int)(tile - warm);
+    p.tiles = (int)pgx::ceil_div(n, (int64_t)p.emit);
+    // (voice, tile) pairs over the workgroups the chip holds at once (PGX_VT_WAVES 4-wave workgroups per CU): one round
+    // of workgroups with the same number of voices (+- 1), the groups a multiple of 8 (one XCD per group: k_voice_tiles);
+    // PGX_VT_GROUPS / PGX_VT_SLOTS: experiments
+    static const int forced = getenv("PGX_VT_GROUPS") ? atoi(getenv("PGX_VT_GROUPS")) : 0;
+    static const int slots = getenv("PGX_VT_SLOTS") ? atoi(getenv("PGX_VT_SLOTS")) : PGX_VT_WAVES * pgx::kNumCU;
+    int64_t groups = forced > 0 ? forced : slots / p.tiles;
+    if (groups >= 8) groups &= ~(int64_t)7;
+    if (groups < 1) groups = 1;
+    if (groups > nvoices) groups = nvoices;
+    p.groups = (int)groups;
+    p.stride = (n + 1) & ~(int64_t)1;
+    p.entries_bytes = (size_t)nvoices * p.tiles * kVtEntryDoubles * sizeof(double);
+    p.bytes = 2 * p.entries_bytes + (size_t)p.groups * p.stride * sizeof(double);     // two sets of entries: this block's and the next one's
+    return p;
+}
+
+int64_t pgx_voice_tiles_max_warm(void) { return 2048; }
+
+size_t pgx_voice_tiles_table_bytes(int nvoices) { return (size_t)(nvoices > 0 ? nvoices : 0) * kVtPack * sizeof(double); }
+
+int pgx_voice_tiles_tables(double *tables, const double *saw_tables, const double *coef, const double *biquad_tables,
+                           int nvoices) {
+    PGX_REQUIRE_INIT();
+    if (nvoices <= 0) return PGX_OK;
+    PGX_CHECK_ARG(tables && saw_tables && coef && biquad_tables, "pgx_voice_tiles_tables: bad argument");
+    hipLaunchKernelGGL(k_voice_tile_pack, dim3(nvoices), dim3(256), 0, pgx::stream(), tables, saw_tables, coef,
+                       biquad_tables);
+    PGX_LAUNCH_CHECK("k_voice_tile_pack");
+    return PGX_OK;
+}
+
+size_t pgx_voice_tiles_workspace_bytes(int nvoices, int64_t n, int64_t warm_frames) {
+    if (nvoices <= 0 || n <= 0 || warm_frames <= 0 || warm_frames > pgx_voice_tiles_max_warm() || (warm_frames & 15)) return 0;
+    return voice_tiles_plan(nvoices, n, warm_frames).bytes;
+}
+
+int pgx_voice_tiles_entries(void *workspace, int slot, int nvoices, int64_t n, const double *tables,
+                            const double *saw_state, int64_t advance_frames, int64_t warm_frames) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || nvoices <= 0) return PGX_OK;
+    PGX_CHECK_ARG(workspace && tables && saw_state && (slot == 0 || slot == 1) && advance_frames >= 0,
+                  "pgx_voice_tiles_entries: bad argument");
+    PGX_CHECK_ARG(warm_frames > 0 && warm_frames <= pgx_voice_tiles_max_warm() && (warm_frames & 15) == 0,
+                  "pgx_voice_tiles_entries: warm_frames must be a multiple of 16 in 16 .. pgx_voice_tiles_max_warm()");
+    const VoiceTilesPlan p = voice_tiles_plan(nvoices, n, warm_frames);
+    double *entries = reinterpret_cast<double *>(static_cast<char *>(workspace) + (size_t)slot * p.entries_bytes);
+    hipLaunchKernelGGL(k_voice_tile_entries, dim3(nvoices), dim3(256), 0, pgx::stream(), entries, tables, saw_state,
+                       advance_frames, p.tiles, p.emit, (int)warm_frames);
+    PGX_LAUNCH_CHECK("k_voice_tile_entries");
+    return PGX_OK;
+}
+
+int pgx_voice_tiles(float *out, int nvoices, int64_t n, const double *tables, const double *saw_state_in,
+                    double *saw_state_out, const double *biquad_state_in, double *biquad_state_out, const float *gain,
+                    int64_t gain_stride, int64_t warm_frames, void *workspace, int entries_slot) {
+    PGX_REQUIRE_INIT();
+    if (n <= 0 || nvoices <= 0) return PGX_OK;
+    PGX_CHECK_ARG(out && tables && saw_state_in && saw_state_out && biquad_state_in && biquad_state_out && workspace &&
+                      saw_state_in != saw_state_out && biquad_state_in != biquad_state_out,
+                  "pgx_voice_tiles: bad argument (states are read from one buffer and written to another)");
+    PGX_CHECK_ARG(warm_frames > 0 && warm_frames <= pgx_voice_tiles_max_warm() && (warm_frames & 15) == 0,
+                  "pgx_voice_tiles: warm_frames must be a multiple of 16 in 16 .. pgx_voice_tiles_max_warm()");
+    PGX_CHECK_ARG(gain == nullptr || nvoices == 1 || gain_stride >= n, "pgx_voice_tiles: gain_stride too small");
+    PGX_CHECK_ARG(n < ((int64_t)1 << 40), "pgx_voice_tiles: block too long");
+    const VoiceTilesPlan p = voice_tiles_plan(nvoices, n, warm_frames);
+    PGX_CHECK_ARG((int64_t)p.tiles * p.groups < ((int64_t)1 << 31), "pgx_voice_tiles: too many tiles");
+    PGX_CHECK_ARG(entries_slot >= -1 && entries_slot <= 1, "pgx_voice_tiles: entries_slot is -1 (made here), 0 or 1");
+    if (entries_slot < 0) {
+        const int rc = pgx_voice_tiles_entries(workspace, 0, nvoices, n, tables, saw_state_in, 0, warm_frames);
+        if (rc != PGX_OK) return rc;
+        entries_slot = 0;
+    }
+    double *entries = reinterpret_cast<double *>(static_cast<char *>(workspace) + (size_t)entries_slot * p.entries_bytes);
+    double *partial = reinterpret_cast<double *>(static_cast<char *>(workspace) + 2 * p.entries_bytes);
+    const dim3 grid((unsigned)(p.tiles * p.groups));
+    if (gain != nullptr)
+        hipLaunchKernelGGL((k_voice_tiles<4, true>), grid, dim3(256), 0, pgx::stream(), partial, p.stride, n, nvoices,
+                           p.groups, p.tiles, p.emit, (int)warm_frames, tables, saw_state_in, saw_state_out,
+                           biquad_state_in, biquad_state_out, (const double *)entries, gain, gain_stride);
+    else
+        hipLaunchKernelGGL((k_voice_tiles<4, false>), grid, dim3(256), 0, pgx::stream(), partial, p.stride, n, nvoices,
+                           p.groups, p.tiles, p.emit, (int)warm_frames, tables, saw_state_in, saw_state_out,
+                           biquad_state_in, biquad_state_out, (const double *)entries, gain, gain_stride);
+    PGX_LAUNCH_CHECK("k_voice_tiles");
+    hipLaunchKernelGGL(k_mix_partials, dim3((unsigned)pgx::ceil_div(n, (int64_t)256)), dim3(256), 0, pgx::stream(), out,
+                       (const double *)partial, p.stride, p.groups, n);
+    PGX_LAUNCH_CHECK("k_mix_partials");
     return PGX_OK;
 }
 

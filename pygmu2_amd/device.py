@@ -68,6 +68,7 @@ _SIGNATURES = [
     ("pgx_event_create", _I, [C.POINTER(_P)]),
     ("pgx_event_destroy", _I, [_P]),
     ("pgx_event_record", _I, [_P]),
+    ("pgx_stream_wait_event", _I, [_P]),
     ("pgx_event_elapsed_ms", _I, [_P, _P, C.POINTER(_F)]),
     ("pgx_selftest_sincos", _I, [_P, _P, _P, _L]),
     ("pgx_selftest_tanh", _I, [_P, _P, _L]),
@@ -123,6 +124,12 @@ _SIGNATURES = [
     ("pgx_blitsaw_biquad_wide", _I, [_P, _L, _I, _L, _P, _P, _P, _P, _P, _P, _L]),
     ("pgx_blitsaw_biquad_wide_segments", _I, [_I, _L, _L]),
     ("pgx_blitsaw_biquad_wide_seg", _I, [_P, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L]),
+    ("pgx_voice_tiles_max_warm", _L, []),
+    ("pgx_voice_tiles_table_bytes", _Z, [_I]),
+    ("pgx_voice_tiles_tables", _I, [_P, _P, _P, _P, _I]),
+    ("pgx_voice_tiles_workspace_bytes", _Z, [_I, _L, _L]),
+    ("pgx_voice_tiles_entries", _I, [_P, _I, _I, _L, _P, _P, _L, _L]),
+    ("pgx_voice_tiles", _I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I]),
     ("pgx_supersaw_bank", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P]),
     ("pgx_supersaw_bank_segments", _I, [_I, _L]),
     ("pgx_supersaw_bank_seg", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P, _P, _P]),

@@ -26,7 +26,7 @@ import numpy as np
 from . import device as _dev
 from ._kernels import DeviceBuffer, blitsaw_workspace, check, lib, ptr
 from .adsr_pe import AdsrGatedPE
-from .biquad_pe import BiquadPE, rbj_coefficients, settle_frames
+from .biquad_pe import BiquadPE, rbj_coefficients, settle_frames, settle_frames_fine
 from .blit_saw_pe import BlitSawPE, wide_oscillators_ok
 from .comb_pe import CombPE
 from .extent import Extent
@@ -60,8 +60,13 @@ SEGMENTED_CHAIN = True       # ... and smaller banks (4 .. 256 voices: a rank's 
                              # segments (pgx_blitsaw_biquad_wide_seg: closed-form oscillator carries, the filters warm up)
 PIPELINE_FULL_SUPERSAW_BANK = True    # ... and for a bank that fills the chip (512 instances: the 17 us mix beside the next block's bank)
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
+VOICE_TILES = os.environ.get("PGX_VOICE_TILES", "1") != "0"   # BlitSaw -> Biquad [-> x envelope] voices mixed on chip (pgx_voice_tiles)
+VOICE_TILES_MIN_FRAMES = 4096
+VOICE_TILES_MIN_VOICES = int(os.environ.get("PGX_VOICE_TILES_MIN_VOICES", "192"))   # (below, the envelope walk -- which the on-chip mix
+                             # waits for BEFORE the voices, the layered path only before the mix -- is the block's critical chain: 128 voices
+                             # 62 us per block against 60, 64 voices 56 against 52; 256 voices 68 against 75, 512 voices 111 against 119)
 FUSE_GAIN_IN_CHAIN = False   # ... and multiplied into the voices by the oscillator -> filter kernel: measured, no gain (render_mix)
-EARLY_WALK_MAX_VOICES = 256  # ... started at once (not behind the block's oscillators) for banks up to this size
+EARLY_WALK_MAX_VOICES = int(os.environ.get("PGX_EARLY_WALK_MAX", "256"))  # ... started at once (not behind the block's oscillators) for banks up to this size
 ENVELOPE_AHEAD = True        # a bank's AdsrGatedPE(PeriodicGate) envelopes one block ahead on the side stream (render_mix)
 WIDE_SUPERSAW = True         # the bank kernel with 16 frames per thread (pgx_supersaw_wide) where its conditions hold
 SEGMENTED_SUPERSAW = True    # below FUSED_SUPERSAW_MIN: the fused bank in concurrent time segments (closed-form carries)
@@ -418,6 +423,11 @@ class _BiquadNode(_Node):
         # 512-voice bank is one workgroup per voice either way.
         settles = [settle_frames(c[3], c[4]) for c in coef]
         self.settle = 0 if min(settles) == 0 else max(settles)
+        fine = [settle_frames_fine(c[3], c[4]) for c in coef] if self.settle else [0]
+        self.settle_fine = 0 if min(fine) == 0 else max(fine)      # (a multiple of 16: the on-chip mix's warm-up)
+        self.rot_tables = None
+        self.tiles_ws = None
+        self.entries_ahead = {}      # start -> (n, set): what the tiles of that block enter with, made behind the block before it
         self.tables = None           # per-voice powers of A (pgx_biquad_tables), made on first render
         self.state = None
         self.state_alt = None        # (the time-segmented chain reads one buffer and writes the other)
@@ -439,6 +449,71 @@ class _BiquadNode(_Node):
             return 0
         segs = lib().pgx_blitsaw_biquad_wide_segments(self.k, n, self.settle)
         return segs if segs > 1 else 0
+
+    def mixes_on_chip(self, n: int) -> bool:
+        """render_mix(start, n[, gain]) returns the MixPE's block: pgx_voice_tiles, no [voices][frames] layer."""
+        src = self.children["source"]
+        return (VOICE_TILES and isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= VOICE_TILES_MIN_VOICES and src.wide()
+                and src.closed_form_ok and n >= VOICE_TILES_MIN_FRAMES
+                and 0 < self.settle_fine <= lib().pgx_voice_tiles_max_warm())
+
+    def quiesce(self):
+        self.entries_ahead = {}
+
+    def _mix_tables(self):
+        L = lib()
+        src = self.children["source"]
+        saw_tables = src.tables.get("wide")
+        if saw_tables is None:
+            saw_tables = src.tables["wide"] = DeviceBuffer((L.pgx_supersaw_wide_table_bytes(self.k, 1),), np.uint8)
+            check(L.pgx_supersaw_wide_tables(saw_tables.ptr, self.k, 1, self.sr, src.params.ptr),
+                  "pgx_supersaw_wide_tables")
+        if self.tables is None:
+            self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
+            check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
+        if self.rot_tables is None:
+            self.rot_tables = DeviceBuffer((L.pgx_voice_tiles_table_bytes(self.k),), np.uint8)
+            check(L.pgx_voice_tiles_tables(self.rot_tables.ptr, saw_tables.ptr, self.coef.ptr, self.tables.ptr, self.k),
+                  "pgx_voice_tiles_tables")
+
+    def render_mix(self, start, n, gain=None, streaming=False):
+        """The voices' mix (times `gain`, [K][n] float32, voice by voice) as one (n, 1) block.  streaming: (start + n, n)
+        is expected next -- what its tiles enter with (the oscillators' phases decide it: pgx_voice_tiles_entries) is made
+        behind this block's mix, off the next block's critical chain."""
+        L = lib()
+        src = self.children["source"]
+        if self.state is None:
+            self.state = DeviceBuffer((self.k, 1, 2), np.float64, zero=True)
+        if self.state_alt is None:
+            self.state_alt = DeviceBuffer(self.state.shape, np.float64)
+        if src.state_alt is None:
+            src.state_alt = DeviceBuffer(src.state.shape, src.state.dtype)
+        slot = -1
+        mine = self.entries_ahead.pop(start, None)
+        if mine is not None and mine[0] == n and src.last_end == start:
+            slot = mine[1]
+        stale = [s0 for s0, (n0, _) in self.entries_ahead.items() if s0 != start + n or n0 != n]
+        if stale:
+            self.entries_ahead = {}
+        src.prepare(start)
+        self._mix_tables()
+        need = L.pgx_voice_tiles_workspace_bytes(self.k, n, self.settle_fine)
+        if self.tiles_ws is None or self.tiles_ws.nbytes < need:
+            self.tiles_ws = DeviceBuffer((need,), np.uint8)
+            slot = -1
+        out = DeviceBuffer((n, 1), np.float32)
+        check(L.pgx_voice_tiles(out.ptr, self.k, n, self.rot_tables.ptr, src.state.ptr, src.state_alt.ptr,
+                                self.state.ptr, self.state_alt.ptr, ptr(gain), n, self.settle_fine, self.tiles_ws.ptr,
+                                slot), "pgx_voice_tiles")
+        if streaming:
+            nxt = (slot if slot >= 0 else 0) ^ 1
+            check(L.pgx_voice_tiles_entries(self.tiles_ws.ptr, nxt, self.k, n, self.rot_tables.ptr, src.state_alt.ptr, 0,
+                                            self.settle_fine), "pgx_voice_tiles_entries")
+            self.entries_ahead[start + n] = (n, nxt)
+        src.state, src.state_alt = src.state_alt, src.state
+        self.state, self.state_alt = self.state_alt, self.state
+        src.last_end = start + n
+        return out
 
     def takes_gain(self) -> bool:
         """render(..., gain=<[K][n] float32>) multiplies the voices by it inside the chain's kernel."""
@@ -808,9 +883,10 @@ class _AdsrGatedNode(_Node):
             return ahead[2]
         return None
 
-    def render_ahead(self, start, n) -> None:
+    def render_ahead(self, start, n, also=None) -> None:
         """Fused PeriodicGate only.  Edge search and walk go to the side stream, which starts behind what the main
-        stream holds so far and is left running (pgx_stream_detach)."""
+        stream holds so far and is left running (pgx_stream_detach).  also: called on the side stream, in front of the
+        walk (the on-chip mix's entries of the same block)."""
         L = lib()
         gate_node = self.children["gate"]
         if self.state_next is None:
@@ -837,6 +913,8 @@ class _AdsrGatedNode(_Node):
         else:
             check(L.pgx_stream_fork_after(seen.ptr), "pgx_stream_fork_after")
         try:
+            if also is not None:                 # (first: short, and nothing behind it on this stream depends on it)
+                also()
             check(L.pgx_adsr_gated_periodic_to(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
                                                self.state.ptr, self.state_next.ptr, scratch.ptr),
                   "pgx_adsr_gated_periodic_to")
@@ -997,6 +1075,7 @@ class VoiceBank:
         self.mix_windows = False     # windows at the level of the mix whatever the root (set_mix_windows)
         self.win = None              # [first, end, n, mixed window (Snippet), served, [(node, snapshot)]]
         self.last = None             # (start, n) of the last block handed out
+        self.streaming = False       # the block being rendered continues the one before it, same length
         self.grow = BANK_WINDOW_FIRST
 
     def reset(self) -> None:
@@ -1051,7 +1130,7 @@ class VoiceBank:
                 row._bank_window = True
                 return row
             self._settle_window()
-        streaming = self.last == (start - duration, duration)
+        streaming = self.streaming = self.last == (start - duration, duration)
         self.last = (start, duration)
         # (SuperSaw banks below the size that fills the chip: measured 44 -> 23 us per block for a rank's 64 instances,
         # 62 -> 42 for 128.  Not 256 and more -- rendered one block ahead already, a window ahead is too much thrown away
@@ -1120,6 +1199,30 @@ class VoiceBank:
                      else (PIPELINE_SUPERSAW_BANK or not root.banked(duration)))
                 and not lib().pgx_stream_is_forked()):
             return self._supersaw_pipelined(start, duration)
+        if isinstance(root, _BiquadNode) and root.mixes_on_chip(duration):
+            return Snippet(start, root.render_mix(start, duration, streaming=self.streaming))
+        if (isinstance(root, _GainNode) and root.gains is None and isinstance(root.children["source"], _BiquadNode)
+                and root.children["source"].mixes_on_chip(duration) and root.children["gain"].channels() == 1):
+            # GainPE(BiquadPE(BlitSawPE), gain=<PE>) voices: oscillator -> filter -> x gain -> mix in one kernel
+            # (pgx_voice_tiles).  The gains come first -- the kernel reads them -- so envelopes with a fused gate are
+            # walked one block ahead on the side stream, the next block's walk enqueued in front of this block's voices.
+            L = lib()
+            gain, source = root.children["gain"], root.children["source"]
+            ahead = (isinstance(gain, _AdsrGatedNode) and gain.fused_gate() and ENVELOPE_AHEAD and duration >= 1024
+                     and not L.pgx_stream_is_forked())
+            g = None
+            if ahead:
+                streaming = gain.last == (start - duration, duration)      # equal blocks, one after the other
+                if gain.ahead is not None:
+                    g = gain.take_ahead(start, duration)
+            if g is None:
+                g = gain.render(start, duration)        # a stream's first block, a seek, another kind of gain: rendered now
+            if ahead and streaming:
+                gain.render_ahead(start + duration, duration)
+            out = source.render_mix(start, duration, gain=g, streaming=ahead and streaming)
+            if isinstance(gain, _AdsrGatedNode):
+                gain.mark_consumed(g)
+            return Snippet(start, out)
         if isinstance(root, _GainNode) and root.gains is None:
             # voices end in GainPE(x, gain=<PE>): fuse the per-voice multiply into the mix.  The gain
             # sub-graph (envelopes: few, latency-bound waves) and the signal sub-graph (oscillators and
