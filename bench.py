@@ -451,8 +451,9 @@ def fp64_roofline(kernel: str, units_per_launch: float, avg_launch_ms: float):
 
 def bank_kernel_fp64(pg, config: str, launches: int = 20):
     """The dominant kernel of a bank mix alone, HIP events around back-to-back launches through the bank's own node
-    (states carried from block to block as in the mix): k_supersaw_wide<4> over 512 x 7 oscillators, or
-    k_blitsaw_biquad_wide<4> over C5's 512 oscillator -> filter chains; 48 000-frame blocks."""
+    (states carried from block to block as in the mix): k_supersaw_wide<4> over 512 x 7 oscillators, or C5's 512
+    oscillator -> filter -> x envelope voices mixed on chip (pgx_voice_tiles: k_voice_tiles<4, env> and its two small
+    launches, timed together; k_blitsaw_biquad_wide<4> where that path is off); 48 000-frame blocks."""
     from pygmu2_amd import voice_bank as vb
     from pygmu2_amd.sharding import mix_voice_factory
     pg.set_sample_rate(48000)
@@ -475,11 +476,23 @@ def bank_kernel_fp64(pg, config: str, launches: int = 20):
         node = next((x for x in bank._nodes() if isinstance(x, vb._BiquadNode)), None)
         if node is None or not node.children["source"].wide():
             return None
-        kernel, units = "k_blitsaw_biquad_wide<4>", voices * n
+        if node.mixes_on_chip(n):
+            # the on-chip mix: oscillator -> filter -> x envelope -> partial sums (k_voice_tiles) + the rows' sum; the
+            # envelopes are a constant buffer here (their walk runs beside this kernel in the mix, on another stream)
+            from pygmu2_amd._kernels import DeviceBuffer
+            import numpy as np
+            gains = DeviceBuffer.from_host(np.full((voices, n, 1), 0.5, dtype=np.float32))
+            kernel, units = "k_voice_tiles<4, env>", voices * n
 
-        def launch():
-            node.render(pos[0], n)
-            pos[0] += n
+            def launch():
+                node.render_mix(pos[0], n, gain=gains, streaming=True)
+                pos[0] += n
+        else:
+            kernel, units = "k_blitsaw_biquad_wide<4>", voices * n
+
+            def launch():
+                node.render(pos[0], n)
+                pos[0] += n
     ms = event_avg_ms(launch, launches)
     return fp64_roofline(kernel, units, ms)
 

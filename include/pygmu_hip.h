@@ -603,10 +603,11 @@ int pgx_adsr_gated_periodic(float *out, int64_t out_stride, int batch, int64_t s
                             void *workspace, int detach_walk);
 /* The same block with the carried state read from one buffer and written to another (a block rendered ahead of the
  * caller's stream -- voice_bank.py: the states it started from stay where they are, a pull that turns out not to be
- * this block costs nothing to undo).  Everything on the current stream. */
+ * this block costs nothing to undo).  detach_walk = 0: everything on the current stream; != 0: as above -- the edge search on
+ * the current stream, then the fork and the walk on the side stream (the caller joins or detaches). */
 int pgx_adsr_gated_periodic_to(float *out, int64_t out_stride, int batch, int64_t start, int64_t n,
                                const pgx_gate_params *gates, const pgx_adsr_params *params,
-                               const double *state_in, double *state_out, void *workspace);
+                               const double *state_in, double *state_out, void *workspace, int detach_walk);
 int pgx_adsr_triggered(float *out, int64_t out_stride, const float *trig, int64_t trig_stride,
                        int batch, int64_t start, int64_t n, const pgx_adsr_params *params,
                        double *state, void *workspace);

@@ -148,7 +148,7 @@ _SIGNATURES = [
     ("pgx_adsr_workspace_bytes", _Z, [_I, _L]),
     ("pgx_adsr_gated", _I, [_P, _L, _P, _L, _I, _L, _P, _P, _P]),
     ("pgx_adsr_gated_periodic", _I, [_P, _L, _I, _L, _L, _P, _P, _P, _P, _I]),
-    ("pgx_adsr_gated_periodic_to", _I, [_P, _L, _I, _L, _L, _P, _P, _P, _P, _P]),
+    ("pgx_adsr_gated_periodic_to", _I, [_P, _L, _I, _L, _L, _P, _P, _P, _P, _P, _I]),
     ("pgx_adsr_triggered", _I, [_P, _L, _P, _L, _I, _L, _L, _P, _P, _P]),
     ("pgx_convolve_workspace_bytes", _Z, [_L, _L, _I]),
     ("pgx_convolve", _I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P]),

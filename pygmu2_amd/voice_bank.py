@@ -883,7 +883,7 @@ class _AdsrGatedNode(_Node):
             return ahead[2]
         return None
 
-    def render_ahead(self, start, n, also=None) -> None:
+    def render_ahead(self, start, n, also=None, edges_here=False) -> None:
         """Fused PeriodicGate only.  Edge search and walk go to the side stream, which starts behind what the main
         stream holds so far and is left running (pgx_stream_detach).  also: called on the side stream, in front of the
         walk (the on-chip mix's entries of the same block)."""
@@ -903,6 +903,19 @@ class _AdsrGatedNode(_Node):
         # 98 MB buffers in turn are more than the memory-side cache holds.  137 us per block against 144.)
         if self.k > EARLY_WALK_MAX_VOICES:
             out, seen = DeviceBuffer((self.k, n, 1), np.float32), None
+            if edges_here and also is None:
+                # (the caller enqueues the block's voices right behind this call: an edge search that starts beside them --
+                # short, parallel -- finds no free SIMD for 20 us, and the walk waits for it.  It goes in front of them, on
+                # the main stream; the library forks behind it)
+                try:
+                    check(L.pgx_adsr_gated_periodic_to(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
+                                                       self.state.ptr, self.state_next.ptr, scratch.ptr, 1),
+                          "pgx_adsr_gated_periodic_to")
+                finally:
+                    if L.pgx_stream_is_forked():
+                        check(L.pgx_stream_detach(), "pgx_stream_detach")
+                self.ahead = (start, n, out)
+                return
         else:
             if not self.ring or self.ring[0][0].shape != (self.k, n, 1):
                 self.ring = [[DeviceBuffer((self.k, n, 1), np.float32), None] for _ in range(3)]
@@ -916,7 +929,7 @@ class _AdsrGatedNode(_Node):
             if also is not None:                 # (first: short, and nothing behind it on this stream depends on it)
                 also()
             check(L.pgx_adsr_gated_periodic_to(out.ptr, n, self.k, start, n, gate_node.params.ptr, self.params.ptr,
-                                               self.state.ptr, self.state_next.ptr, scratch.ptr),
+                                               self.state.ptr, self.state_next.ptr, scratch.ptr, 0),
                   "pgx_adsr_gated_periodic_to")
         finally:
             check(L.pgx_stream_detach(), "pgx_stream_detach")
@@ -1218,7 +1231,7 @@ class VoiceBank:
             if g is None:
                 g = gain.render(start, duration)        # a stream's first block, a seek, another kind of gain: rendered now
             if ahead and streaming:
-                gain.render_ahead(start + duration, duration)
+                gain.render_ahead(start + duration, duration, edges_here=True)
             out = source.render_mix(start, duration, gain=g, streaming=ahead and streaming)
             if isinstance(gain, _AdsrGatedNode):
                 gain.mark_consumed(g)

@@ -188,7 +188,7 @@ def test_fused_periodic_gate_matches_rendered_gate(k):
         device.check(lib.pgx_adsr_gated_periodic(fused.ptr, b, k, pos, b, gp.ptr, params.ptr, st_fused.ptr, ws[1].ptr, 0))
         to = device.DeviceBuffer((k, b), np.float32)
         device.check(lib.pgx_adsr_gated_periodic_to(to.ptr, b, k, pos, b, gp.ptr, params.ptr, st_a.ptr, st_b.ptr,
-                                                    ws[2].ptr))
+                                                    ws[2].ptr, 0))
         st_a, st_b = st_b, st_a
         w = want.to_host()
         for name, got in (("fused", fused.to_host()), ("fused, states elsewhere", to.to_host())):

@@ -160,6 +160,10 @@ KERNELS = {
     "k_blitsaw_biquad_wide<4, env>": dict(
         source="pgx_scan.hip", match="k_blitsaw_biquad_wideILi4ELb1", depth=1, units=16, unit="voice-frame",
         why="one voice per workgroup: the loop over its tiles, 16 frames per lane and tile (oscillator + filter)"),
+    "k_voice_tiles<4, env>": dict(
+        source="pgx_scan.hip", match="k_voice_tilesILi4ELb1", depth=1, units=16, unit="voice-frame",
+        why="a workgroup's loop over its voices: one trip is one voice's 16 frames of a lane over the tile (anchor turn, "
+            "oscillator, integrator scan, filter, x envelope, accumulate)"),
     "k_blitsaw_biquad_wide<4>": dict(
         source="pgx_scan.hip", match="k_blitsaw_biquad_wideILi4ELb0", depth=1, units=16, unit="voice-frame",
         why="one voice per workgroup: the loop over its tiles, 16 frames per lane and tile (oscillator + filter)"),
