@@ -60,6 +60,19 @@ def test_c5_voices_on_chip_mix_equals_layered_path(small_banks_on_chip, count):
         assert np.max(np.abs(a - b)) <= 1e-6 * peak, f"block {(s, n)}: {np.max(np.abs(a - b)) / peak:.3e} of peak"
 
 
+def test_stream_that_changes_paths_block_by_block(small_banks_on_chip):
+    """Blocks below 4096 frames take the layered path, the others the on-chip mix: the states travel between them."""
+    pg.set_sample_rate(SR)
+    blocks, pos = [], 0
+    for n in (48000, 1000, 48000, 2000, 4096, 4095, 30000, 30000, 512, 30000):
+        blocks.append((pos, n))
+        pos += n
+    new, old = _both(lambda: pg.MixPE(*[c5_voice(pg, 11 * i) for i in range(40)]), blocks)
+    peak = max(float(np.max(np.abs(b))) for b in old)
+    for (s0, n), a, b in zip(blocks, new, old):
+        assert np.max(np.abs(a - b)) <= 1e-6 * peak, f"block {(s0, n)}: {np.max(np.abs(a - b)) / peak:.3e} of peak"
+
+
 def test_voices_without_gain_and_mixed_filters(small_banks_on_chip):
     pg.set_sample_rate(SR)
 

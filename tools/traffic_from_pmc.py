@@ -132,11 +132,25 @@ for (k, g), v in sorted(f.items()):
 # (k_mix_batch runs at two sizes in the probe -- 512 inputs for the SuperSaw mix, 64 for C4 -- its largest launch is the 512-input one)
 mix512 = max(v for (n_, k, g), v in MAXES.items() if n_ == "mixes_FETCH_SIZE" and k.startswith("k_mix_batch"))
 ss = (kib(w, "k_supersaw_wide<4>", 131072) + 2 * mix512) * 1024
-c5 = (kib(w, "k_blitsaw_biquad_wide", 131072) + kib(w, "k_adsr_walk_par<8>", 262144) + 2 * kib(f, "k_gain_mix_batch", 48128)) * 1024
+on_chip = any(k.startswith("k_voice_tiles") for (k, g) in f)
+if on_chip:
+    # round 4, late: C5's voices are mixed on chip (pgx_voice_tiles).  What still crosses HBM per block: the envelopes (written by
+    # the walk, read once by k_voice_tiles: wide reads, x2), the groups' rows of partial sums (written, read once by
+    # k_mix_partials: x2), the tiles' entries, the final mix
+    vt = [(k, g) for (k, g) in f if k.startswith("k_voice_tiles")]
+    vt_key = max(vt, key=lambda kg: kg[1])
+    c5 = (2 * f[vt_key] + w.get(vt_key, 0.0) + kib(w, "k_adsr_walk_par<8>", 262144) + 2 * kib(f, "k_mix_partials", 48128)
+          + kib(w, "k_mix_partials", 48128) + kib(f, "k_voice_tile_entries", 131072) + kib(w, "k_voice_tile_entries", 131072)) * 1024
+    c5_text = (f"C5 (voices mixed on chip, `pgx_voice_tiles`): the `[512][48000]` layer of voices is gone; what crosses HBM is the envelope "
+               f"layer (float32, written by the walk and read once by `k_voice_tiles`), the groups' rows of partial sums and the tiles' "
+               f"entries: about **{c5 / 1e6:.0f} MB** per block (394 MB with the layered path, `r3_pmc_traffic.md`).")
+else:
+    c5 = (kib(w, "k_blitsaw_biquad_wide", 131072) + kib(w, "k_adsr_walk_par<8>", 262144) + 2 * kib(f, "k_gain_mix_batch", 48128)) * 1024
+    c5_text = (f"C5: oscillator+filter output and envelopes, each `[512][48000]`, written and read by "
+               f"`k_gain_mix_batch`: about **{c5 / 1e6:.0f} MB** per block.")
 md += ["", f"SuperSaw mix (512 x 7 oscillators): the `[512][48000]` float32 layer under the MixPE is written once and read once "
        f"(x2 on the wide reads of `k_mix_batch`; the 512-input launch is the table's maximum, its mean blends in C4's 64-input mix): about **{ss / 1e6:.0f} MB** per block against "
-       f"0.192 MB of final mix.  C5: oscillator+filter output and envelopes, each `[512][48000]`, written and read by "
-       f"`k_gain_mix_batch`: about **{c5 / 1e6:.0f} MB** per block.  See DESIGN.md section 7 for why the layer stays.", ""]
+       f"0.192 MB of final mix.  {c5_text}  See DESIGN.md section 7.", ""]
 out["supersaw_mix_512"] = {"48000": int(round(ss, -5))}
 out["c5_voice_mix_512"] = {"48000": int(round(c5, -5))}
 
