@@ -100,9 +100,6 @@ int pgx_event_create(void **event);
 int pgx_event_destroy(void *event);
 int pgx_event_record(void *event);              /* on the library stream */
 int pgx_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
-/* What is enqueued from here on -- on the side stream while forked, else on the library stream -- starts after `event`
- * (recorded with pgx_event_record) has completed: side work that reads ONE thing the main stream produced. */
-int pgx_stream_wait_event(void *event);
 
 /* Diagnostics: evaluate the library's float64 sine / cosine (the routine every oscillator and
  * coefficient kernel uses in place of np.sin / np.cos) on n device doubles. */

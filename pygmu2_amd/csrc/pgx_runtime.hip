@@ -531,13 +531,6 @@ int pgx_event_record(void *event) {
     return PGX_OK;
 }
 
-int pgx_stream_wait_event(void *event) {
-    PGX_REQUIRE_INIT();
-    PGX_CHECK_ARG(event != nullptr, "pgx_stream_wait_event: null event");
-    PGX_HIP(hipStreamWaitEvent(rt().current, (hipEvent_t)event, 0));
-    return PGX_OK;
-}
-
 int pgx_event_elapsed_ms(void *start, void *stop, float *ms) {
     PGX_REQUIRE_INIT();
     PGX_CHECK_ARG(start && stop && ms, "pgx_event_elapsed_ms: null argument");

@@ -68,7 +68,6 @@ _SIGNATURES = [
     ("pgx_event_create", _I, [C.POINTER(_P)]),
     ("pgx_event_destroy", _I, [_P]),
     ("pgx_event_record", _I, [_P]),
-    ("pgx_stream_wait_event", _I, [_P]),
     ("pgx_event_elapsed_ms", _I, [_P, _P, C.POINTER(_F)]),
     ("pgx_selftest_sincos", _I, [_P, _P, _P, _L]),
     ("pgx_selftest_tanh", _I, [_P, _P, _L]),

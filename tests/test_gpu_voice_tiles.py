@@ -2,8 +2,6 @@
 voices and the MixPE) against the layered path it replaces, the CPU oracle, and itself across seeks, resets, block lengths
 and the two ways its tiles' entries are made (inline, or behind the block before)."""
 
-import ctypes as C
-
 import numpy as np
 import pytest
 
