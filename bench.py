@@ -449,7 +449,7 @@ def fp64_roofline(kernel: str, units_per_launch: float, avg_launch_ms: float):
                            "32-bit VALU instructions count half a slot in frac_with_32bit_valu)"}
 
 
-def bank_kernel_fp64(pg, config: str, launches: int = 20):
+def bank_kernel_fp64(pg, config: str, launches: int = 300, warm: int = 100):
     """The dominant kernel of a bank mix alone, HIP events around back-to-back launches through the bank's own node
     (states carried from block to block as in the mix): k_supersaw_wide<4> over 512 x 7 oscillators, or C5's 512
     oscillator -> filter -> x envelope voices mixed on chip (pgx_voice_tiles: k_voice_tiles<4, env> and its two small
@@ -493,7 +493,7 @@ def bank_kernel_fp64(pg, config: str, launches: int = 20):
             def launch():
                 node.render(pos[0], n)
                 pos[0] += n
-    ms = event_avg_ms(launch, launches)
+    ms = event_avg_ms(launch, launches, warm)        # (a few hundred launches: the clock a stream runs at, as for the mixes)
     return fp64_roofline(kernel, units, ms)
 
 
@@ -1203,15 +1203,17 @@ def main():
         result["voice_mix"], result["supersaw_mix"] = dict(note), dict(note)
     elif not sharded and not args.no_extras:
         # collectives: every rank takes part.  The sharded mixes ride along in the default line.
-        result["voice_mix"] = mix_entry(pg, dist, "c5", 50, 5, with_cpu and dist.rank == 0)
-        # (48 blocks after 15: a rank's share of a sharded run renders windows of 2, 4, 8, 8, ... blocks from the second
+        # (streams of a few hundred blocks -- 40 - 60 ms of device time: over 50 blocks the chip has not yet reached the clock
+        # a stream runs at, and the same kernels took 5 - 7 % longer: DESIGN 7)
+        result["voice_mix"] = mix_entry(pg, dist, "c5", 400, 40, with_cpu and dist.rank == 0)
+        # (384 blocks after 47: a rank's share of a sharded run renders windows of 2, 4, 8, 8, ... blocks from the second
         # block on and reduces each in one collective -- the warm-up ends on a window's last block and holds the first
-        # 8-block collective, the timed region is six whole windows: 48 blocks rendered for the 48 counted)
-        result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 48, 15, with_cpu and dist.rank == 0)
+        # 8-block collectives, the timed region is 48 whole windows: 384 blocks rendered for the 384 counted)
+        result["supersaw_mix"] = mix_entry(pg, dist, "supersaw", 384, 47, with_cpu and dist.rank == 0)
         result["voice_mix"].pop("_dt"), result["supersaw_mix"].pop("_dt")
         if dist.enabled:
             # BASELINE config 4 sharded as well (at N = 1 it is `cases.c4_supersaw_ladder_mix_64`)
-            result["ladder_mix"] = mix_entry(pg, dist, "c4", 64, 63, False)
+            result["ladder_mix"] = mix_entry(pg, dist, "c4", 256, 63, False)
             result["ladder_mix"].pop("_dt")
 
     if dist.rank == 0 and not args.no_extras and not sharded:
@@ -1262,10 +1264,10 @@ def main():
             # (64 blocks after 63: the ladder bank's windows of 2, 4, 8, 16 blocks and the first one of 32 -- whose 2 x 393 MB
             # of buffers are allocated then -- open during the warm-up, which ends on a window's last block; the timed
             # region is two whole windows of 32 -- 64 blocks rendered for the 64 counted)
-            cases["c4_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4", 64, 63, with_cpu)
+            cases["c4_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4", 256, 63, with_cpu)
             cases["c4_supersaw_ladder_mix_64"].pop("_dt")
             # the same bank with the ladders above self-oscillation (resonance 0.6): warm-ups by trial
-            cases["c4_res06_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4r06", 64, 63, with_cpu)
+            cases["c4_res06_supersaw_ladder_mix_64"] = mix_entry(pg, solo, "c4r06", 256, 63, with_cpu)
             cases["c4_res06_supersaw_ladder_mix_64"].pop("_dt")
             cases["autowah_biquad_1024_blocks"] = {"value": autowah_case(pg, "biquad"), "unit": "Msamples/s"}
             cases["autowah_svf_1024_blocks"] = {"value": autowah_case(pg, "svf"), "unit": "Msamples/s"}

@@ -883,7 +883,7 @@ class _AdsrGatedNode(_Node):
             return ahead[2]
         return None
 
-    def render_ahead(self, start, n, also=None, edges_here=False) -> None:
+    def render_ahead(self, start, n, also=None, edges_here=False, behind_main=False) -> None:
         """Fused PeriodicGate only.  Edge search and walk go to the side stream, which starts behind what the main
         stream holds so far and is left running (pgx_stream_detach).  also: called on the side stream, in front of the
         walk (the on-chip mix's entries of the same block)."""
@@ -921,7 +921,7 @@ class _AdsrGatedNode(_Node):
                 self.ring = [[DeviceBuffer((self.k, n, 1), np.float32), None] for _ in range(3)]
             self.ring_at = (self.ring_at + 1) % 3
             out, seen = self.ring[self.ring_at]
-        if seen is None:
+        if seen is None or behind_main:       # (behind_main: the states this walk starts from were written on the main stream)
             check(L.pgx_stream_fork(), "pgx_stream_fork")
         else:
             check(L.pgx_stream_fork_after(seen.ptr), "pgx_stream_fork_after")
@@ -1228,10 +1228,13 @@ class VoiceBank:
                 streaming = gain.last == (start - duration, duration)      # equal blocks, one after the other
                 if gain.ahead is not None:
                     g = gain.take_ahead(start, duration)
-            if g is None:
+            walked_here = g is None
+            if walked_here:
                 g = gain.render(start, duration)        # a stream's first block, a seek, another kind of gain: rendered now
             if ahead and streaming:
-                gain.render_ahead(start + duration, duration, edges_here=True)
+                # (walked_here: this block's walk ran on the MAIN stream and left the states the next one starts from there --
+                # the side stream, which otherwise only waits for its envelope buffer's last reader, has to start behind it)
+                gain.render_ahead(start + duration, duration, edges_here=True, behind_main=walked_here)
             out = source.render_mix(start, duration, gain=g, streaming=ahead and streaming)
             if isinstance(gain, _AdsrGatedNode):
                 gain.mark_consumed(g)

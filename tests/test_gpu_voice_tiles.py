@@ -71,6 +71,30 @@ def test_stream_that_changes_paths_block_by_block(small_banks_on_chip):
         assert np.max(np.abs(a - b)) <= 1e-6 * peak, f"block {(s0, n)}: {np.max(np.abs(a - b)) / peak:.3e} of peak"
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PGX_FUZZ_BANK_STREAMS", "16"))))
+def test_random_pulls_with_everything_ahead_against_nothing_ahead(small_banks_on_chip, monkeypatch, seed):
+    """test_gpu_bank_streams' pull patterns (streams with seeks, steps back, restarts, odd lengths) on banks that take the
+    on-chip mix: envelopes one block ahead, the next block's entries behind the mix -- against every pull rendered when it
+    is asked for.  (Found: a walk rendered on the main stream after a seek, followed by a walk ahead on a side stream that
+    did not wait for it.)"""
+    import test_gpu_bank_streams as streams
+    rng = np.random.default_rng(81_000 + seed)
+    count = int(rng.choice([6, 64, 130, 200, 260]))
+    pulls = streams._pulls(rng)
+    pg.set_sample_rate(SR)
+
+    def run(ahead):
+        for name in streams.SWITCHES:
+            monkeypatch.setattr(voice_bank, name, ahead)
+        return _render(pg.MixPE(*[c5_voice(pg, (3 * i) % 512) for i in range(count)]), pulls)
+
+    got, want = run(True), run(False)
+    peak = max(float(np.max(np.abs(w))) for w in want) or 1.0
+    for i, ((s0, n), a, b) in enumerate(zip(pulls, got, want)):
+        err = float(np.max(np.abs(a.astype(np.float64) - b)))
+        assert err <= 1e-6 * peak, (count, i, pulls[max(0, i - 2):i + 1], err, peak)
+
+
 def test_voices_without_gain_and_mixed_filters(small_banks_on_chip):
     pg.set_sample_rate(SR)
 

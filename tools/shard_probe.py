@@ -22,12 +22,14 @@ for world in [int(w) for w in os.environ.get("PGX_WORLDS", "1,2,4,8").split(",")
     r.start()
     # (15 blocks of warm-up: a small bank's windows of 2, 4, 8 blocks open -- and their buffers are allocated, a hipMalloc
     # of a few hundred MB is milliseconds on some boxes -- before the clock starts; 24 timed blocks = three whole windows)
-    warm = 31 if which == "c4" else 15            # (C4's windows grow to 32 blocks)
+    # PGX_SHARD_REPS: timed blocks (default 24 / 64; a few hundred -- 384, 256: whole windows -- let the chip reach the clock
+    # a stream runs at: the same kernels are 5 - 10 % faster than in a 24-block burst)
+    warm = 63 if which == "c4" else 15            # (C4's windows grow to 32 blocks)
     for i in range(warm):
         root.render(i * block, block)
     device.synchronize()
     t0 = time.perf_counter()
-    reps = 64 if which == "c4" else 24
+    reps = int(os.environ.get("PGX_SHARD_REPS", "0")) or (64 if which == "c4" else 24)
     for i in range(reps):
         keep = root.render((warm + i) * block, block)
     device.synchronize()
