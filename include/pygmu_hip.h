@@ -445,7 +445,9 @@ int pgx_voice_tiles(float *out /* [n] */, int nvoices, int64_t n, const double *
                     const double *saw_state_in, double *saw_state_out /* [nvoices][2] */,
                     const double *biquad_state_in, double *biquad_state_out /* [nvoices][2] */,
                     const float *gain /* NULL, or [nvoices][gain_stride] */, int64_t gain_stride, int64_t warm_frames,
-                    void *workspace /* pgx_voice_tiles_workspace_bytes(nvoices, n, warm_frames) */, int entries_slot);
+                    void *workspace /* pgx_voice_tiles_workspace_bytes(nvoices, n, warm_frames) */, int entries_slot,
+                    int next_entries_slot /* -1, or the other set: the entries of the block that follows this one in the
+                                             stream are made in the launch that adds the rows (from saw_state_out) */);
 
 /* A bank of scalar-parameter SuperSawPEs in one launch, voices summed on chip: the same samples as
  * pgx_blitsaw over batch*nvoices oscillators followed by pgx_supersaw_sum, bit for bit, without the

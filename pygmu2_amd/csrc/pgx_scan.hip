@@ -2529,12 +2529,12 @@ k_voice_tile_pack(double *pack, const double *saw_tables, const double *coef, co
 // vectors of consecutive tiles by a fixed turn -- a tile's advance, reduced exactly), then one thread per tile for the
 // anchors.  advance: the block begins that many frames after the one `saw_state` is the start of (its phase by the same
 // expression k_voice_tiles leaves it with: the entries of the NEXT block can be made while this one is rendered).
-__global__ void __launch_bounds__(256)
-k_voice_tile_entries(double *entries, const double *pack, const double *saw_state, int64_t advance, int ntiles,
-                     int emit_frames, int warm) {
-    constexpr int TT = 15;                                  // tiles per pass (+ the sum at the block's start: 16 rows)
-    __shared__ double part[TT + 1][256];
-    const int v = blockIdx.x, tid = threadIdx.x;
+constexpr int kVtEntryTiles = 15;                           // tiles per pass (+ the sum at the block's start: 16 rows)
+__device__ __forceinline__ void voice_tile_entries_body(double (*part)[256], int v, double *entries, const double *pack,
+                                                        const double *saw_state, int64_t advance, int ntiles,
+                                                        int emit_frames, int warm) {
+    constexpr int TT = kVtEntryTiles;
+    const int tid = threadIdx.x;
     const double *st = pack + (int64_t)v * kVtPack;
     const double inc = st[0], m = st[1], invP = st[3], leak = st[5];
     double phase0 = saw_state[v * 2 + 0];
@@ -2609,6 +2609,13 @@ k_voice_tile_entries(double *entries, const double *pack, const double *saw_stat
         d[2] = sd; d[3] = cd; d[4] = sn; d[5] = cn;
         if (t == 0) { d[0] = 0.0; d[1] = 1.0; d[6] = 0.0; d[7] = 0.0; }
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_voice_tile_entries(double *entries, const double *pack, const double *saw_state, int64_t advance, int ntiles,
+                     int emit_frames, int warm) {
+    __shared__ double part[kVtEntryTiles + 1][256];
+    voice_tile_entries_body(part, blockIdx.x, entries, pack, saw_state, advance, ntiles, emit_frames, warm);
 }
 
 #ifndef PGX_VT_WAVES
@@ -2806,9 +2813,9 @@ k_voice_tiles(double *__restrict__ partial, int64_t partial_stride, int64_t n, i
 }
 
 // out[f] = float32(sum over the groups' rows, in group order)
-__global__ void __launch_bounds__(256)
-k_mix_partials(float *out, const double *partial, int64_t partial_stride, int groups, int64_t n) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void mix_partials_body(int64_t block, float *out, const double *partial, int64_t partial_stride,
+                                                  int groups, int64_t n) {
+    const int64_t f = block * 256 + threadIdx.x;
     if (f >= n) return;
     constexpr int U = 16;
     double acc = 0.0;
@@ -2828,6 +2835,24 @@ k_mix_partials(float *out, const double *partial, int64_t partial_stride, int gr
         for (int u = 0; u < U; ++u) acc += v[u];
     }
     out[f] = (float)acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_mix_partials(float *out, const double *partial, int64_t partial_stride, int groups, int64_t n) {
+    mix_partials_body(blockIdx.x, out, partial, partial_stride, groups, n);
+}
+
+// The rows' sum and, in the same launch, what the tiles of the NEXT block of the stream enter with (from the states this
+// block's k_voice_tiles has just written): two kernels' worth of independent workgroups, one dispatch -- the entries (7 us
+// alone) ride beside the sum instead of behind it on the block's chain.  Workgroups [0, nvoices): entries; the rest: rows.
+__global__ void __launch_bounds__(256)
+k_mix_partials_entries(float *out, const double *partial, int64_t partial_stride, int groups, int64_t n, int nvoices,
+                       double *entries, const double *pack, const double *saw_state, int ntiles, int emit_frames, int warm) {
+    __shared__ double part[kVtEntryTiles + 1][256];
+    if ((int)blockIdx.x < nvoices)
+        voice_tile_entries_body(part, blockIdx.x, entries, pack, saw_state, 0, ntiles, emit_frames, warm);
+    else
+        mix_partials_body((int64_t)blockIdx.x - nvoices, out, partial, partial_stride, groups, n);
 }
 
 // Several workgroups per oscillator pay two launches and the Dirichlet kernel twice: worth it from 3 tiles on.
@@ -4329,7 +4354,7 @@ int pgx_voice_tiles_entries(void *workspace, int slot, int nvoices, int64_t n, c
 
 int pgx_voice_tiles(float *out, int nvoices, int64_t n, const double *tables, const double *saw_state_in,
                     double *saw_state_out, const double *biquad_state_in, double *biquad_state_out, const float *gain,
-                    int64_t gain_stride, int64_t warm_frames, void *workspace, int entries_slot) {
+                    int64_t gain_stride, int64_t warm_frames, void *workspace, int entries_slot, int next_entries_slot) {
     PGX_REQUIRE_INIT();
     if (n <= 0 || nvoices <= 0) return PGX_OK;
     PGX_CHECK_ARG(out && tables && saw_state_in && saw_state_out && biquad_state_in && biquad_state_out && workspace &&
@@ -4342,6 +4367,8 @@ int pgx_voice_tiles(float *out, int nvoices, int64_t n, const double *tables, co
     const VoiceTilesPlan p = voice_tiles_plan(nvoices, n, warm_frames);
     PGX_CHECK_ARG((int64_t)p.tiles * p.groups < ((int64_t)1 << 31), "pgx_voice_tiles: too many tiles");
     PGX_CHECK_ARG(entries_slot >= -1 && entries_slot <= 1, "pgx_voice_tiles: entries_slot is -1 (made here), 0 or 1");
+    PGX_CHECK_ARG(next_entries_slot >= -1 && next_entries_slot <= 1 && (next_entries_slot < 0 || next_entries_slot != (entries_slot < 0 ? 0 : entries_slot)),
+                  "pgx_voice_tiles: next_entries_slot is -1 (none) or the set this block does not read");
     if (entries_slot < 0) {
         const int rc = pgx_voice_tiles_entries(workspace, 0, nvoices, n, tables, saw_state_in, 0, warm_frames);
         if (rc != PGX_OK) return rc;
@@ -4359,8 +4386,16 @@ int pgx_voice_tiles(float *out, int nvoices, int64_t n, const double *tables, co
                            p.groups, p.tiles, p.emit, (int)warm_frames, tables, saw_state_in, saw_state_out,
                            biquad_state_in, biquad_state_out, (const double *)entries, gain, gain_stride);
     PGX_LAUNCH_CHECK("k_voice_tiles");
-    hipLaunchKernelGGL(k_mix_partials, dim3((unsigned)pgx::ceil_div(n, (int64_t)256)), dim3(256), 0, pgx::stream(), out,
-                       (const double *)partial, p.stride, p.groups, n);
+    const unsigned mix_blocks = (unsigned)pgx::ceil_div(n, (int64_t)256);
+    if (next_entries_slot >= 0) {
+        double *next = reinterpret_cast<double *>(static_cast<char *>(workspace) + (size_t)next_entries_slot * p.entries_bytes);
+        hipLaunchKernelGGL(k_mix_partials_entries, dim3(mix_blocks + (unsigned)nvoices), dim3(256), 0, pgx::stream(), out,
+                           (const double *)partial, p.stride, p.groups, n, nvoices, next, tables,
+                           (const double *)saw_state_out, p.tiles, p.emit, (int)warm_frames);
+    } else {
+        hipLaunchKernelGGL(k_mix_partials, dim3(mix_blocks), dim3(256), 0, pgx::stream(), out, (const double *)partial,
+                           p.stride, p.groups, n);
+    }
     PGX_LAUNCH_CHECK("k_mix_partials");
     return PGX_OK;
 }

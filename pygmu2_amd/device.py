@@ -128,7 +128,7 @@ _SIGNATURES = [
     ("pgx_voice_tiles_tables", _I, [_P, _P, _P, _P, _I]),
     ("pgx_voice_tiles_workspace_bytes", _Z, [_I, _L, _L]),
     ("pgx_voice_tiles_entries", _I, [_P, _I, _I, _L, _P, _P, _L, _L]),
-    ("pgx_voice_tiles", _I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I]),
+    ("pgx_voice_tiles", _I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I, _I]),
     ("pgx_supersaw_bank", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P]),
     ("pgx_supersaw_bank_segments", _I, [_I, _L]),
     ("pgx_supersaw_bank_seg", _I, [_P, _L, _I, _I, _L, _I, _D, _P, _P, _P, _P, _P]),

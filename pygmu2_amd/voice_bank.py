@@ -479,7 +479,7 @@ class _BiquadNode(_Node):
     def render_mix(self, start, n, gain=None, streaming=False):
         """The voices' mix (times `gain`, [K][n] float32, voice by voice) as one (n, 1) block.  streaming: (start + n, n)
         is expected next -- what its tiles enter with (the oscillators' phases decide it: pgx_voice_tiles_entries) is made
-        behind this block's mix, off the next block's critical chain."""
+        in the launch that adds this block's rows, off the next block's critical chain."""
         L = lib()
         src = self.children["source"]
         if self.state is None:
@@ -502,13 +502,11 @@ class _BiquadNode(_Node):
             self.tiles_ws = DeviceBuffer((need,), np.uint8)
             slot = -1
         out = DeviceBuffer((n, 1), np.float32)
+        nxt = ((slot if slot >= 0 else 0) ^ 1) if streaming else -1
         check(L.pgx_voice_tiles(out.ptr, self.k, n, self.rot_tables.ptr, src.state.ptr, src.state_alt.ptr,
                                 self.state.ptr, self.state_alt.ptr, ptr(gain), n, self.settle_fine, self.tiles_ws.ptr,
-                                slot), "pgx_voice_tiles")
+                                slot, nxt), "pgx_voice_tiles")
         if streaming:
-            nxt = (slot if slot >= 0 else 0) ^ 1
-            check(L.pgx_voice_tiles_entries(self.tiles_ws.ptr, nxt, self.k, n, self.rot_tables.ptr, src.state_alt.ptr, 0,
-                                            self.settle_fine), "pgx_voice_tiles_entries")
             self.entries_ahead[start + n] = (n, nxt)
         src.state, src.state_alt = src.state_alt, src.state
         self.state, self.state_alt = self.state_alt, self.state
