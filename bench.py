@@ -1235,7 +1235,7 @@ def main():
         result["device"] = device.device_name()
         # the filter kernel as the C2 steps launch it: look-ahead renders `ahead` 1 M-frame steps per launch
         from pygmu2_amd import look_ahead
-        ahead = max(2, min(look_ahead.AHEAD_BLOCKS, look_ahead.AHEAD_FRAMES // 1_000_000)) if look_ahead.enabled() else 1
+        ahead = max(2, min(look_ahead.AHEAD_BLOCKS, look_ahead.frame_cap(2) // 1_000_000)) if look_ahead.enabled() else 1
         # (steady state: a stream's windows are 8, 16, 32, then `ahead` steps long)
         far = (args.warmup + 1000) * 1_000_000
         # (the dominant kernel over 1 000 back-to-back launches after 300: 50 ms -- the clock the chip holds over a stream,

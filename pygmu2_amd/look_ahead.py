@@ -41,6 +41,18 @@ AHEAD_BLOCKS = int(os.environ.get("PGX_LOOK_AHEAD_BLOCKS", "256"))   # ... at mo
                             # graphs in 1024-frame blocks 519 / 544 Msamples/s at 64, 548 / 568 at 128, 581 / 592 at 256) ...
 AHEAD_FRAMES = int(os.environ.get("PGX_LOOK_AHEAD_FRAMES", str(1 << 25)))      # ... and about this many frames (1 M-frame pulls: 32 blocks per window, 128 MB per
                             # channel of every PE in it: C2 3.8 us per step at 2^24, 3.5 at 2^25, 3.3 at 2^26)
+AHEAD_FRAMES_SMALL_GRAPH = int(os.environ.get("PGX_LOOK_AHEAD_FRAMES_SMALL", str(1 << 27)))   # a window root with one or two PEs
+                            # under it holds one or two such buffers, not dozens: 4x the frames (3 - 4 PEs: 2x).  C2 over a stream
+                            # of 20 000 steps: 883 000 Msamples/s at 2^25, 978 000 at 2^26, 1 045 000 at 2^27 (fewer launch ramps
+                            # and warm-up halves per frame, a quarter of the window openings)
+_FRAMES_EXPLICIT = "PGX_LOOK_AHEAD_FRAMES" in os.environ
+
+
+def frame_cap(n_nodes: int) -> int:
+    """Frames per window for a window root with `n_nodes` PEs in its sub-graph (itself included)."""
+    if _FRAMES_EXPLICIT or n_nodes > 4:
+        return AHEAD_FRAMES
+    return max(AHEAD_FRAMES, AHEAD_FRAMES_SMALL_GRAPH if n_nodes <= 2 else AHEAD_FRAMES_SMALL_GRAPH // 2)
 
 STATS = {"window_frames": 0, "windows": 0}     # frames rendered into windows since the process started (bench.py reports
                                                # how many frames a timed region really rendered next to those it counts)
@@ -245,7 +257,7 @@ def render(pe, start: int, duration: int):
     # slow start: a stream that stops after a few blocks has not paid for 64; one that keeps going doubles its
     # window with every refill (8, 16, 32, 64 blocks)
     grow = d.get("_la_grow", FIRST_WINDOW_BLOCKS)
-    blocks = max(2, min(grow, AHEAD_BLOCKS, AHEAD_FRAMES // duration))
+    blocks = max(2, min(grow, AHEAD_BLOCKS, frame_cap(len(nodes)) // duration))
     try:
         big = pe._render(start, duration * blocks)
     except BaseException as exc:

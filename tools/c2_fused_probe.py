@@ -14,7 +14,7 @@ state = device.DeviceBuffer((1, 2), np.float64, zero=True)
 tables = device.DeviceBuffer((lib.pgx_biquad_table_doubles(),), np.float64)
 device.check(lib.pgx_biquad_tables(tables.ptr, coef.ptr, 1))
 w = 2.0 * np.pi * 440.0
-for frames, reps in ((1_000_000, 5), (16_000_000, 5), (33_000_000, 5), (1 << 26, 3)):
+for frames, reps in ((1_000_000, 5), (16_000_000, 5), (33_000_000, 5), (1 << 26, 3), (134_000_000, 3)):
     out = device.DeviceBuffer((frames, 1), np.float32)
     for _ in range(reps):
         device.check(lib.pgx_biquad_sine(out.ptr, 10 ** 9, frames, 44100.0, w, 1.0, 0.0, coef.ptr, tables.ptr, settle, state.ptr, None))

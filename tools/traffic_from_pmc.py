@@ -54,7 +54,7 @@ md = [f"# PMC: HBM traffic of the kernels priced against the HBM roofline, round
       "wide (16 B per lane) coalesced streaming read -> x2 where stated; WRITE_SIZE is exact.", ""]
 
 # ---- C2 fused
-sizes = [1_000_000, 16_000_000, 33_000_000, 1 << 26]
+sizes = [1_000_000, 16_000_000, 33_000_000, 1 << 26, 134_000_000]       # (134 M: a stream's window since the cap grows with small graphs)
 wr_rows = rows_of("c2fused_WRITE_SIZE", "k_biquad_settled<true, true, true")
 fe_rows = rows_of("c2fused_FETCH_SIZE", "k_biquad_settled<true, true, true")
 assert len(wr_rows) == len(sizes), wr_rows          # one cluster of launches per size, ascending
