@@ -1100,6 +1100,13 @@ def flat_keys(result) -> dict:
                     flat[f"{tag}_{k}"] = row[k]
     if isinstance(result.get("roofline_fp64"), dict):
         flat["c2_roofline_fp64_frac"] = result["roofline_fp64"].get("frac")
+    if isinstance(result.get("roofline"), dict) and result["roofline"].get("steps_per_launch"):
+        flat["c2_kernel_steps_per_launch"] = result["roofline"]["steps_per_launch"]
+        flat["c2_kernel_us_per_launch"] = round(result["roofline"]["avg_launch_ms"] * 1e3, 2)
+    if isinstance(result.get("roofline_burst"), dict):
+        flat["c2_roofline_burst_frac"] = result["roofline_burst"].get("frac")
+    if result.get("process_warmup_streams") is not None:
+        flat["c2_process_warmup_streams"] = result["process_warmup_streams"]
     return flat
 
 
@@ -1169,6 +1176,7 @@ def main():
             bench_c2(pg, dist, 2000, 20)
         result["process_warmup"] = (f"{process_warmup} untimed C2 streams of 2 000 steps on other PE objects before the "
                                     f"{args.warmup} warm-up steps" if process_warmup else "none")
+        result["process_warmup_streams"] = process_warmup
         dt, frames = bench_c2(pg, dist, args.steps, args.warmup)
         name = "C2: BiquadPE(SinePE(440), lowpass 1 kHz, q 0.707), 44.1 kHz mono, render(start, 1_000_000) per step"
         units = frames * args.steps * n_gpus
