@@ -1935,7 +1935,7 @@ k_supersaw_bank(float *out, int64_t out_stride, int nv, int64_t n, int channels,
 // against the voices rendered one by one, 1e-5 against the oracle), not to the bits of k_blitsaw.
 // Time segments as in k_supersaw_bank (closed-form integrator level on entering a later segment).
 constexpr int kSswT = 16;
-// per voice: [0] inc, M, P, 1/P, M/P, leak, 2*amp, (spare); [8] sin/cos(pi inc), sin/cos(M pi inc);
+// per voice: [0] inc, M, P, 1/P, M/P, leak, 2*amp, [7] 4 sin^2(pi inc / 2); [8] sin/cos(pi inc), sin/cos(M pi inc);
 // [12] (leak^16)^(2^k), k = 0..5; [18] leak^(16*64); [19] 2 cos(M pi inc); [20] sin/cos of a 4096-frame tile's advance
 // pi*4096*inc and of M times that (the angles reduced exactly before the sincos); [24] lane powers [3][64]
 constexpr int kSswTabDoubles = 24 + 3 * 64;
@@ -1970,7 +1970,12 @@ k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_para
         if (lane == 0) {
             const SawRot r = saw_rot(kt);
             tab[0] = kt.inc; tab[1] = kt.m; tab[2] = kt.P; tab[3] = kt.invP; tab[4] = kt.m / kt.P;
-            tab[5] = pt.leak; tab[6] = 2.0 * pt.amp; tab[7] = r.usable ? 1.0 : 0.0;
+            tab[5] = pt.leak; tab[6] = 2.0 * pt.amp;
+            {                                                   // 4 sin^2(d / 2), d = pi inc: the denominators' difference recurrence
+                double sh_, ch_;
+                pgx::pgx_sincos_bounded(0.5 * kPi * kt.inc, sh_, ch_);
+                tab[7] = 4.0 * sh_ * sh_;
+            }
             tab[8] = r.sd; tab[9] = r.cd; tab[10] = r.sm; tab[11] = r.cm;
 #pragma unroll
             for (int k = 0; k < 6; ++k) tab[12 + k] = lamp[k];
@@ -1992,34 +1997,35 @@ k_supersaw_wide_tables(double *tables, int nv, double sr, const pgx_blitsaw_para
 }
 
 // xb[j] = blit - 1/P for T consecutive frames from the anchors (sd, cd) = sincos(theta), (sn, cn) = sincos(M theta).
-// Per frame: the denominator sin(theta_j) by rotation (4 operations; its absolute error must stay ~1e-15 because the
-// quotient divides by it where it is small), the numerator sin(M theta_j) / P by the three-term recurrence
+// Per frame: the denominator sin(theta_j) by the difference form of its recurrence -- s[j+1] = s[j] + d[j], d[j+1] = d[j] -
+// alpha s[j+1] with alpha = 4 sin^2(d/2) and d[0] = cos(theta) sin d - (alpha/2) sin(theta): 2 operations where the
+// rotation of (sin, cos) it replaced (end of round 4) takes 4, and as accurate -- 2e-15 after 15 steps for every step angle
+// up to pi/2, measured against the rotation's 2e-15 (its absolute error must stay ~1e-15 because the quotient divides
+// by it where it is small; the plain three-term form 2 cos d s[j] - s[j-1] loses digits for small d) --, the numerator
+// sin(M theta_j) / P by the three-term recurrence
 // n[j+1] = 2 cos(M d) n[j] - n[j-1] (1 operation; M d = M pi inc lies within 2 d of pi/2, so the recurrence does not
 // amplify its roundings: ~1e-15 after 15 steps), the quotient with one Newton step on the reciprocal and no residual
 // correction (2^-48), one reciprocal per pair of frames.  16 instruction slots per frame where saw_dirichlet_rot_body has 30.
 // GUARD as there: the singularity test is only OR-ed together, a wave that met it runs the frames again with selects.
 template <int T, bool GUARD>
 __device__ __forceinline__ unsigned long long saw_rot_frames(double sd, double cd, double sn, double cn, double invP,
-                                                             double m_over_p, double rsd, double rcd, double rsm,
+                                                             double m_over_p, double rsd, double alpha, double rsm,
                                                              double rcm, double two_cm, double (&xb)[T]) {
     static_assert(T % 2 == 0, "frames are taken in pairs");
     unsigned long long any = 0ull;
     double n_prev = invP * sn;
     double n_cur = invP * __builtin_fma(sn, rcm, cn * rsm);
+    double dd = __builtin_fma(cd, rsd, -((0.5 * alpha) * sd));        // sin(theta + d) - sin(theta)
 #pragma unroll
     for (int j = 0; j < T; j += 2) {
-        // two frames: the denominators sin(theta_j), sin(theta_j+1) by rotation, the numerators by the recurrence
+        // two frames: the denominators sin(theta_j), sin(theta_j+1) by the difference recurrence, the numerators by theirs
         if (j) {
-            const double s2 = __builtin_fma(sd, rcd, cd * rsd);
-            cd = __builtin_fma(cd, rcd, -(sd * rsd));
-            sd = s2;
+            sd = sd + dd;
+            dd = __builtin_fma(-alpha, sd, dd);
         }
         const double sd0 = sd;
-        {
-            const double s2 = __builtin_fma(sd, rcd, cd * rsd);
-            cd = __builtin_fma(cd, rcd, -(sd * rsd));
-            sd = s2;
-        }
+        sd = sd + dd;
+        dd = __builtin_fma(-alpha, sd, dd);
         const double sd1 = sd;
         double num0, num1;
         if (j == 0) {
@@ -2164,7 +2170,7 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                 const double inc = tb[0], m = tb[1], invP = tb[3], m_over_p = tb[4], two_cm = tb[19];
                 leak[u] = tb[5];
                 amp2[u] = tb[6];
-                const double rsd = tb[8], rcd = tb[9], rsm = tb[10], rcm = tb[11];
+                const double rsd = tb[8], alpha = tb[7], rsm = tb[10], rcm = tb[11];
                 double lamp[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) lamp[k] = tb[12 + k];
@@ -2191,9 +2197,9 @@ k_supersaw_wide(float *out, int64_t out_stride, int nv, int64_t n, int channels,
                     cn = __builtin_fma(a.cn, tcm, -(a.sn * tsm));
                 }
                 if (anc != nullptr) *anc = SswAnchor{sd, cd, sn, cn};
-                const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]);
+                const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, alpha, rsm, rcm, two_cm, xb[u]);
                 if (PGX_COLD(met != 0ull))
-                    saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb[u]);
+                    saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, alpha, rsm, rcm, two_cm, xb[u]);
                 double f = 0.0;
 #pragma unroll
                 for (int j = 0; j < T; ++j) f = __builtin_fma(leak[u], f, xb[u][j]);   // feeds the scan only
@@ -2297,7 +2303,7 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
     // uniform loads: the voice's constants live in scalar registers
     const double *st = saw_tables + (int64_t)inst * kSswTabDoubles;
     const double inc = st[0], m = st[1], invP = st[3], m_over_p = st[4], leak = st[5], amp2 = st[6];
-    const double rsd = st[8], rcd = st[9], rsm = st[10], rcm = st[11], two_cm = st[19];
+    const double rsd = st[8], alpha = st[7], rsm = st[10], rcm = st[11], two_cm = st[19];
     double lamp[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) lamp[k] = st[12 + k];
@@ -2388,9 +2394,9 @@ k_blitsaw_biquad_wide(float *out, int64_t out_stride, int64_t n, const double *s
         }
         const double sd = a_sd, cd = a_cd, sn = a_sn, cn = a_cn;
         double xb[T];
-        const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+        const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, alpha, rsm, rcm, two_cm, xb);
         if (PGX_COLD(met != 0ull))
-            saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+            saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, alpha, rsm, rcm, two_cm, xb);
         double e = 0.0;
 #pragma unroll
         for (int j = 0; j < T; ++j) e = __builtin_fma(leak, e, xb[j]);           // feeds the scan only
@@ -2689,11 +2695,11 @@ k_voice_tiles(double *__restrict__ partial, int64_t partial_stride, int64_t n, i
         const double sd = __builtin_fma(en[2], r_c, en[3] * r_s), cd = __builtin_fma(en[3], r_c, -(en[2] * r_s));
         const double sn = __builtin_fma(en[4], r_cm, en[5] * r_sm), cn = __builtin_fma(en[5], r_cm, -(en[4] * r_sm));
         const double inc = cb[0], invP = vt_uniform(cb[3]), m_over_p = cb[4], leak = vt_uniform(cb[5]), amp2 = cb[6];
-        const double rsd = vt_uniform(cb[8]), rcd = vt_uniform(cb[9]), rsm = cb[10], rcm = cb[11], two_cm = vt_uniform(cb[19]);
+        const double rsd = vt_uniform(cb[8]), alpha = vt_uniform(cb[7]), rsm = cb[10], rcm = cb[11], two_cm = vt_uniform(cb[19]);
         double xb[T];
-        const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+        const unsigned long long met = saw_rot_frames<T, false>(sd, cd, sn, cn, invP, m_over_p, rsd, alpha, rsm, rcm, two_cm, xb);
         if (PGX_COLD(met != 0ull))
-            saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, rcd, rsm, rcm, two_cm, xb);
+            saw_rot_frames<T, true>(sd, cd, sn, cn, invP, m_over_p, rsd, alpha, rsm, rcm, two_cm, xb);
         double e = 0.0;
 #pragma unroll
         for (int j = 0; j < T; ++j) e = __builtin_fma(leak, e, xb[j]);           // feeds the scan only
@@ -2779,7 +2785,7 @@ k_voice_tiles(double *__restrict__ partial, int64_t partial_stride, int64_t n, i
             double xo[T];                                         // (the oscillator's frames again, from the anchors again:
             const double o_sd = __builtin_fma(en[2], rt[1], en[3] * rt[0]), o_cd = __builtin_fma(en[3], rt[1], -(en[2] * rt[0]));   // kept until
             const double o_sn = __builtin_fma(en[4], rt[3], en[5] * rt[2]), o_cn = __builtin_fma(en[5], rt[3], -(en[4] * rt[2]));   // here they cost
-            saw_rot_frames<T, true>(o_sd, o_cd, o_sn, o_cn, cb[3], cb[4], cb[8], cb[9], cb[10], cb[11], cb[19], xo);               // every thread 40 registers)
+            saw_rot_frames<T, true>(o_sd, o_cd, o_sn, o_cn, cb[3], cb[4], cb[8], cb[7], cb[10], cb[11], cb[19], xo);               // every thread 40 registers)
 #pragma unroll
             for (int j = 0; j < T; ++j) {
                 const double yn = __builtin_fma(leak, yl, xo[j]);
