@@ -42,9 +42,9 @@ MIN_VOICES = 4
 BANK_WINDOWS = True           # a small bank streamed in equal blocks: 2, 4, 8 blocks per render, handed out as rows (VoiceBank)
 BANK_WINDOWS_ANY_ROOT = os.environ.get("PGX_BANK_WINDOWS_ANY_ROOT", "0") == "1"     # experiments (C5: measured slower)
 BANK_WINDOW_FIRST = 2
-BANK_WINDOW_MAX = 8
+BANK_WINDOW_MAX = int(os.environ.get("PGX_BANK_WINDOW_MAX", "8"))
 BANK_WINDOW_FRAMES = 1 << 20
-BANK_WINDOW_MAX_VOICES = 256  # (a bank that fills the chip gains nothing: its launches are long)
+BANK_WINDOW_MAX_VOICES = int(os.environ.get("PGX_BANK_WINDOW_MAX_VOICES", "256"))  # (a bank that fills the chip gains nothing: its launches are long)
 LADDER_WINDOWS = True         # a ladder bank directly under the mix, streamed in equal blocks: several blocks per launch
 LADDER_WINDOW_FIRST = 2       # ... 2, then 4, 8, 16, 32 blocks (a lane of k_ladder_segments pays its 1024-sample warm-up once per
                               # launch: C4 over a stream 0.0675 ms per block with windows up to 8, 0.0591 up to 16, 0.0497 up to 32
@@ -62,9 +62,14 @@ PIPELINE_FULL_SUPERSAW_BANK = True    # ... and for a bank that fills the chip (
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
 VOICE_TILES = os.environ.get("PGX_VOICE_TILES", "1") != "0"   # BlitSaw -> Biquad [-> x envelope] voices mixed on chip (pgx_voice_tiles)
 VOICE_TILES_MIN_FRAMES = 4096
-VOICE_TILES_MIN_VOICES = int(os.environ.get("PGX_VOICE_TILES_MIN_VOICES", "192"))   # (below, the envelope walk -- which the on-chip mix
-                             # waits for BEFORE the voices, the layered path only before the mix -- is the block's critical chain: 128 voices
-                             # 62 us per block against 60, 64 voices 56 against 52; 256 voices 68 against 75, 512 voices 111 against 119)
+VOICE_TILE_WINDOWS = os.environ.get("PGX_VOICE_TILE_WINDOWS", "1") != "0"    # ... in windows of 2, 4, 8 blocks: the stream synchronisations,
+                             # the edge searches and the small launches of a block are per window then, and the envelopes of the NEXT
+                             # window are walked beside this one's voices (C5: 94 -> 83 us per block)
+VOICE_TILES_MIN_VOICES = int(os.environ.get("PGX_VOICE_TILES_MIN_VOICES", "16"))   # (192 while the mix ran block by block: the
+                             # envelope walk, which the on-chip mix waits for BEFORE the voices, was then the block's critical chain for
+                             # smaller banks -- 64 voices 56 us per block against 52.  In windows: 8 voices 33 against 45, 64 voices 40
+                             # against 49, 128: 48 against 56, 256: 63 against 72, 512: 83 against 106.  Smaller banks keep the kernels
+                             # that are bit-identical to the per-voice path)
 FUSE_GAIN_IN_CHAIN = False   # ... and multiplied into the voices by the oscillator -> filter kernel: measured, no gain (render_mix)
 EARLY_WALK_MAX_VOICES = int(os.environ.get("PGX_EARLY_WALK_MAX", "256"))  # ... started at once (not behind the block's oscillators) for banks up to this size
 ENVELOPE_AHEAD = True        # a bank's AdsrGatedPE(PeriodicGate) envelopes one block ahead on the side stream (render_mix)
@@ -107,7 +112,7 @@ class _Node:
     # ---- what VoiceBank's windows need of a node: its carried state by name, and a way to come to rest
     _STATE = ()                  # attributes (DeviceBuffers, numbers, None) that make up the carried state
 
-    def quiesce(self) -> None:
+    def quiesce(self, keep=None) -> None:
         """Anything rendered ahead of the stream is dropped: the states are where the last block handed out left them."""
 
     def snapshot(self) -> dict:
@@ -247,7 +252,7 @@ class _SuperSawNode(_Node):
 
     _STATE = ("state", "last_end")
 
-    def quiesce(self):
+    def quiesce(self, keep=None):
         self._forget_ahead(restore=True)
         if self.ahead_bank is not None:
             self._forget_bank_ahead(restore=True)
@@ -457,8 +462,9 @@ class _BiquadNode(_Node):
                 and src.closed_form_ok and n >= VOICE_TILES_MIN_FRAMES
                 and 0 < self.settle_fine <= lib().pgx_voice_tiles_max_warm())
 
-    def quiesce(self):
-        self.entries_ahead = {}
+    def quiesce(self, keep=None):
+        mine = self.entries_ahead.get(keep[0]) if keep is not None else None
+        self.entries_ahead = {keep[0]: mine} if mine is not None and mine[0] == keep[1] else {}
 
     def _mix_tables(self):
         L = lib()
@@ -603,7 +609,7 @@ class _LadderNode(_Node):
 
     _STATE = ("state",)
 
-    def quiesce(self):
+    def quiesce(self, keep=None):
         self._settle_window()
         self._forget_ahead(restore=True)
 
@@ -826,7 +832,11 @@ class _GateNode(_Node):
 class _AdsrGatedNode(_Node):
     _STATE = ("state", "last")
 
-    def quiesce(self):
+    def quiesce(self, keep=None):
+        """keep = (start, n): the render that follows -- envelopes walked ahead for exactly that render stay (they were
+        made from `state`, which they leave alone: a snapshot taken now is the state before them)."""
+        if keep is not None and self.ahead is not None and self.ahead[:2] == tuple(keep):
+            return
         self.forget_ahead()
 
     def __init__(self, pes, children):
@@ -1147,9 +1157,10 @@ class VoiceBank:
         # 62 -> 42 for 128.  Not 256 and more -- rendered one block ahead already, a window ahead is too much thrown away
         # when the stream ends: 97 -> 155 us; not the C5 graph -- its envelope walk and mixes do not shrink with the
         # block, 56 -> 93 us for 64 voices.  A ladder root has windows of its own.)
-        if (BANK_WINDOWS and streaming and self.k <= BANK_WINDOW_MAX_VOICES and duration >= 4096
+        on_chip = VOICE_TILE_WINDOWS and self._mixes_on_chip(duration)
+        if (BANK_WINDOWS and streaming and (self.k <= BANK_WINDOW_MAX_VOICES or on_chip) and duration >= 4096
                 and (isinstance(self.root, _SuperSawNode) and not self.root.fused() or BANK_WINDOWS_ANY_ROOT
-                     or self.mix_windows)
+                     or self.mix_windows or on_chip)
                 and not lib().pgx_stream_is_forked()):
             # (a ladder root -- a rank's share of C4 -- takes the ladder bank's longer windows: its lanes' warm-up does
             # not shrink with the share, so the fewer instances a rank owns the more of a short window is warm-up)
@@ -1159,7 +1170,7 @@ class VoiceBank:
                 self.grow = min(self.grow * 2, LADDER_WINDOW_MAX if ladder_root else BANK_WINDOW_MAX)
                 nodes = self._nodes()
                 for node in nodes:
-                    node.quiesce()
+                    node.quiesce(keep=(start, duration * blocks))
                 snaps = [(node, node.snapshot()) for node in nodes if node._STATE]
                 big = self._render_mix_now(start, duration * blocks)
                 from . import look_ahead as _look_ahead
@@ -1172,6 +1183,13 @@ class VoiceBank:
         elif not streaming:
             self.grow = BANK_WINDOW_FIRST
         return self._render_mix_now(start, duration)
+
+    def _mixes_on_chip(self, n: int) -> bool:
+        """The voices of this bank are added on chip (pgx_voice_tiles) for blocks of n frames."""
+        root = self.root
+        if isinstance(root, _GainNode) and root.gains is None:
+            root = root.children["source"]
+        return isinstance(root, _BiquadNode) and root.mixes_on_chip(n)
 
     def _supersaw_pipelined(self, start: int, n: int) -> Snippet:
         """A bank of SuperSawPEs under the mix (a rank's share of a sharded mix: 64 instances at G = 8 -- or all 512).
