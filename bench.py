@@ -1227,7 +1227,8 @@ def main():
         # collectives: every rank takes part.  The sharded mixes ride along in the default line.
         # (streams of a few hundred blocks -- 40 - 60 ms of device time: over 50 blocks the chip has not yet reached the clock
         # a stream runs at, and the same kernels took 5 - 7 % longer: DESIGN 7)
-        result["voice_mix"] = mix_entry(pg, dist, "c5", 400, 40, with_cpu and dist.rank == 0)
+        # (C5 renders in windows of 2, 4, 8 blocks since its voices are mixed on chip: 384 after 47, as for the SuperSaw mix below)
+        result["voice_mix"] = mix_entry(pg, dist, "c5", 384, 47, with_cpu and dist.rank == 0)
         # (384 blocks after 47: a rank's share of a sharded run renders windows of 2, 4, 8, 8, ... blocks from the second
         # block on and reduces each in one collective -- the warm-up ends on a window's last block and holds the first
         # 8-block collectives, the timed region is 48 whole windows: 384 blocks rendered for the 384 counted)

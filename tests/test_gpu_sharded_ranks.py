@@ -1,7 +1,8 @@
 """GPU: two and three REAL ranks (processes) of a sharded mix on one card, exchanging through gloo on host payloads --
 the rank logic of ShardedMixPE with the device banks underneath: every rank pulls the same random sequence (streams of
 equal blocks, seeks, steps back, odd lengths), the SuperSaw and SuperSaw -> ladder shares render windows of 2, 4, 8
-blocks and reduce each window in ONE collective, C5 shares reduce block by block -- and every rank ends up with the full
+blocks and reduce each window in ONE collective, as do C5 shares of 16 voices and more (voices mixed on chip); smaller C5
+shares reduce block by block -- and every rank ends up with the full
 mix.  A rank that issued a different sequence of collectives (another size, one more, one less) would fail or hang gloo:
 the run itself is the check that all ranks decide alike."""
 
@@ -68,7 +69,7 @@ def _pulls(rng):
 
 
 @pytest.mark.parametrize("world,kind,total,seed", [(2, "supersaw", 48, 1), (3, "supersaw", 40, 2), (2, "c4", 12, 3),
-                                                   (3, "c5", 30, 4)])
+                                                   (3, "c5", 30, 4), (3, "c5", 60, 5), (2, "c5", 70, 6)])
 def test_every_rank_gets_the_full_mix(tmp_path, world, kind, total, seed):
     import pygmu2_amd as pg
     from pygmu2_amd import voice_bank
@@ -118,7 +119,8 @@ def test_every_rank_gets_the_full_mix(tmp_path, world, kind, total, seed):
         assert got.shape == want.shape
         assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5 * peak, r_
         assert np.array_equal(np.load(tmp_path / f"sizes{r_}.npy"), sizes0)          # the same collectives, in the same order
-    if kind in ("supersaw", "c4"):
+    if kind in ("supersaw", "c4") or (kind == "c5" and total // world >= voice_bank.VOICE_TILES_MIN_VOICES):
+        # (C5 shares of 16 voices and more mix their voices on chip, in windows: one collective each, like the others)
         n = max(set(m for _, m in pulls), key=[m for _, m in pulls].count)
         assert int(sizes0.max()) >= 4 * n, sizes0                                    # windows were reduced whole
     else:
