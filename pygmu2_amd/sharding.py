@@ -308,13 +308,14 @@ class ShardedMixPE(ProcessingElement):
             # Round 4: banks whose voices are mixed on chip (C5: GainPE(BiquadPE(BlitSawPE), gain=<envelope>)) run in
             # windows too (voice_bank.VOICE_TILE_WINDOWS).  Whether a bank takes that path is a matter of its voices'
             # parameters -- every oscillator wide-capable with a closed-form carry, every filter settling inside a tile --
-            # and of its size; a rank answers for ALL inputs (a bank of all of them, built once and dropped: if every voice
-            # qualifies, every rank's share does) and for the smallest share.
+            # and of its size; a rank answers for ALL inputs (voice_bank.on_chip_mix_rule, host-side: if every voice qualifies,
+            # every rank's share does) and for the smallest share.
             if (not self._windows and WINDOW_COLLECTIVES and vb.BANK_WINDOWS and not vb.BANK_WINDOWS_ANY_ROOT and vb.VOICE_TILES
                     and vb.VOICE_TILE_WINDOWS and n // world >= max(vb.MIN_VOICES, vb.VOICE_TILES_MIN_VOICES)
                     and sig is not None and sig[0] in ("gain_pe", "biquad")):
-                bank = vb.try_build_bank(self._all_inputs)
-                self._windows = bool(bank is not None and bank._mixes_on_chip(vb.VOICE_TILES_MIN_FRAMES))
+                seen = set()
+                self._windows = bool(all(vb._signature(pe) == sig and vb._collect_ids(pe, seen) for pe in self._all_inputs)
+                                     and vb.on_chip_mix_rule(self._all_inputs))
         return self._windows
 
     def _fold(self, *words) -> None:

@@ -62,6 +62,7 @@ PIPELINE_FULL_SUPERSAW_BANK = True    # ... and for a bank that fills the chip (
 PIPELINE_SUPERSAW_BANK = False  # the same overlap for the voices-summed-on-chip bank: measured slower (render_mix)
 VOICE_TILES = os.environ.get("PGX_VOICE_TILES", "1") != "0"   # BlitSaw -> Biquad [-> x envelope] voices mixed on chip (pgx_voice_tiles)
 VOICE_TILES_MIN_FRAMES = 4096
+VOICE_TILES_MAX_WARM = 2048  # pgx_voice_tiles_max_warm(): a filter has to settle (every entry of A^warm below 2^-90) within this many frames
 VOICE_TILE_WINDOWS = os.environ.get("PGX_VOICE_TILE_WINDOWS", "1") != "0"    # ... in windows of 2, 4, 8 blocks: the stream synchronisations,
                              # the edge searches and the small launches of a block are per window then, and the envelopes of the NEXT
                              # window are walked beside this one's voices (C5: 94 -> 83 us per block)
@@ -460,7 +461,7 @@ class _BiquadNode(_Node):
         src = self.children["source"]
         return (VOICE_TILES and isinstance(src, _BlitSawNode) and src.ch == 1 and self.k >= VOICE_TILES_MIN_VOICES and src.wide()
                 and src.closed_form_ok and n >= VOICE_TILES_MIN_FRAMES
-                and 0 < self.settle_fine <= lib().pgx_voice_tiles_max_warm())
+                and 0 < self.settle_fine <= VOICE_TILES_MAX_WARM)
 
     def quiesce(self, keep=None):
         mine = self.entries_ahead.get(keep[0]) if keep is not None else None
@@ -478,6 +479,7 @@ class _BiquadNode(_Node):
             self.tables = DeviceBuffer((self.k, L.pgx_biquad_table_doubles()), np.float64)
             check(L.pgx_biquad_tables(self.tables.ptr, self.coef.ptr, self.k), "pgx_biquad_tables")
         if self.rot_tables is None:
+            assert L.pgx_voice_tiles_max_warm() == VOICE_TILES_MAX_WARM
             self.rot_tables = DeviceBuffer((L.pgx_voice_tiles_table_bytes(self.k),), np.uint8)
             check(L.pgx_voice_tiles_tables(self.rot_tables.ptr, saw_tables.ptr, self.coef.ptr, self.tables.ptr, self.k),
                   "pgx_voice_tiles_tables")
@@ -1007,6 +1009,39 @@ class _GainNode(_Node):
 
 
 # ------------------------------------------------------------------------------------ builder
+def on_chip_mix_rule(pes) -> bool:
+    """Host-only (no device, no bank): would a bank of these voices -- or of any subset of at least VOICE_TILES_MIN_VOICES of
+    them -- mix its voices on chip (_BiquadNode.mixes_on_chip, block length permitting)?  ShardedMixPE asks this of ALL the
+    inputs of a sharded mix on every rank: the conditions are per voice, so what holds for all holds for every rank's share."""
+    if not (VOICE_TILES and WIDE_SUPERSAW and pes):
+        return False
+    chains = []
+    for pe in pes:
+        if isinstance(pe, GainPE):
+            if not pe._gain_is_pe or pe._gain.channel_count() != 1:
+                return False
+            pe = pe._source
+        if not isinstance(pe, BiquadPE) or pe._freq_is_pe or pe._q_is_pe:
+            return False
+        saw = pe._source
+        if not isinstance(saw, BlitSawPE) or saw.inputs() or saw._channels != 1:
+            return False
+        chains.append((saw, pe))
+    sr = float(pes[0].sample_rate)
+    rec = np.zeros(len(chains), dtype=_dev.BLITSAW_PARAMS)
+    for i, (saw, _) in enumerate(chains):
+        for key, v in saw._scalar_params().items():
+            rec[i][key] = v
+    if not (np.all(rec["m"] < 0.0) and np.all(rec["leak"] > 0.0) and np.all(rec["leak"] <= 0.9999)
+            and np.all(rec["freq"] >= 1.0) and wide_oscillators_ok(rec, sr)):        # (_BlitSawNode.closed_form_ok, .wide_ok)
+        return False
+    for _, bq in chains:
+        c = rbj_coefficients(bq._mode, bq._frequency, bq._q, bq._gain_db, sr)
+        if not settle_frames(c[3], c[4]) or not 0 < settle_frames_fine(c[3], c[4]) <= VOICE_TILES_MAX_WARM:
+            return False
+    return True
+
+
 def _signature(pe):
     """Structural key of a voice tree, or None when the tree cannot be batched."""
     if pe.extent() != Extent(None, None):

@@ -73,8 +73,14 @@ def test_every_rank_answers_the_window_question_alike(n_voices, world, expected)
     voices = [supersaw_voice(pg, i) for i in range(n_voices)]
     answers = {ShardedMixPE(voices, rank, world)._whole_windows() for rank in range(world)}
     assert answers == {expected}
+    # C5-like voices: a share that mixes its voices on chip (16 voices and more, every filter settling inside a tile)
+    # renders in windows and reduces each whole; smaller shares and filters that ring do not -- answered from all inputs
     other = [c5_voice(pg, i) for i in range(64)]
-    assert {ShardedMixPE(other, rank, 4)._whole_windows() for rank in range(4)} == {False}
+    assert {ShardedMixPE(other, rank, 4)._whole_windows() for rank in range(4)} == {True}
+    assert {ShardedMixPE(other[:60], rank, 4)._whole_windows() for rank in range(4)} == {False}        # 15 voices a rank
+    ringing = other[:63] + [pg.GainPE(pg.BiquadPE(pg.BlitSawPE(440.0), 500.0, 400.0),
+                                      gain=pg.AdsrGatedPE(pg.PeriodicGate(2.0, 0.5), 0.01, 0.1, 0.7, 0.2))]
+    assert {ShardedMixPE(ringing, rank, 4)._whole_windows() for rank in range(4)} == {False}           # one voice's Q 400
 
 
 @pytest.mark.parametrize("kind", ["count", "history"])
