@@ -957,11 +957,24 @@ int adsr_launch(float *out, int64_t out_stride, const float *ctl, int64_t ctl_st
     static const int par_max_batch = getenv("PGX_ADSR_PAR_MAX_BATCH") ? atoi(getenv("PGX_ADSR_PAR_MAX_BATCH")) : kParWalkBatch;
     if (MODE != 1 && (par_on || chunk_stride) && batch <= par_max_batch &&
         pgx::ceil_div(w.nchunks, kGroupChunks) <= kParMaxGroups)
+    {
+        // sixteen waves per envelope for small banks (a rank's share of a sharded mix): a 65 536-frame chunk of C5's
+        // envelopes has 7 - 11 starts, with eight waves some walk two stretches one after the other while most of the chip
+        // idles -- 64 envelopes in windows 39.7 -> 36.4 us per block; 128 envelopes: no gain.  PGX_ADSR_PAR_WAVES16_UPTO
+        static const int many = getenv("PGX_ADSR_PAR_WAVES16_UPTO") ? atoi(getenv("PGX_ADSR_PAR_WAVES16_UPTO")) : 64;
+        if (batch <= many && !chunk_stride)
+            hipLaunchKernelGGL(k_adsr_walk_par<16>, dim3(batch), dim3(16 * 64), 0, pgx::stream(), out,
+                               out_stride, batch, start, n, w.nchunks, w.gwords, params,
+                               (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
+                               (const float *)w.last_gate, (const double *)state, state_out, chunk_stride ? 1 : 0,
+                               skip_if_zero);
+        else
         hipLaunchKernelGGL(k_adsr_walk_par<kParWaves>, dim3(batch), dim3(kParWaves * 64), 0, pgx::stream(), out,
                            out_stride, batch, start, n, w.nchunks, w.gwords, params,
                            (const unsigned long long *)w.masks, (const unsigned long long *)w.group_bits,
                            (const float *)w.last_gate, (const double *)state, state_out, chunk_stride ? 1 : 0,
                            skip_if_zero);
+    }
     else if (batch <= kWideWalkBatch)
         hipLaunchKernelGGL((k_adsr_walk<MODE == 1, 4>), dim3(batch), dim3(256), 0, pgx::stream(), out, out_stride,
                            batch, start, n, w.nchunks, w.gwords, params, (const unsigned long long *)w.masks,
