@@ -8,7 +8,7 @@ import bench
 import pygmu2_amd as pg
 res = {}
 for rep in range(3):
-    for frames, launches in ((33_000_000, 60), (1 << 26, 30), (16_000_000, 60)):
-        r = bench.biquad_sine_roofline(pg, frames, launches, 10 ** 9)
+    for frames, launches in ((134_000_000, 200), (33_000_000, 300), (1 << 26, 200), (16_000_000, 300)):      # (streams: the chip at its held clock)
+        r = bench.biquad_sine_roofline(pg, frames, launches, 10 ** 9, warm=50)
         res.setdefault(frames, []).append(r["avg_launch_ms"] * 1e3)
 print(os.environ.get("PGX_LIB_PATH", "default build"), {k: round(float(np.median(v)), 2) for k, v in res.items()})
