@@ -809,6 +809,14 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
     const M2 mlane = load_m2(tb + 28 + 4 * lane);
     const M2 m16 = load_m2(tb + 28 + 4 * ((lane & 15) + 1));
     const M2 m32 = load_m2(tb + 28 + 4 * ((lane & 31) + 1));
+    // SINE: the first rows of A^j (pass 2) live in LDS, read as broadcasts where they are used.  As 32 uniform values in
+    // scalar registers they did not fit beside the scan's matrices: the compiler parked them in the lanes of a vector
+    // register and fetched them back with 64 v_readlane per tile -- a sixth of the loop's vector instructions (end of round 4)
+    __shared__ __attribute__((aligned(16))) double rows_lds[SINE ? 2 * kBqT : 2];
+    if (SINE) {
+        if (tid < 2 * kBqT) rows_lds[tid] = tb[kBqRowsAt + tid];
+        __syncthreads();
+    }
 
     int image = 0;
 #pragma nounroll
@@ -895,7 +903,7 @@ k_biquad_settled(float *__restrict__ out, int64_t out_stride, const float *__res
                     // the zero-state outputs of pass 1 plus what the carried state adds, (A^j zin).x: two
                     // multiply-adds per frame instead of the recurrence again (the sine chain is within the rounding
                     // noise of the reference's phase anyway; the plain filter below keeps scipy's operation order)
-                    const double *rows = tb + kBqRowsAt;          // uniform: scalar loads
+                    const double *rows = rows_lds;               // (LDS broadcasts: see above)
 #pragma unroll
                     for (int j = 0; j < kBqT; ++j)
                         yf[j] = (float)__builtin_fma(rows[2 * j], zin.x, __builtin_fma(rows[2 * j + 1], zin.y, yz[j]));
