@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <string>
 
@@ -239,11 +240,16 @@ __device__ __forceinline__ void pgx_sincos(double x, double &sn, double &cs) {
 }
 #endif
 
-// Grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
+// Grid size for a grid-stride elementwise kernel: a workgroup per `block` items, at most 128 per CU (PGX_GRID_CAP).
+// (8 per CU until the end of round 4 -- enough to fill the chip, but a launch of a look-ahead window's size then walks its
+// buffer in 2 048 strided runs, which the memory system takes slower than many short workgroups each writing ONE contiguous
+// piece: fill 134 M floats 4.7 -> 5.9 TB/s, gain 5.0 -> 5.7; at 11 M frames -- a 256-block window of 44 100 frames -- no
+// difference.  tools/microbench/fill_rate.hip: hipMemsetAsync 6.5 TB/s, one 16 KB chunk per workgroup 6.0, the strided loop 4.6)
 inline int grid_for(int64_t work_items, int block) {
+    static const int per_cu = getenv("PGX_GRID_CAP") ? atoi(getenv("PGX_GRID_CAP")) : 128;
     int64_t g = ceil_div(work_items, block);
     if (g < 1) g = 1;
-    if (g > kNumCU * 8) g = kNumCU * 8;
+    if (g > (int64_t)kNumCU * per_cu) g = (int64_t)kNumCU * per_cu;
     return (int)g;
 }
 
