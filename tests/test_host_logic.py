@@ -475,3 +475,33 @@ def test_fft_convolution_sizes():
     # 96 000 stereo frames, 65 536 taps: two overlap-save blocks per channel -> two packed transforms of 2^17 complex doubles
     need = lib.pgx_convolve_fft_workspace_bytes(96_000, 65536, 2, 131072)
     assert need >= 2 * 131072 * 16 + 65535 * 2 * 4
+
+
+def test_look_ahead_frame_cap_grows_only_for_small_graphs(monkeypatch):
+    """A window root with one or two PEs under it takes four times the frames (one or two buffers of that size, not dozens);
+    PGX_LOOK_AHEAD_FRAMES pins the cap for every graph."""
+    from pygmu2_amd import look_ahead
+    monkeypatch.setattr(look_ahead, "_FRAMES_EXPLICIT", False)
+    base, small = look_ahead.AHEAD_FRAMES, look_ahead.AHEAD_FRAMES_SMALL_GRAPH
+    assert look_ahead.frame_cap(1) == look_ahead.frame_cap(2) == max(base, small)
+    assert look_ahead.frame_cap(3) == look_ahead.frame_cap(4) == max(base, small // 2)
+    assert look_ahead.frame_cap(5) == look_ahead.frame_cap(500) == base
+    monkeypatch.setattr(look_ahead, "_FRAMES_EXPLICIT", True)
+    assert look_ahead.frame_cap(1) == base
+
+
+def test_settle_frames_fine_is_the_first_multiple_of_16_that_settles():
+    """The on-chip mix's warm-up: the smallest multiple of 16 frames W with every entry of A^W below 2^-90 -- never above
+    settle_frames' power of two, 0 where the section does not settle within the limit."""
+    import numpy as np
+    from pygmu2_amd.biquad_pe import BiquadMode, rbj_coefficients, settle_frames, settle_frames_fine
+    for f, q in ((2000.0, 0.707), (500.0, 2.0), (8000.0, 0.5), (120.0, 0.9)):
+        c = rbj_coefficients(BiquadMode.LOWPASS, f, q, 0.0, 48000)
+        w, w2 = settle_frames_fine(c[3], c[4]), settle_frames(c[3], c[4])
+        if w:
+            a = np.array([[-c[3], 1.0], [-c[4], 0.0]])
+            assert w % 16 == 0 and 0 < w <= 2048 and (not w2 or w <= w2)
+            assert np.all(np.abs(np.linalg.matrix_power(a, w)) < 2.0 ** -90)
+            assert not np.all(np.abs(np.linalg.matrix_power(a, w - 16)) < 2.0 ** -90)
+    ringing = rbj_coefficients(BiquadMode.LOWPASS, 500.0, 400.0, 0.0, 48000)
+    assert settle_frames_fine(ringing[3], ringing[4]) == 0
